@@ -1,0 +1,122 @@
+/* gfft.h -- C ABI of libgfft.so, the MI355X (gfx950) engine behind the PFFT hot path.
+ *
+ * Drop-in boundary: these entry points are what mpi4py-fft's native layer binds today
+ * (Cython `fftw_xfftn.FFT` over `fftw_planxfftn`, plus what MPI's datatype engine does inside
+ * `Alltoallw`), re-expressed for device memory:
+ *
+ *   gfft_plan_create    <- fftw_planxfftn()            mpi4py_fft/fftw/fftw_planxfftn.h:9-17, .c:10-77
+ *   gfft_execute        <- fftw_execute_dft{,_r2c,_c2r}  mpi4py_fft/fftw/fftw_xfftn.pyx:29-48,291-292
+ *   gfft_plan_destroy   <- fftw_destroy_plan()         mpi4py_fft/fftw/fftw_xfftn.pyx:162-163
+ *   gfft_plan_describe  <- fftw_print_plan()           mpi4py_fft/fftw/fftw_xfftn.pyx:173-175
+ *   gfft_pack/unpack    <- Create_subarray + Alltoallw's pack/unpack   mpi4py_fft/pencil.py:12-29,182,200
+ *   gfft_truncate/pad   <- FFTBase._truncation_forward/_padding_backward  mpi4py_fft/libfft.py:263-311
+ *   gfft_scale          <- `output_array *= M`         mpi4py_fft/libfft.py:412-413, fftw_xfftn.pyx:293-294
+ *
+ * Conventions: every function returns 0 (GFFT_OK) or a negative gfft_status; nothing throws
+ * across the ABI.  All pointers named d_* are DEVICE pointers, borrowed (never owned or freed by
+ * the library).  All work is enqueued asynchronously on `stream` (a hipStream_t passed as void*;
+ * NULL = the default stream).  Sizes and strides are 64-bit (the reference's C planner uses
+ * `int`, fftw_planxfftn.c:11-22; 1024^3 is its edge).  Arrays are C-contiguous (row-major), the
+ * only layout the reference plans for (fftw_planxfftn.c:25-30).  Caller is single-threaded per
+ * plan.  No host fallback exists: without a HIP device every compute entry point returns
+ * GFFT_ERR_NO_DEVICE.
+ */
+#ifndef GFFT_H
+#define GFFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gfft_plan_s *gfft_plan;
+
+typedef enum {
+  GFFT_OK = 0,
+  GFFT_ERR_INVALID = -1,     /* bad argument (shape/axes/kind mismatch)                */
+  GFFT_ERR_UNSUPPORTED = -2, /* valid request the engine cannot plan (e.g. huge prime) */
+  GFFT_ERR_NO_DEVICE = -3,   /* no HIP device / HIP runtime failure at init            */
+  GFFT_ERR_HIP = -4,         /* a HIP call failed; see gfft_last_error()               */
+  GFFT_ERR_NOMEM = -5
+} gfft_status;
+
+/* transform kinds: same integers as the reference (fftw_planxfftn.c:3-8, utilities.pyx:7-26) */
+enum { GFFT_C2C_FORWARD = -1, GFFT_C2C_BACKWARD = +1, GFFT_R2C = -2, GFFT_C2R = +2 };
+/* precision of the real type: float (fftwf_* clone, setup.py:93-111) or double */
+enum { GFFT_F32 = 4, GFFT_F64 = 8 };
+
+const char *gfft_strerror(int status);
+const char *gfft_last_error(void);          /* detail of the last failure on this thread */
+int gfft_version(void);
+int gfft_device_count(int *count);          /* hipGetDeviceCount; GFFT_ERR_NO_DEVICE if none */
+int gfft_device_name(int device, char *buf, size_t len);
+/* tunables consulted when a plan is created: "grid_cap", "variant_rows", "variant_cols",
+ * "force_generic" (also readable from the environment as GFFT_<UPPERCASE NAME>) */
+int gfft_set_option(const char *key, int value);
+
+/* ---- serial multi-axis transform plan ------------------------------------------------
+ * Same decomposition as fftw_planxfftn(): transform dims = `axes` (executed last-listed axis
+ * first; for R2C/C2R the halved axis is axes[naxes-1], xfftn.py:231-232,309-315), every other
+ * dim is a batch dim.  sizes_in/sizes_out are the full array shapes (they differ only along
+ * axes[naxes-1] for R2C/C2R: n vs n/2+1).  R2C/C2R logical length n is taken from the real
+ * side, as fftw_planxfftn.c:23 does.  */
+int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const int64_t *sizes_out,
+                     int naxes, const int *axes, int kind, int precision);
+/* out = scale * DFT(in).  d_in == d_out is allowed for C2C.  C2C out-of-place preserves the
+ * input; C2R with naxes > 1 overwrites it (as FFTW does).  */
+int gfft_execute(gfft_plan plan, const void *d_in, void *d_out, double scale, void *stream);
+int gfft_plan_destroy(gfft_plan plan);
+int gfft_plan_describe(gfft_plan plan, char *buf, size_t len);
+/* flops (5 n log2 n per line, half for real) and algorithmic bytes (one read + one write of
+ * the array per 1-D pass) of one execute, and the number of kernel launches it issues */
+int gfft_plan_cost(gfft_plan plan, double *flops, double *bytes, int *launches);
+
+/* ---- global-redistribution helpers (what Alltoallw's datatype engine does) ------------
+ * An array of shape `shape[ndims]` is cut along `axis` into `nparts` blocks by the reference's
+ * block rule (pencil.py:5-9).  pack: block i is copied, in row-major order of the sub-block, to
+ * d_packed + offset_i (offset_i = itemsize * prod(other dims) * start_i), i.e. the send buffer of
+ * an all-to-all.  unpack is the inverse (receive buffer -> array).  itemsize in bytes (4,8,16). */
+int gfft_pack(const void *d_array, void *d_packed, int ndims, const int64_t *shape, int axis,
+              int nparts, int itemsize, void *stream);
+int gfft_unpack(const void *d_packed, void *d_array, int ndims, const int64_t *shape, int axis,
+                int nparts, int itemsize, void *stream);
+
+/* ---- 3/2-rule truncation / padding along one axis (libfft.py:263-311) ------------------
+ * shapes differ only along `axis` (n_padded vs n_trunc entries).  is_real: the axis is the
+ * Hermitian half-axis of an r2c transform.  Element type complex<precision>.  `scale` is applied
+ * to every written element (fuses `*= M`).  */
+int gfft_truncate(const void *d_padded, void *d_trunc, int ndims, const int64_t *shape_padded,
+                  int axis, int64_t n_trunc, int is_real, int precision, double scale, void *stream);
+int gfft_pad(const void *d_trunc, void *d_padded, int ndims, const int64_t *shape_padded,
+             int axis, int64_t n_trunc, int is_real, int precision, void *stream);
+
+/* d_data[i] *= scale for `count` real scalars of the given precision */
+int gfft_scale(void *d_data, int64_t count, int precision, double scale, void *stream);
+
+/* ---- raw device helpers for non-torch hosts (the Python host uses torch for these) ---- */
+int gfft_malloc(void **d_ptr, size_t bytes);
+int gfft_free(void *d_ptr);
+int gfft_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int gfft_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int gfft_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
+int gfft_stream_synchronize(void *stream);
+
+/* ---- measurement helpers used by bench.py (HIP events on the launch stream) ------------ */
+int gfft_event_create(void **event);
+int gfft_event_record(void *event, void *stream);
+int gfft_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on `stop` */
+int gfft_event_destroy(void *event);
+/* streaming-copy probe: dst[i] = src[i] over `bytes` (multiple of 16); the HBM ceiling quoted
+ * beside roofline numbers */
+int gfft_probe_copy(const void *d_src, void *d_dst, size_t bytes, void *stream);
+/* strided-tile copy probe: the access pattern of a column pass without the arithmetic:
+ * array [outer][n][inner] of 16-byte elements, tiles of `tcols` consecutive inner elements */
+int gfft_probe_tile_copy(const void *d_src, void *d_dst, int64_t outer, int64_t n, int64_t inner,
+                         int tcols, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFFT_H */

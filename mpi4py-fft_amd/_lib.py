@@ -1,0 +1,194 @@
+"""ctypes binding of libgfft.so (include/gfft.h) and the engine object the host classes call.
+
+There is exactly one product engine: :class:`HipEngine`, a thin veneer over the C ABI.  It has no
+host fallback -- if the shared library is missing or no HIP device is visible every compute call
+raises.  ``set_engine`` exists so that CPU-only unit tests of the *host logic* (pencil arithmetic,
+exchange plans, gloo all-to-all) can inject a checker engine from tests/; nothing in this package
+ever selects another engine on its own.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(_HERE, 'libgfft.so')
+
+C2C_FORWARD, C2C_BACKWARD, R2C, C2R = -1, 1, -2, 2
+
+_lib = None
+
+
+class GfftError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    c = ctypes
+    i64p = c.POINTER(c.c_int64)
+    ip = c.POINTER(c.c_int)
+    vp = c.c_void_p
+    sigs = {
+        'gfft_strerror': (c.c_char_p, [c.c_int]),
+        'gfft_last_error': (c.c_char_p, []),
+        'gfft_version': (c.c_int, []),
+        'gfft_device_count': (c.c_int, [ip]),
+        'gfft_device_name': (c.c_int, [c.c_int, c.c_char_p, c.c_size_t]),
+        'gfft_set_option': (c.c_int, [c.c_char_p, c.c_int]),
+        'gfft_plan_create': (c.c_int, [c.POINTER(vp), c.c_int, i64p, i64p, c.c_int, ip, c.c_int, c.c_int]),
+        'gfft_execute': (c.c_int, [vp, vp, vp, c.c_double, vp]),
+        'gfft_plan_destroy': (c.c_int, [vp]),
+        'gfft_plan_describe': (c.c_int, [vp, c.c_char_p, c.c_size_t]),
+        'gfft_plan_cost': (c.c_int, [vp, c.POINTER(c.c_double), c.POINTER(c.c_double), ip]),
+        'gfft_pack': (c.c_int, [vp, vp, c.c_int, i64p, c.c_int, c.c_int, c.c_int, vp]),
+        'gfft_unpack': (c.c_int, [vp, vp, c.c_int, i64p, c.c_int, c.c_int, c.c_int, vp]),
+        'gfft_truncate': (c.c_int, [vp, vp, c.c_int, i64p, c.c_int, c.c_int64, c.c_int, c.c_int, c.c_double, vp]),
+        'gfft_pad': (c.c_int, [vp, vp, c.c_int, i64p, c.c_int, c.c_int64, c.c_int, c.c_int, vp]),
+        'gfft_scale': (c.c_int, [vp, c.c_int64, c.c_int, c.c_double, vp]),
+        'gfft_malloc': (c.c_int, [c.POINTER(vp), c.c_size_t]),
+        'gfft_free': (c.c_int, [vp]),
+        'gfft_memcpy_h2d': (c.c_int, [vp, vp, c.c_size_t, vp]),
+        'gfft_memcpy_d2h': (c.c_int, [vp, vp, c.c_size_t, vp]),
+        'gfft_memcpy_d2d': (c.c_int, [vp, vp, c.c_size_t, vp]),
+        'gfft_stream_synchronize': (c.c_int, [vp]),
+        'gfft_event_create': (c.c_int, [c.POINTER(vp)]),
+        'gfft_event_record': (c.c_int, [vp, vp]),
+        'gfft_event_elapsed_ms': (c.c_int, [vp, vp, c.POINTER(c.c_float)]),
+        'gfft_event_destroy': (c.c_int, [vp]),
+        'gfft_probe_copy': (c.c_int, [vp, vp, c.c_size_t, vp]),
+        'gfft_probe_tile_copy': (c.c_int, [vp, vp, c.c_int64, c.c_int64, c.c_int64, c.c_int, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return sigs
+
+
+EXPORTS = None
+
+
+def lib():
+    """The loaded shared library; raises if it has not been built."""
+    global _lib, EXPORTS
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise ImportError(
+                "libgfft.so is not built (%s). Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C mpi4py-fft_amd/csrc`. There is no CPU fallback." % LIBPATH)
+        _lib = ctypes.CDLL(LIBPATH)
+        EXPORTS = _declare(_lib)
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        l = lib()
+        raise GfftError('%s: %s' % (l.gfft_strerror(rc).decode(), l.gfft_last_error().decode()))
+
+
+def _i64(seq):
+    return (ctypes.c_int64 * len(seq))(*[int(s) for s in seq])
+
+
+def current_stream():
+    """hipStream_t of torch's current stream (torch owns device memory and streams here)."""
+    import torch
+    if torch.cuda.is_available():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(0)
+
+
+def precision_of(dtype):
+    return 8 if np.dtype(dtype).char in 'dD' else 4
+
+
+class HipEngine:
+    """The product engine: every method is one call through the C ABI."""
+    name = 'hip'
+
+    def require_device(self, tensor):
+        if tensor.device.type != 'cuda':
+            raise GfftError('array lives on %s: libgfft runs on HIP device memory only '
+                            '(no CPU fallback)' % tensor.device)
+
+    def plan_create(self, sizes_in, sizes_out, axes, kind, precision):
+        h = ctypes.c_void_p()
+        ax = (ctypes.c_int * len(axes))(*[int(a) for a in axes])
+        check(lib().gfft_plan_create(ctypes.byref(h), len(sizes_in), _i64(sizes_in), _i64(sizes_out),
+                                     len(axes), ax, int(kind), int(precision)))
+        return h
+
+    def plan_execute(self, h, tin, tout, scale):
+        self.require_device(tin)
+        self.require_device(tout)
+        check(lib().gfft_execute(h, tin.data_ptr(), tout.data_ptr(), float(scale), current_stream()))
+
+    def plan_destroy(self, h):
+        if h is not None and _lib is not None:
+            _lib.gfft_plan_destroy(h)
+
+    def plan_describe(self, h):
+        buf = ctypes.create_string_buffer(4096)
+        check(lib().gfft_plan_describe(h, buf, 4096))
+        return buf.value.decode()
+
+    def plan_cost(self, h):
+        f, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        check(lib().gfft_plan_cost(h, ctypes.byref(f), ctypes.byref(b), ctypes.byref(n)))
+        return f.value, b.value, n.value
+
+    def pack(self, tarray, tpacked, shape, axis, nparts, itemsize):
+        self.require_device(tarray)
+        check(lib().gfft_pack(tarray.data_ptr(), tpacked.data_ptr(), len(shape), _i64(shape), axis,
+                              nparts, itemsize, current_stream()))
+
+    def unpack(self, tpacked, tarray, shape, axis, nparts, itemsize):
+        self.require_device(tarray)
+        check(lib().gfft_unpack(tpacked.data_ptr(), tarray.data_ptr(), len(shape), _i64(shape), axis,
+                                nparts, itemsize, current_stream()))
+
+    def truncate(self, tpadded, ttrunc, shape_padded, axis, n_trunc, is_real, precision, scale):
+        self.require_device(tpadded)
+        check(lib().gfft_truncate(tpadded.data_ptr(), ttrunc.data_ptr(), len(shape_padded),
+                                  _i64(shape_padded), axis, n_trunc, int(is_real), precision,
+                                  float(scale), current_stream()))
+
+    def pad(self, ttrunc, tpadded, shape_padded, axis, n_trunc, is_real, precision):
+        self.require_device(tpadded)
+        check(lib().gfft_pad(ttrunc.data_ptr(), tpadded.data_ptr(), len(shape_padded),
+                             _i64(shape_padded), axis, n_trunc, int(is_real), precision,
+                             current_stream()))
+
+    def scale(self, t, count, precision, scale):
+        self.require_device(t)
+        check(lib().gfft_scale(t.data_ptr(), count, precision, float(scale), current_stream()))
+
+    def copy(self, tsrc, tdst):
+        self.require_device(tsrc)
+        check(lib().gfft_memcpy_d2d(tdst.data_ptr(), tsrc.data_ptr(),
+                                    tsrc.numel() * tsrc.element_size(), current_stream()))
+
+
+_engine = HipEngine()
+
+
+def engine():
+    return _engine
+
+
+def set_engine(e):
+    """TEST SEAM ONLY (see module docstring).  Returns the previous engine."""
+    global _engine
+    old, _engine = _engine, (e if e is not None else HipEngine())
+    return old
+
+
+def set_option(key, value):
+    check(lib().gfft_set_option(key.encode(), int(value)))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    rc = lib().gfft_device_count(ctypes.byref(n))
+    return n.value if rc == 0 else 0

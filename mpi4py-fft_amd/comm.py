@@ -1,0 +1,267 @@
+"""Minimal communicator layer: the handful of MPI operations the PFFT path needs
+(SURVEY.md Appendix B), provided over ``torch.distributed`` -- backend "nccl" (= RCCL over xGMI)
+on GPUs, "gloo" on CPUs -- or, for a single process, by a trivial self-communicator.
+
+Replaces, for this path, what the reference gets from mpi4py: ``Get_size/Get_rank``,
+``Compute_dims``, ``Create_cart`` + ``Sub`` (pencil.py:64-93) and the exchange inside
+``Alltoallw`` (pencil.py:182,200).  One process per GPU; ranks are row-major over the Cartesian
+grid and the rank inside a sub-communicator is the grid coordinate, as MPI_Cart_create /
+MPI_Cart_sub give.
+"""
+import itertools
+import os
+
+import numpy as np
+
+CART = 1
+UNDEFINED = -32766
+
+
+def Compute_dims(nnodes, dims):
+    """MPI_Dims_create as MPICH computes it: zero entries become a balanced, non-increasing
+    factorisation of ``nnodes / prod(non-zero entries)``.  Restates what ``MPI.Compute_dims``
+    returns at pencil.py:79 (pinned by tests/golden/geometry.npz)."""
+    dims = [0] * int(dims) if np.ndim(dims) == 0 else [max(0, int(d)) for d in dims]
+    fixed = 1
+    for d in dims:
+        if d > 0:
+            fixed *= d
+    assert nnodes % fixed == 0, 'grid %s does not divide %d ranks' % (dims, nnodes)
+    rest, primes, p = nnodes // fixed, [], 2
+    while rest > 1:
+        while rest % p == 0:
+            primes.append(p)
+            rest //= p
+        p += 1
+    free = [1] * dims.count(0)
+    for q in sorted(primes, reverse=True):
+        free[free.index(min(free))] *= q
+    free = iter(sorted(free, reverse=True))
+    return [d if d > 0 else next(free) for d in dims]
+
+
+class Comm:
+    """Interface (duck-typed like an mpi4py communicator where the reference touches one)."""
+    _topo = None
+
+    def Get_size(self):
+        raise NotImplementedError
+
+    def Get_rank(self):
+        raise NotImplementedError
+
+    size = property(lambda self: self.Get_size())
+    rank = property(lambda self: self.Get_rank())
+
+    def Is_inter(self):
+        return False
+
+    def Get_topology(self):
+        return CART if self._topo is not None else UNDEFINED
+
+    def Get_dim(self):
+        return len(self._topo[0])
+
+    def Free(self):
+        pass
+
+    def __bool__(self):
+        return True
+
+    # -- topology
+    def Create_cart(self, dims, periods=None, reorder=False):
+        dims = tuple(int(d) for d in dims)
+        assert int(np.prod(dims)) == self.Get_size(), (dims, self.Get_size())
+        return _CartView(self, dims)
+
+    # -- collectives on python objects (tests / reporting)
+    def bcast(self, obj, root=0):
+        return obj
+
+    def allreduce_max(self, x):
+        return x
+
+    def allgather_obj(self, obj):
+        return [obj]
+
+    def barrier(self):
+        pass
+
+    Barrier = barrier
+
+    def alltoall(self, send, recv, send_counts, recv_counts):
+        """Exchange contiguous blocks: block i of `send` (send_counts[i] elements) goes to rank i;
+        block j of `recv` (recv_counts[j] elements) comes from rank j.  1-D real-typed tensors."""
+        raise NotImplementedError
+
+
+class SelfComm(Comm):
+    _count = itertools.count()
+
+    def __init__(self):
+        self._id = ('self',)
+
+    def Get_size(self):
+        return 1
+
+    def Get_rank(self):
+        return 0
+
+    def __eq__(self, other):
+        return isinstance(other, Comm) and other.Get_size() == 1
+
+    def __hash__(self):
+        return 7
+
+    def alltoall(self, send, recv, send_counts, recv_counts):
+        recv.copy_(send)
+
+
+COMM_SELF = SelfComm()
+
+
+class TorchComm(Comm):
+    """A ``torch.distributed`` process group.  `ranks` = world ranks in group-rank order."""
+    _groups = {}   # tuple(world ranks) -> ProcessGroup (new_group is collective over the world)
+
+    def __init__(self, ranks=None, key=None):
+        import torch.distributed as dist
+        assert dist.is_initialized(), 'torch.distributed is not initialised'
+        self._dist = dist
+        self._world_rank = dist.get_rank()
+        self._ranks = tuple(range(dist.get_world_size())) if ranks is None else tuple(ranks)
+        self._key = key if key is not None else ('world',)
+        self._pg = None if ranks is None else TorchComm._groups[self._ranks]
+
+    def Get_size(self):
+        return len(self._ranks)
+
+    def Get_rank(self):
+        return self._ranks.index(self._world_rank)
+
+    def __eq__(self, other):
+        if isinstance(other, TorchComm):
+            return self._ranks == other._ranks
+        return isinstance(other, Comm) and self.Get_size() == 1 and other.Get_size() == 1
+
+    def __hash__(self):
+        return hash(self._ranks)
+
+    @classmethod
+    def ensure_group(cls, ranks):
+        """Collective over the WORLD: every process must call this for every group, same order."""
+        import torch.distributed as dist
+        ranks = tuple(ranks)
+        if ranks not in cls._groups:
+            cls._groups[ranks] = dist.new_group(list(ranks))
+        return cls._groups[ranks]
+
+    def bcast(self, obj, root=0):
+        box = [obj]
+        self._dist.broadcast_object_list(box, src=self._ranks[root], group=self._pg)
+        return box[0]
+
+    def allgather_obj(self, obj):
+        out = [None] * self.Get_size()
+        self._dist.all_gather_object(out, obj, group=self._pg)
+        return out
+
+    def allreduce_max(self, x):
+        return max(self.allgather_obj(x))
+
+    def barrier(self):
+        self._dist.barrier(group=self._pg)
+
+    Barrier = barrier
+
+    def alltoall(self, send, recv, send_counts, recv_counts):
+        if self.Get_size() == 1:
+            recv.copy_(send)
+            return
+        self._dist.all_to_all_single(recv, send, [int(c) for c in recv_counts],
+                                     [int(c) for c in send_counts], group=self._pg)
+
+
+class _CartView(Comm):
+    """Cartesian topology over a parent communicator (row-major rank order)."""
+    def __init__(self, parent, dims):
+        self._parent = parent
+        self._dims = dims
+        self._coords = tuple(int(c) for c in np.unravel_index(parent.Get_rank(), dims))
+        self._topo = (dims, self._coords)
+
+    def Get_size(self):
+        return self._parent.Get_size()
+
+    def Get_rank(self):
+        return self._parent.Get_rank()
+
+    def __eq__(self, other):
+        return isinstance(other, _CartView) and self._parent == other._parent and self._dims == other._dims
+
+    def __hash__(self):
+        return hash((hash(self._parent), self._dims))
+
+    def Sub(self, remdims):
+        """Sub-communicator keeping the grid dims flagged in `remdims` (MPI_Cart_sub)."""
+        remdims = tuple(bool(r) for r in remdims)
+        dims, me = self._dims, self._coords
+        if isinstance(self._parent, SelfComm) or self.Get_size() == 1:
+            return COMM_SELF
+        parent_ranks = self._parent._ranks
+        mine = None
+        fixed_axes = [i for i, r in enumerate(remdims) if not r]
+        # every process creates every group of this family, in the same (lexicographic) order
+        for fixed in itertools.product(*[range(dims[i]) for i in fixed_axes]):
+            members = []
+            for r in range(len(parent_ranks)):
+                c = np.unravel_index(r, dims)
+                if all(c[a] == f for a, f in zip(fixed_axes, fixed)):
+                    members.append(parent_ranks[r])
+            if len(members) > 1:
+                TorchComm.ensure_group(members)
+            if all(me[a] == f for a, f in zip(fixed_axes, fixed)):
+                mine = tuple(members)
+        if len(mine) == 1:
+            return COMM_SELF
+        return TorchComm(mine, key=('sub', dims, remdims))
+
+    def alltoall(self, *a):
+        return self._parent.alltoall(*a)
+
+    def bcast(self, obj, root=0):
+        return self._parent.bcast(obj, root)
+
+    def barrier(self):
+        self._parent.barrier()
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE /
+    LOCAL_RANK / MASTER_*), one process per GPU, and return the world communicator.
+    Single-process runs get the self communicator."""
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1 and 'RANK' not in os.environ:
+        return COMM_SELF
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group(backend)
+    return TorchComm()
+
+
+def world():
+    """COMM_WORLD analogue: the torch.distributed world if initialised, else COMM_SELF."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return TorchComm()
+    except Exception:
+        pass
+    return COMM_SELF

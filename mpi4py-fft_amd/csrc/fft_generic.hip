@@ -1,0 +1,177 @@
+// Generic any-length 1-D pass: LDS-resident mixed-radix Stockham (radices from a runtime factor
+// list; 2/3/4 unrolled, any other prime by its O(r^2) definition).  This is the completeness
+// path (odd sizes, primes, ragged tiles); power-of-two lengths take fft_pow2_impl.h instead.
+//
+// One workgroup = one tile of T columns; two ping-pong LDS buffers of T*n complex each.
+// Loads/stores run with lanes along whichever of (element, column) is unit-stride in memory.
+#include "gfft_internal.h"
+#include "pass_io.h"
+
+namespace gfft {
+
+constexpr int GEN_THREADS = 256;
+
+template <typename real>
+__device__ __forceinline__ void generic_butterfly(const cx<real> *__restrict__ X, cx<real> *__restrict__ Y,
+                                                  int j, int r, int Ns, int n,
+                                                  const cx<real> *__restrict__ tw) {
+  const int m = n / r;
+  const int k = j % Ns;
+  const int j0 = (j / Ns) * Ns * r + k;
+  const int tstep = n / (Ns * r);  // twiddle-table stride of W_{Ns*r}
+  if (r == 2) {
+    cx<real> a = X[j], b = X[j + m];
+    if (k) b = cmul(b, tw[k * tstep]);
+    Y[j0] = a + b;
+    Y[j0 + Ns] = a - b;
+  } else if (r == 4) {
+    cx<real> a0 = X[j], a1 = X[j + m], a2 = X[j + 2 * m], a3 = X[j + 3 * m];
+    if (k) {
+      a1 = cmul(a1, tw[k * tstep]);
+      a2 = cmul(a2, tw[2 * k * tstep]);
+      a3 = cmul(a3, tw[3 * k * tstep]);
+    }
+    cx<real> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mi(a1 - a3);
+    Y[j0] = t0 + t2;
+    Y[j0 + Ns] = t1 + t3;
+    Y[j0 + 2 * Ns] = t0 - t2;
+    Y[j0 + 3 * Ns] = t1 - t3;
+  } else if (r == 3) {
+    cx<real> a = X[j], b = X[j + m], c = X[j + 2 * m];
+    if (k) {
+      b = cmul(b, tw[k * tstep]);
+      c = cmul(c, tw[2 * k * tstep]);
+    }
+    const real h = (real)0.86602540378443864676372317075294;  // sqrt(3)/2
+    cx<real> t1 = b + c;
+    cx<real> t2 = {a.x - (real)0.5 * t1.x, a.y - (real)0.5 * t1.y};
+    cx<real> t3 = {(b.x - c.x) * h, (b.y - c.y) * h};
+    Y[j0] = a + t1;
+    Y[j0 + Ns] = {t2.x + t3.y, t2.y - t3.x};
+    Y[j0 + 2 * Ns] = {t2.x - t3.y, t2.y + t3.x};
+  } else {
+    // y[p] = sum_q x[q] * W_{Ns r}^{q k} * W_r^{p q}
+    const int rstep = n / r;
+    for (int p = 0; p < r; ++p) {
+      cx<real> acc = {0, 0};
+      int pq = 0;  // (p*q) mod r
+      for (int q = 0; q < r; ++q) {
+        cx<real> x = X[j + q * m];
+        int ti = q * k * tstep + pq * rstep;  // < 2n
+        if (ti >= n) ti -= n;
+        x = cmul(x, tw[ti]);
+        acc = acc + x;
+        pq += p;
+        if (pq >= r) pq -= r;
+      }
+      Y[j0 + p * Ns] = acc;
+    }
+  }
+}
+
+template <typename real>
+__global__ void __launch_bounds__(GEN_THREADS)
+fft_generic_kernel(PassDesc d, Factors f, int T, const void *__restrict__ in, void *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n = d.n;
+  cx<real> *X = reinterpret_cast<cx<real> *>(smem);
+  cx<real> *Y = X + (size_t)T * n;
+  int64_t *colbase = reinterpret_cast<int64_t *>(Y + (size_t)T * n);  // [3][T]: in, out, mid
+  const cx<real> *tw = reinterpret_cast<const cx<real> *>(d.tw);
+  const int tid = threadIdx.x;
+
+  for (int64_t tile = blockIdx.x; tile * T < d.batch; tile += gridDim.x) {
+    const int64_t b0 = tile * T;
+    const int ncols = (int)((d.batch - b0) < (int64_t)T ? (d.batch - b0) : (int64_t)T);
+    __syncthreads();
+    if (tid < ncols) {
+      ColAddr a = column_address(d, b0 + tid);
+      colbase[tid] = a.in;
+      colbase[T + tid] = a.out;
+      colbase[2 * T + tid] = a.mid;
+    }
+    __syncthreads();
+    // ---- load
+    const int nin = n;  // every logical element is materialised (r2c: imag 0; c2r: Hermitian mirror)
+    const int total = ncols * nin;
+    if (d.in_es == 1 || ncols == 1) {
+      for (int idx = tid; idx < total; idx += GEN_THREADS) {
+        int c = idx / nin, e = idx - c * nin;
+        X[c * n + e] = load_elem<real>(d, in, colbase[c], e);
+      }
+    } else {
+      for (int idx = tid; idx < total; idx += GEN_THREADS) {
+        int e = idx / ncols, c = idx - e * ncols;
+        X[c * n + e] = load_elem<real>(d, in, colbase[c], e);
+      }
+    }
+    __syncthreads();
+    // ---- Stockham stages
+    cx<real> *A = X, *B = Y;
+    int Ns = 1;
+    for (int s = 0; s < f.count; ++s) {
+      const int r = f.r[s];
+      const int m = n / r;
+      const int work = ncols * m;
+      for (int idx = tid; idx < work; idx += GEN_THREADS) {
+        int c = idx / m, j = idx - c * m;
+        generic_butterfly<real>(A + c * n, B + c * n, j, r, Ns, n, tw);
+      }
+      __syncthreads();
+      cx<real> *t = A;
+      A = B;
+      B = t;
+      Ns *= r;
+    }
+    // ---- store
+    const int nout = (d.mode == MODE_R2C) ? n / 2 + 1 : n;
+    const int stotal = ncols * nout;
+    if (d.out_es == 1 || ncols == 1) {
+      for (int idx = tid; idx < stotal; idx += GEN_THREADS) {
+        int c = idx / nout, e = idx - c * nout;
+        store_elem<real>(d, out, colbase[T + c], e, colbase[2 * T + c], A[c * n + e]);
+      }
+    } else {
+      for (int idx = tid; idx < stotal; idx += GEN_THREADS) {
+        int e = idx / ncols, c = idx - e * ncols;
+        store_elem<real>(d, out, colbase[T + c], e, colbase[2 * T + c], A[c * n + e]);
+      }
+    }
+  }
+}
+
+int generic_max_n(int precision) { return precision == 8 ? 4096 : 8192; }
+
+template <typename real>
+static hipError_t launch_generic_t(const PassDesc &d, const Factors &f, const void *in, void *out,
+                                   hipStream_t s) {
+  const size_t esz = sizeof(cx<real>);
+  // columns per tile: aim for ~32 KiB per ping-pong buffer, at least 1, at most 64
+  int T = (int)((32 * 1024) / ((size_t)d.n * esz));
+  if (T < 1) T = 1;
+  if (T > 64) T = 64;
+  if ((int64_t)T > d.batch) T = (int)d.batch;
+  // keep the chip busy: prefer >= 1024 tiles when the batch allows
+  while (T > 8 && (d.batch + T - 1) / T < 1024) T /= 2;
+  size_t lds = 2 * (size_t)T * d.n * esz + 3 * (size_t)T * sizeof(int64_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_generic_kernel<real>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  int64_t tiles = (d.batch + T - 1) / T;
+  int grid = (int)(tiles < 4096 ? tiles : 4096);
+  hipLaunchKernelGGL(fft_generic_kernel<real>, dim3(grid), dim3(GEN_THREADS), lds, s, d, f, T, in, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_generic(const PassDesc &d, const Factors &f, int precision, const void *in,
+                          void *out, hipStream_t s) {
+  if (d.batch <= 0) return hipSuccess;
+  if (precision == 8) return launch_generic_t<double>(d, f, in, out, s);
+  return launch_generic_t<float>(d, f, in, out, s);
+}
+
+}  // namespace gfft

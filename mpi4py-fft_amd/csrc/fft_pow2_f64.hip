@@ -1,0 +1,63 @@
+// fp64 (complex128) instantiations of the power-of-two pass kernels.
+//
+// Plan table (R = elements per thread, T = columns per workgroup, radices per stage):
+// R = 8 keeps a thread at <= 128 VGPRs (32 for data), so 16 waves/CU stay resident; R = 16
+// variants (256 VGPRs, fewer exchanges) exist for N = 1024 as measurable alternatives
+// (`variant` argument; see DESIGN.md for the A/B numbers that picked the default).
+#include "fft_pow2_impl.h"
+
+namespace gfft {
+
+//                 real    N  R  T  COLS  SPLIT MINW radices
+#define P64(N, R, T, COLS, MINW, ...) \
+  launch_pow2_inst<double, N, R, T, COLS, true, MINW, __VA_ARGS__>(d, in, out, s)
+
+bool pow2_supported_f64(int n) { return n >= 16 && n <= 4096 && (n & (n - 1)) == 0; }
+
+hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void *in, void *out,
+                           hipStream_t s) {
+  if (!cols) {
+    switch (d.n) {
+      case 16: return P64(16, 4, 16, false, 1, 4, 4);
+      case 32: return P64(32, 8, 16, false, 1, 8, 4);
+      case 64: return P64(64, 8, 8, false, 1, 8, 8);
+      case 128: return P64(128, 8, 4, false, 1, 8, 8, 2);
+      case 256: return P64(256, 8, 2, false, 1, 8, 8, 4);
+      case 512: return P64(512, 8, 1, false, 1, 8, 8, 8);
+      case 1024:
+        switch (variant) {
+          default: return P64(1024, 8, 1, false, 1, 8, 8, 8, 2);
+          case 1: return P64(1024, 8, 2, false, 1, 8, 8, 8, 2);
+          case 2: return P64(1024, 16, 1, false, 1, 16, 16, 4);
+          case 3: return P64(1024, 16, 4, false, 1, 16, 16, 4);
+        }
+      case 2048: return P64(2048, 8, 1, false, 1, 8, 8, 8, 4);
+      case 4096: return P64(4096, 8, 1, false, 1, 8, 8, 8, 8);
+    }
+  } else {
+    switch (d.n) {
+      case 16: return P64(16, 4, 16, true, 1, 4, 4);
+      case 32: return P64(32, 8, 16, true, 1, 8, 4);
+      case 64: return P64(64, 8, 8, true, 1, 8, 8);
+      case 128: return P64(128, 8, 8, true, 1, 8, 8, 2);
+      case 256: return P64(256, 8, 8, true, 1, 8, 8, 4);
+      case 512:
+        switch (variant) {
+          default: return P64(512, 8, 8, true, 1, 8, 8, 8);
+          case 1: return P64(512, 8, 4, true, 1, 8, 8, 8);
+        }
+      case 1024:
+        switch (variant) {
+          default: return P64(1024, 8, 4, true, 1, 8, 8, 8, 2);
+          case 1: return P64(1024, 8, 8, true, 1, 8, 8, 8, 2);
+          case 2: return P64(1024, 16, 8, true, 1, 16, 16, 4);
+          case 3: return P64(1024, 16, 4, true, 1, 16, 16, 4);
+        }
+      case 2048: return P64(2048, 8, 4, true, 1, 8, 8, 8, 4);
+      case 4096: return P64(4096, 8, 2, true, 1, 8, 8, 8, 8);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace gfft

@@ -1,0 +1,356 @@
+// Power-of-two 1-D pass for gfx950: register-resident Stockham with LDS exchange.
+//
+// A workgroup owns a tile of T columns of length N.  Each thread keeps R elements of one column
+// in VGPRs for the whole pass (element slots e = t + q*N/R, q < R: the constant-geometry read
+// side of Stockham), runs radix-16/8/4/2 butterflies on them, and between stages scatters
+// through LDS (autosort write side) and reads its slots back.  First-stage inputs come straight
+// from HBM, last-stage outputs go straight to HBM, so a pass reads and writes the array once.
+//
+//   ROWS kernel: lanes run along the transform axis (contiguous rows, 16 B/lane coalesced).
+//   COLS kernel: lanes run along T adjacent columns (T*sizeof(complex) = 128 B segments), the
+//                transform axis is strided: no transposes anywhere in a 3-D transform.
+//
+// LDS exchange is either SPLIT (real plane, then imaginary plane: halves the footprint, e.g.
+// 2 workgroups/CU at fp64 N=1024 T=8) or whole complex values (fp32 only).
+// Twiddles: log2(r) table lookups per butterfly (w^k, w^2k, w^4k, w^8k; exact table built in
+// long double on the host), the other powers by <=3 multiplications.  Inverse transforms swap
+// re/im on load and store (pass_io.h), so only forward butterflies exist.
+#pragma once
+#include "gfft_internal.h"
+#include "pass_io.h"
+
+namespace gfft {
+
+template <typename real> struct K {
+  static constexpr real SQ = (real)0.70710678118654752440084436210485;   // cos(pi/4)
+  static constexpr real C1 = (real)0.92387953251128675612818318939679;   // cos(pi/8)
+  static constexpr real S1 = (real)0.38268343236508977172845998403040;   // sin(pi/8)
+};
+
+// ---- in-register radix-r DFTs (forward), natural order in and out, elements v[0], v[S], ...
+template <typename real, int S> __device__ __forceinline__ void dft2(cx<real> *v) {
+  cx<real> a = v[0], b = v[S];
+  v[0] = a + b;
+  v[S] = a - b;
+}
+
+template <typename real> __device__ __forceinline__ void bf4(cx<real> &a0, cx<real> &a1, cx<real> &a2, cx<real> &a3) {
+  cx<real> t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mi(a1 - a3);
+  a0 = t0 + t2;
+  a1 = t1 + t3;
+  a2 = t0 - t2;
+  a3 = t1 - t3;
+}
+
+template <typename real, int S> __device__ __forceinline__ void dft4(cx<real> *v) {
+  bf4(v[0], v[S], v[2 * S], v[3 * S]);
+}
+
+template <typename real> __device__ __forceinline__ cx<real> mul_w8_1(cx<real> a) {  // * exp(-i pi/4)
+  return {(a.x + a.y) * K<real>::SQ, (a.y - a.x) * K<real>::SQ};
+}
+template <typename real> __device__ __forceinline__ cx<real> mul_w8_3(cx<real> a) {  // * exp(-3i pi/4)
+  return {(a.y - a.x) * K<real>::SQ, -(a.x + a.y) * K<real>::SQ};
+}
+template <typename real> __device__ __forceinline__ cx<real> mul_c(cx<real> a, real wx, real wy) {
+  return {a.x * wx - a.y * wy, a.x * wy + a.y * wx};
+}
+
+template <typename real, int S> __device__ __forceinline__ void dft8(cx<real> *v) {
+  // x[n] = v[n*S]; n = i + 2a
+  bf4(v[0], v[2 * S], v[4 * S], v[6 * S]);
+  bf4(v[1 * S], v[3 * S], v[5 * S], v[7 * S]);
+  v[3 * S] = mul_w8_1(v[3 * S]);  // Y_1[1]
+  v[5 * S] = mul_mi(v[5 * S]);    // Y_1[2]
+  v[7 * S] = mul_w8_3(v[7 * S]);  // Y_1[3]
+  // radix-2 over i: (x[2k1], x[2k1+1]) -> X[k1], X[k1+4]
+  cx<real> o[8];
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) {
+    cx<real> a = v[(2 * k1) * S], b = v[(2 * k1 + 1) * S];
+    o[k1] = a + b;
+    o[k1 + 4] = a - b;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k * S] = o[k];
+}
+
+template <typename real, int S> __device__ __forceinline__ void dft16(cx<real> *v) {
+  // x[n] = v[n*S]; n = i + 4a.  Step A: radix-4 over a.
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bf4(v[i * S], v[(i + 4) * S], v[(i + 8) * S], v[(i + 12) * S]);
+  // twiddles W16^(i*k1) on x[i + 4*k1]
+  const real C1 = K<real>::C1, S1 = K<real>::S1, SQ = K<real>::SQ;
+  v[5 * S] = mul_c(v[5 * S], C1, -S1);    // i=1,k1=1: W^1
+  v[9 * S] = mul_w8_1(v[9 * S]);          // i=1,k1=2: W^2
+  v[13 * S] = mul_c(v[13 * S], S1, -C1);  // i=1,k1=3: W^3
+  v[6 * S] = mul_w8_1(v[6 * S]);          // i=2,k1=1: W^2
+  v[10 * S] = mul_mi(v[10 * S]);          // i=2,k1=2: W^4
+  v[14 * S] = mul_w8_3(v[14 * S]);        // i=2,k1=3: W^6
+  v[7 * S] = mul_c(v[7 * S], S1, -C1);    // i=3,k1=1: W^3
+  v[11 * S] = mul_w8_3(v[11 * S]);        // i=3,k1=2: W^6
+  v[15 * S] = mul_c(v[15 * S], -C1, S1);  // i=3,k1=3: W^9
+  (void)SQ;
+  // Step B: radix-4 over i on (x[4k1..4k1+3]) -> X[k1 + 4*k2] at x[4k1 + k2]
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) bf4(v[(4 * k1) * S], v[(4 * k1 + 1) * S], v[(4 * k1 + 2) * S], v[(4 * k1 + 3) * S]);
+  // 4x4 transpose to natural order
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = a + 1; b < 4; ++b) {
+      cx<real> t = v[(4 * a + b) * S];
+      v[(4 * a + b) * S] = v[(4 * b + a) * S];
+      v[(4 * b + a) * S] = t;
+    }
+}
+
+template <typename real, int r, int S> __device__ __forceinline__ void dft(cx<real> *v) {
+  if constexpr (r == 2) dft2<real, S>(v);
+  else if constexpr (r == 4) dft4<real, S>(v);
+  else if constexpr (r == 8) dft8<real, S>(v);
+  else dft16<real, S>(v);
+}
+
+// ---- LDS layout -----------------------------------------------------------------------------
+__host__ __device__ constexpr int pad_slot(int e) { return e + (e >> 4); }
+
+template <int N, bool COLS> struct Lds {
+  static constexpr int NP = N + N / 16 + 1;
+  // COLS: column stride == 2 (mod 16) words so that 8 adjacent columns x 2 rows cover the banks
+  static constexpr int CS = COLS ? ((NP + 15) / 16) * 16 + 2 : NP;
+};
+
+// multiply v[i + m*S] (m = 1..r-1) by w^(m*k); w = exp(-2 pi i/(Ns*r)); table stride = N/(Ns*r)
+template <typename real, int N, int r, int Ns, int S>
+__device__ __forceinline__ void twiddle(cx<real> *v, int k, const cx<real> *__restrict__ tw) {
+  constexpr int step = N / (Ns * r);
+  const cx<real> w1 = tw[k * step];
+  v[1 * S] = cmul(v[1 * S], w1);
+  if constexpr (r >= 4) {
+    const cx<real> w2 = tw[2 * k * step];
+    const cx<real> w3 = cmul(w1, w2);
+    v[2 * S] = cmul(v[2 * S], w2);
+    v[3 * S] = cmul(v[3 * S], w3);
+    if constexpr (r >= 8) {
+      const cx<real> w4 = tw[4 * k * step];
+      const cx<real> w5 = cmul(w1, w4), w6 = cmul(w2, w4), w7 = cmul(w3, w4);
+      v[4 * S] = cmul(v[4 * S], w4);
+      v[5 * S] = cmul(v[5 * S], w5);
+      v[6 * S] = cmul(v[6 * S], w6);
+      v[7 * S] = cmul(v[7 * S], w7);
+      if constexpr (r >= 16) {
+        const cx<real> w8 = tw[8 * k * step];
+        v[8 * S] = cmul(v[8 * S], w8);
+        v[9 * S] = cmul(v[9 * S], cmul(w1, w8));
+        v[10 * S] = cmul(v[10 * S], cmul(w2, w8));
+        v[11 * S] = cmul(v[11 * S], cmul(w3, w8));
+        v[12 * S] = cmul(v[12 * S], cmul(w4, w8));
+        v[13 * S] = cmul(v[13 * S], cmul(w5, w8));
+        v[14 * S] = cmul(v[14 * S], cmul(w6, w8));
+        v[15 * S] = cmul(v[15 * S], cmul(w7, w8));
+      }
+    }
+  }
+}
+
+// ---- one Stockham stage + exchange, recursing over the radix list -------------------------
+template <typename real, int N, int R, bool SPLIT, int Ns, int... RADS> struct Stage;
+
+template <typename real, int N, int R, bool SPLIT, int Ns> struct Stage<real, N, R, SPLIT, Ns> {
+  static __device__ __forceinline__ void run(cx<real> *, int, void *, const cx<real> *) {}
+};
+
+template <typename real, int N, int R, bool SPLIT, int Ns, int r, int... REST>
+struct Stage<real, N, R, SPLIT, Ns, r, REST...> {
+  static constexpr int NT = N / R;   // threads per column
+  static constexpr int NB = R / r;   // butterflies per thread in this stage
+  static __device__ __forceinline__ void run(cx<real> *v, int t, void *col,
+                                             const cx<real> *__restrict__ tw) {
+    static_assert(R % r == 0 && N % (Ns * r) == 0, "bad radix plan");
+    if constexpr (Ns > 1) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int k = (t + i * NT) & (Ns - 1);
+        twiddle<real, N, r, Ns, NB>(v + i, k, tw);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) dft<real, r, NB>(v + i);
+    if constexpr (sizeof...(REST) > 0) {
+      // scatter: butterfly j = t + i*NT, output m -> index j0 + m*Ns, j0 = (j/Ns)*Ns*r + j%Ns.
+      // pad_slot(j0 + m*Ns) == pad_slot(j0) + woff(m) and pad_slot(t + q*NT) == pad_slot(t) + roff(q)
+      // for power-of-two Ns, NT: one address register per butterfly, the rest are DS immediates.
+      int wbase[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int j = t + i * NT;
+        wbase[i] = pad_slot((j / Ns) * (Ns * r) + (j & (Ns - 1)));
+      }
+      const int rbase = pad_slot(t);
+      if constexpr (SPLIT) {
+        real *w = reinterpret_cast<real *>(col);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+          for (int m = 0; m < r; ++m) w[wbase[i] + m * Ns + ((m * Ns) >> 4)] = v[i + m * NB].x;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q].x = w[rbase + q * NT + ((q * NT) >> 4)];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+          for (int m = 0; m < r; ++m) w[wbase[i] + m * Ns + ((m * Ns) >> 4)] = v[i + m * NB].y;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q].y = w[rbase + q * NT + ((q * NT) >> 4)];
+      } else {
+        float2 *w = reinterpret_cast<float2 *>(col);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+          for (int m = 0; m < r; ++m)
+            w[wbase[i] + m * Ns + ((m * Ns) >> 4)] = make_float2(v[i + m * NB].x, v[i + m * NB].y);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          float2 f = w[rbase + q * NT + ((q * NT) >> 4)];
+          v[q].x = f.x;
+          v[q].y = f.y;
+        }
+      }
+      Stage<real, N, R, SPLIT, Ns * r, REST...>::run(v, t, col, tw);
+    }
+  }
+};
+
+// Tile-specialised load/store.  MODE is compile time (no per-element branches), BIGTW too.
+// Conjugation (inverse transforms) is a sign on the imaginary part: on load one multiply, on
+// store it is folded into the scale (scale_y = +-scale), so backward costs what forward does.
+template <typename real, int MODE>
+__device__ __forceinline__ cx<real> tile_load(const PassDesc &d, const void *__restrict__ in,
+                                              int64_t base, int e, real sy) {
+  cx<real> v;
+  if constexpr (MODE == MODE_R2C) {
+    v.x = reinterpret_cast<const real *>(in)[base + (int64_t)e * d.in_es];
+    v.y = 0;
+  } else if constexpr (MODE == MODE_C2R) {
+    const int h = d.n >> 1;
+    const bool mirror = e > h;
+    const int ee = mirror ? d.n - e : e;
+    v = reinterpret_cast<const cx<real> *>(in)[base + (int64_t)ee * d.in_es];
+    v.y *= mirror ? -sy : sy;
+  } else {
+    v = reinterpret_cast<const cx<real> *>(in)[base + (int64_t)e * d.in_es];
+    v.y *= sy;
+  }
+  return v;
+}
+
+template <typename real, int MODE, bool BIGTW>
+__device__ __forceinline__ void tile_store(const PassDesc &d, void *__restrict__ out, int64_t base,
+                                           int e, unsigned mid, cx<real> v, real sx, real sy) {
+  if constexpr (BIGTW) {
+    const unsigned x = mid * (unsigned)e;          // < big_n <= 2^24
+    const cx<real> a = reinterpret_cast<const cx<real> *>(d.tw_hi)[x >> d.tw_L];
+    const cx<real> b = reinterpret_cast<const cx<real> *>(d.tw_lo)[x & ((1u << d.tw_L) - 1)];
+    v = cmul(v, cmul(a, b));
+  }
+  v.x *= sx;
+  v.y *= sy;
+  if constexpr (MODE == MODE_C2R) {
+    reinterpret_cast<real *>(out)[base + (int64_t)e * d.out_es] = v.x;
+  } else if constexpr (MODE == MODE_R2C) {
+    if (e <= (d.n >> 1)) reinterpret_cast<cx<real> *>(out)[base + (int64_t)e * d.out_es] = v;
+  } else {
+    reinterpret_cast<cx<real> *>(out)[base + (int64_t)e * d.out_es] = v;
+  }
+}
+
+template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int MODE, bool BIGTW, int... RADS>
+__global__ void __launch_bounds__(T *(N / R), MINW)
+fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
+  static_assert(SPLIT || sizeof(real) == 4, "fp64 exchanges split planes");
+  constexpr int NT = N / R;
+  constexpr int CS = Lds<N, COLS>::CS;
+  constexpr int WORD = SPLIT ? sizeof(real) : 2 * sizeof(real);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const cx<real> *tw = reinterpret_cast<const cx<real> *>(d.tw);
+  const int tid = threadIdx.x;
+  const int c = COLS ? (tid % T) : (tid / NT);
+  const int t = COLS ? (tid / T) : (tid % NT);
+  void *col = smem + (size_t)c * CS * WORD;
+  const unsigned batch = (unsigned)d.batch, inner = (unsigned)d.inner, mid = (unsigned)d.mid;
+  const unsigned ntiles = (batch + T - 1) / T;
+  const real sy_in = d.conj_in ? (real)-1 : (real)1;
+  const real sx_out = (real)d.scale;
+  const real sy_out = d.conj_out ? -sx_out : sx_out;
+
+  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const unsigned b = tile * T + c;
+    const bool valid = b < batch;
+    // b = (o * mid + m) * inner + i
+    const unsigned bb = valid ? b : 0;
+    const unsigned bm = bb / inner, i = bb - bm * inner;
+    const unsigned o = bm / mid, m = bm - o * mid;
+    const int64_t in0 = (int64_t)o * d.in_os + (int64_t)m * d.in_ms + (int64_t)i * d.in_is;
+    const int64_t out0 = (int64_t)o * d.out_os + (int64_t)m * d.out_ms + (int64_t)i * d.out_is;
+    cx<real> v[R];
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < R; ++q) v[q] = tile_load<real, MODE>(d, in, in0, t + q * NT, sy_in);
+    } else {
+#pragma unroll
+      for (int q = 0; q < R; ++q) v[q] = {0, 0};
+    }
+    Stage<real, N, R, SPLIT, 1, RADS...>::run(v, t, col, tw);
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < R; ++q) tile_store<real, MODE, BIGTW>(d, out, out0, t + q * NT, m, v[q], sx_out, sy_out);
+    }
+  }
+}
+
+// ---- launch helpers ------------------------------------------------------------------------
+
+template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int MODE, bool BIGTW, int... RADS>
+hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStream_t s) {
+  constexpr int NT = N / R;
+  constexpr int threads = T * NT;
+  static_assert(threads >= 64 && threads <= 1024, "workgroup size");
+  constexpr size_t lds = (sizeof...(RADS) > 1) ? (size_t)T * Lds<N, COLS>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  auto kern = fft_pow2_kernel<real, N, R, T, COLS, SPLIT, MINW, MODE, BIGTW, RADS...>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int64_t ntiles = (d.batch + T - 1) / T;
+  const int64_t cap = pow2_grid_cap();
+  const int grid = (int)(ntiles < cap ? ntiles : cap);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, d, in, out);
+  return hipGetLastError();
+}
+
+// runtime (mode, four-step twiddle) -> instantiation
+template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int... RADS>
+hipError_t launch_pow2_inst(const PassDesc &d, const void *in, void *out, hipStream_t s) {
+  if (d.tw_hi) {
+    if (d.mode != MODE_C2C) return hipErrorInvalidValue;
+    return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, MODE_C2C, true, RADS...>(d, in, out, s);
+  }
+  switch (d.mode) {
+    case MODE_C2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, MODE_C2C, false, RADS...>(d, in, out, s);
+    case MODE_R2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, MODE_R2C, false, RADS...>(d, in, out, s);
+    case MODE_C2R: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, MODE_C2R, false, RADS...>(d, in, out, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace gfft

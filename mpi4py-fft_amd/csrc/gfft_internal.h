@@ -1,0 +1,73 @@
+// Internal declarations shared by the kernel translation units and the planner.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gfft {
+
+// ---- complex helpers (device) ------------------------------------------------------------
+template <typename T> struct cx { T x, y; };
+
+template <typename T> __device__ __forceinline__ cx<T> operator+(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T> __device__ __forceinline__ cx<T> operator-(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename T> __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
+  return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+// a * (-i)
+template <typename T> __device__ __forceinline__ cx<T> mul_mi(cx<T> a) { return {a.y, -a.x}; }
+template <typename T> __device__ __forceinline__ cx<T> cswap(cx<T> a) { return {a.y, a.x}; }
+
+// ---- one 1-D pass over a row-major array -------------------------------------------------
+// Column b of the batch decomposes as b = (o * mid + m) * inner + i; element e of that column
+// sits at  base + o*os + m*ms + i*is + e*es  (strides in units of the buffer's element type:
+// real scalars on the real side of r2c/c2r, complex otherwise).
+enum PassMode { MODE_C2C = 0, MODE_R2C = 1, MODE_C2R = 2 };
+
+struct PassDesc {
+  int n;          // logical transform length
+  int mode;       // PassMode
+  int conj_in;    // conjugate on load   (inverse transform = conj . forward . conj)
+  int conj_out;   // conjugate on store
+  int64_t batch;  // number of columns = outer * mid * inner
+  int64_t mid, inner;
+  int64_t in_os, in_ms, in_is, in_es;
+  int64_t out_os, out_ms, out_is, out_es;
+  double scale;           // applied on store
+  const void *tw;         // cx<real>[n]: exp(-2 pi i k / n)
+  // optional four-step twiddle: output element k of a column with mid index m is multiplied
+  // by W_big^(m*k), W_big = exp(-2 pi i / big_n), m*k < big_n <= 2^24;
+  // factored as hi[(m*k) >> tw_L] * lo[(m*k) & (2^tw_L - 1)]
+  const void *tw_hi, *tw_lo;
+  int64_t big_n;
+  int tw_L;
+};
+
+struct Factors {
+  int count;
+  int r[24];
+};
+
+// launchers implemented in the kernel translation units; all return hipError_t
+hipError_t launch_generic(const PassDesc &d, const Factors &f, int precision, const void *in,
+                          void *out, hipStream_t s);
+// max transform length the generic LDS kernel accepts for this precision
+int generic_max_n(int precision);
+
+// fast power-of-two kernels; returns false if (n, precision) has no instantiation
+bool pow2_supported_f64(int n);
+bool pow2_supported_f32(int n);
+hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void *in, void *out, hipStream_t s);
+hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void *in, void *out, hipStream_t s);
+int pow2_grid_cap();
+
+hipError_t launch_pack(const void *src, void *dst, int64_t outer, int64_t naxis, int64_t inner,
+                       int nparts, int itemsize, bool unpack, hipStream_t s);
+hipError_t launch_trunc(const void *src, void *dst, int64_t outer, int64_t npad,
+                        int64_t ntrunc, int64_t inner, int is_real, int precision, double scale,
+                        bool pad_direction, hipStream_t s);
+hipError_t launch_scale(void *data, int64_t count, int precision, double scale, hipStream_t s);
+hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s);
+hipError_t launch_tile_copy(const void *src, void *dst, int64_t outer, int64_t n, int64_t inner,
+                            int tcols, hipStream_t s);
+
+}  // namespace gfft

@@ -1,0 +1,220 @@
+// Data-movement kernels around the transforms:
+//   pack / unpack   what MPI's subarray datatypes do inside Alltoallw (pencil.py:12-29,182,200)
+//   truncate / pad  3/2-rule dealiasing copies (libfft.py:263-311) with the scale fused
+//   scale           `array *= M` (libfft.py:412-413)
+//   copy probes     HBM ceilings quoted next to the roofline numbers
+// All are pure streaming kernels: 16-byte accesses where the geometry allows, grid-stride loops.
+#include "gfft_internal.h"
+
+namespace gfft {
+
+constexpr int MV_THREADS = 256;
+constexpr int MV_MAX_BLOCKS = 256 * 16;
+
+static inline int mv_grid(int64_t work) {
+  int64_t b = (work + MV_THREADS - 1) / MV_THREADS;
+  if (b > MV_MAX_BLOCKS) b = MV_MAX_BLOCKS;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// block p of an axis of length N cut into P blocks (pencil.py:5-9): first r blocks have q+1
+struct BlockRule {
+  int64_t q, r;
+  __host__ __device__ void locate(int64_t a, int64_t &p, int64_t &start, int64_t &len) const {
+    const int64_t big = r * (q + 1);
+    if (a < big) {
+      p = a / (q + 1);
+      start = p * (q + 1);
+      len = q + 1;
+    } else {
+      p = r + (a - big) / q;
+      start = big + (p - r) * q;
+      len = q;
+    }
+  }
+};
+
+// array [outer][naxis][inner] (units of U bytes) <-> blocks laid out one after another, block p
+// being the row-major [outer][len_p][inner] sub-array starting at outer*inner*start_p units.
+template <typename U, bool UNPACK>
+__global__ void __launch_bounds__(MV_THREADS)
+pack_kernel(const U *__restrict__ src, U *__restrict__ dst, int64_t outer, int64_t naxis,
+            int64_t inner, BlockRule rule) {
+  const int64_t total = outer * naxis * inner;
+  const int64_t row = naxis * inner;
+  for (int64_t idx = (int64_t)blockIdx.x * MV_THREADS + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * MV_THREADS) {
+    const int64_t o = idx / row;
+    const int64_t rem = idx - o * row;
+    const int64_t a = rem / inner;
+    const int64_t i = rem - a * inner;
+    int64_t p, start, len;
+    rule.locate(a, p, start, len);
+    const int64_t packed = outer * inner * start + (o * len + (a - start)) * inner + i;
+    if (UNPACK) dst[idx] = src[packed];
+    else dst[packed] = src[idx];
+  }
+}
+
+struct alignas(16) u128 { unsigned long long a, b; };
+
+hipError_t launch_pack(const void *src, void *dst, int64_t outer, int64_t naxis, int64_t inner,
+                       int nparts, int itemsize, bool unpack, hipStream_t s) {
+  if (outer * naxis * inner == 0) return hipSuccess;
+  BlockRule rule{naxis / nparts, naxis % nparts};
+  const int64_t rowbytes = inner * itemsize;
+  const bool al16 = (rowbytes % 16 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+#define PK(U, UNP, INNER) \
+  hipLaunchKernelGGL((pack_kernel<U, UNP>), dim3(mv_grid(outer * naxis * (INNER))), dim3(MV_THREADS), 0, s, \
+                     (const U *)src, (U *)dst, outer, naxis, (INNER), rule)
+  if (al16) {
+    if (unpack) PK(u128, true, rowbytes / 16); else PK(u128, false, rowbytes / 16);
+  } else if (itemsize == 16) {
+    if (unpack) PK(u128, true, inner); else PK(u128, false, inner);
+  } else if (itemsize == 8) {
+    if (unpack) PK(unsigned long long, true, inner); else PK(unsigned long long, false, inner);
+  } else if (itemsize == 4) {
+    if (unpack) PK(unsigned int, true, inner); else PK(unsigned int, false, inner);
+  } else {
+    return hipErrorInvalidValue;
+  }
+#undef PK
+  return hipGetLastError();
+}
+
+// ---- truncation / padding ---------------------------------------------------------------------
+// PAD == false: trunc[o][k][i] = scale * f(padded)   (libfft.py:263-284)
+// PAD == true : padded[o][kp][i] = g(trunc)          (libfft.py:286-311)
+template <typename real, bool PAD>
+__global__ void __launch_bounds__(MV_THREADS)
+trunc_kernel(const cx<real> *__restrict__ src, cx<real> *__restrict__ dst, int64_t outer,
+             int64_t npad, int64_t N, int64_t inner, int is_real, real scale) {
+  const int64_t nd = PAD ? npad : N;        // destination axis length
+  const int64_t ns = PAD ? N : npad;        // source axis length
+  const int64_t total = outer * nd * inner;
+  const int64_t h = N / 2;
+  const bool even = (N % 2) == 0;           // parity rule is on the TRUNCATED length (libfft.py:267,290)
+  for (int64_t idx = (int64_t)blockIdx.x * MV_THREADS + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * MV_THREADS) {
+    const int64_t o = idx / (nd * inner);
+    const int64_t rem = idx - o * nd * inner;
+    const int64_t k = rem / inner;
+    const int64_t i = rem - k * inner;
+    const cx<real> *s = src + o * ns * inner + i;
+    cx<real> v = {0, 0};
+    if (!PAD) {
+      if (is_real) {
+        v = s[k * inner];
+        if (even && k == N - 1) { v.x *= 2; v.y = 0; }
+      } else {
+        if (k <= h) v = s[k * inner];
+        if (h > 0 && k >= N - h) v = v + s[(npad - N + k) * inner];
+      }
+      v.x *= scale;
+      v.y *= scale;
+    } else {
+      if (is_real) {
+        if (k < N) {
+          v = s[k * inner];
+          if (even && k == N - 1) { v.x *= (real)0.5; v.y = 0; }
+        }
+      } else {
+        if (k <= h) v = s[k * inner];
+        else if (h > 0 && k >= npad - h) v = s[(N - npad + k) * inner];
+        if (even && (k == h || k == npad - h)) { v.x *= (real)0.5; v.y *= (real)0.5; }
+      }
+    }
+    dst[idx] = v;
+  }
+}
+
+hipError_t launch_trunc(const void *src, void *dst, int64_t outer, int64_t npad,
+                        int64_t ntrunc, int64_t inner, int is_real, int precision, double scale,
+                        bool pad_direction, hipStream_t s) {
+  const int64_t total = outer * (pad_direction ? npad : ntrunc) * inner;
+  if (total == 0) return hipSuccess;
+  const int grid = mv_grid(total);
+  if (precision == 8) {
+    if (pad_direction)
+      hipLaunchKernelGGL((trunc_kernel<double, true>), dim3(grid), dim3(MV_THREADS), 0, s,
+                         (const cx<double> *)src, (cx<double> *)dst, outer, npad, ntrunc, inner, is_real, 1.0);
+    else
+      hipLaunchKernelGGL((trunc_kernel<double, false>), dim3(grid), dim3(MV_THREADS), 0, s,
+                         (const cx<double> *)src, (cx<double> *)dst, outer, npad, ntrunc, inner, is_real, scale);
+  } else {
+    if (pad_direction)
+      hipLaunchKernelGGL((trunc_kernel<float, true>), dim3(grid), dim3(MV_THREADS), 0, s,
+                         (const cx<float> *)src, (cx<float> *)dst, outer, npad, ntrunc, inner, is_real, 1.0f);
+    else
+      hipLaunchKernelGGL((trunc_kernel<float, false>), dim3(grid), dim3(MV_THREADS), 0, s,
+                         (const cx<float> *)src, (cx<float> *)dst, outer, npad, ntrunc, inner, is_real, (float)scale);
+  }
+  return hipGetLastError();
+}
+
+// ---- scale ----------------------------------------------------------------------------------
+template <typename real>
+__global__ void __launch_bounds__(MV_THREADS) scale_kernel(real *__restrict__ p, int64_t n, real sc) {
+  for (int64_t i = (int64_t)blockIdx.x * MV_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * MV_THREADS)
+    p[i] *= sc;
+}
+
+hipError_t launch_scale(void *data, int64_t count, int precision, double scale, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  if (precision == 8)
+    hipLaunchKernelGGL(scale_kernel<double>, dim3(mv_grid(count)), dim3(MV_THREADS), 0, s, (double *)data, count, scale);
+  else
+    hipLaunchKernelGGL(scale_kernel<float>, dim3(mv_grid(count)), dim3(MV_THREADS), 0, s, (float *)data, count, (float)scale);
+  return hipGetLastError();
+}
+
+// ---- probes ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(MV_THREADS) copy_kernel(const u128 *__restrict__ src, u128 *__restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * MV_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * MV_THREADS)
+    dst[i] = src[i];
+}
+
+hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s) {
+  const int64_t n = (int64_t)(bytes / 16);
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(copy_kernel, dim3(MV_MAX_BLOCKS), dim3(MV_THREADS), 0, s, (const u128 *)src, (u128 *)dst, n);
+  return hipGetLastError();
+}
+
+// column-pass access pattern without arithmetic: a workgroup moves a [n][tcols] tile of 16-byte
+// elements (rows `inner` elements apart), 8 rows in flight per thread.
+__global__ void __launch_bounds__(MV_THREADS)
+tile_copy_kernel(const u128 *__restrict__ src, u128 *__restrict__ dst, int64_t outer, int64_t n,
+                 int64_t inner, int tcols) {
+  const int64_t tiles_per_outer = inner / tcols;
+  const int64_t ntiles = outer * tiles_per_outer;
+  const int c = threadIdx.x % tcols;
+  const int r0 = threadIdx.x / tcols;
+  const int rstep = MV_THREADS / tcols;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t o = tile / tiles_per_outer;
+    const int64_t i0 = (tile - o * tiles_per_outer) * tcols;
+    const int64_t base = o * n * inner + i0 + c;
+    for (int64_t e = r0; e < n; e += 8 * rstep) {
+      u128 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e + u * rstep < n) v[u] = src[base + (e + u * rstep) * inner];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e + u * rstep < n) dst[base + (e + u * rstep) * inner] = v[u];
+    }
+  }
+}
+
+hipError_t launch_tile_copy(const void *src, void *dst, int64_t outer, int64_t n, int64_t inner,
+                            int tcols, hipStream_t s) {
+  if (tcols < 1 || tcols > MV_THREADS || (MV_THREADS % tcols) || (inner % tcols)) return hipErrorInvalidValue;
+  const int64_t ntiles = outer * (inner / tcols);
+  const int grid = (int)(ntiles < MV_MAX_BLOCKS ? ntiles : MV_MAX_BLOCKS);
+  hipLaunchKernelGGL(tile_copy_kernel, dim3(grid), dim3(MV_THREADS), 0, s, (const u128 *)src, (u128 *)dst, outer, n, inner, tcols);
+  return hipGetLastError();
+}
+
+}  // namespace gfft

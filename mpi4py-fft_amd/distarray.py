@@ -1,0 +1,203 @@
+"""Distributed array with device (HBM) backing.
+
+Mirror of mpi4py_fft/distarray.py: ``DistArray`` carries a :class:`Pencil` describing which block
+of the global array this rank holds, supports tensor-valued fields (``rank`` leading axes that
+are never distributed) and ``redistribute``; ``newDistArray(pfft, ...)`` allocates the input or
+output array of a :class:`PFFT`.  The reference subclasses ``np.ndarray``; here the storage is a
+:class:`DeviceArray` (see array.py for the ndarray behaviour it keeps).  ``get / write / read``
+(HDF5 / NetCDF I/O, distarray.py:182-241,365-439) are storage features outside this path.
+"""
+from numbers import Number
+
+import numpy as np
+
+from .array import DeviceArray
+from .pencil import Pencil, Subcomm
+from . import comm as _comm
+
+
+class DistArray(DeviceArray):
+    """Distributed device array (distarray.py:10-101).
+
+    Parameters
+    ----------
+    global_shape : shape of the non-distributed global array (incl. ``rank`` leading axes)
+    subcomm : None, a :class:`Subcomm`, a sequence of communicators, or a sequence of ints
+        (grid with 0 = free entries)
+    val : fill value;  dtype : 'f', 'd', 'F', 'D';  buffer : a DeviceArray/tensor to adopt
+    alignment : the undistributed axis (tensor rank not counted);  rank : tensor rank (0,1,2)
+    """
+    def __init__(self, global_shape, subcomm=None, val=None, dtype=float, buffer=None,
+                 strides=None, alignment=None, rank=0):
+        global_shape = tuple(int(s) for s in global_shape)
+        if len(global_shape[rank:]) < 2:   # 1-D: a plain undistributed array
+            self._p0, self._rank = None, rank
+            self._init_storage(global_shape, dtype, buffer, val)
+            return
+        if isinstance(subcomm, Subcomm):
+            pass
+        else:
+            if isinstance(subcomm, (tuple, list)):
+                assert len(subcomm) == len(global_shape[rank:])
+                if not np.all([isinstance(s, _comm.Comm) for s in subcomm]):
+                    subcomm = Subcomm(_comm.world(), subcomm)
+            else:
+                assert subcomm is None
+                subcomm = [0] * len(global_shape[rank:])
+                if alignment is not None:
+                    subcomm[alignment] = 1
+                else:
+                    subcomm[-1] = 1
+                    alignment = len(subcomm) - 1
+                subcomm = Subcomm(_comm.world(), subcomm)
+        sizes = [s.Get_size() for s in subcomm]
+        if alignment is not None:
+            assert isinstance(alignment, (int, np.integer))
+            assert sizes[alignment] == 1
+        else:
+            alignment = np.flatnonzero(np.array(sizes) == 1)[-1]
+        p0 = Pencil(subcomm, global_shape[rank:], axis=int(alignment))
+        subshape = p0.subshape
+        if rank > 0:
+            subshape = global_shape[:rank] + subshape
+        self._p0, self._rank = p0, rank
+        self._init_storage(subshape, dtype, buffer, val)
+
+    def _init_storage(self, shape, dtype, buffer, val):
+        tensor = None
+        if buffer is not None:
+            tensor = buffer.tensor if isinstance(buffer, DeviceArray) else buffer
+            tensor = tensor.reshape(tuple(shape))
+        DeviceArray.__init__(self, shape, dtype, tensor=tensor,
+                             val=val if (buffer is None and isinstance(val, Number)) else None)
+
+    def _view(self, sub):
+        # slicing returns a DistArray only while the shape is intact (distarray.py:155-175)
+        if sub.ndim == 0:
+            return sub.item()
+        if tuple(sub.shape) == self._shape:
+            out = DistArray.__new__(DistArray)
+            out._p0, out._rank = self._p0, self._rank
+        else:
+            out = DeviceArray.__new__(DeviceArray)
+        out._shape, out._dtype, out._t = tuple(sub.shape), self._dtype, sub
+        return out
+
+    @property
+    def alignment(self):
+        return self._p0.axis
+
+    @property
+    def global_shape(self):
+        return self.shape[:self.rank] + self._p0.shape
+
+    @property
+    def substart(self):
+        return (0,) * self.rank + self._p0.substart
+
+    @property
+    def subcomm(self):
+        return (_comm.COMM_SELF,) * self.rank + self._p0.subcomm
+
+    @property
+    def commsizes(self):
+        return [s.Get_size() for s in self.subcomm]
+
+    @property
+    def pencil(self):
+        return self._p0
+
+    @property
+    def rank(self):
+        return self._rank
+
+    @property
+    def dimensions(self):
+        return len(self._p0.shape)
+
+    @property
+    def v(self):
+        """The plain array view (``.view(np.ndarray)`` in the reference)."""
+        out = DeviceArray.__new__(DeviceArray)
+        out._shape, out._dtype, out._t = self._shape, self._dtype, self._t
+        return out
+
+    def local_slice(self):
+        v = [slice(start, start + shape) for start, shape in zip(self._p0.substart, self._p0.subshape)]
+        return tuple([slice(0, s) for s in self.shape[:self.rank]] + v)
+
+    def get_pencil_and_transfer(self, axis):
+        p1 = self._p0.pencil(axis)
+        return p1, self._p0.transfer(p1, self.dtype)
+
+    def redistribute(self, axis=None, out=None):
+        """Global redistribution so that `axis` (or `out`'s aligned axis) becomes undivided
+        (distarray.py:298-363).  Vector/tensor components are moved one transfer each."""
+        if axis == self.alignment:
+            return self
+        if axis is not None and isinstance(out, DistArray):
+            assert axis == out.alignment
+        if axis is not None:
+            if self.commsizes[self.rank + axis] == 1:
+                self.pencil.axis = axis
+                return self
+        if out is not None:
+            assert isinstance(out, DistArray)
+            assert self.global_shape == out.global_shape
+            axis = out.alignment
+            if self.commsizes == out.commsizes:
+                out[...] = self
+                return out
+            for i in range(len(self._p0.shape)):
+                if i not in (self.alignment, out.alignment):
+                    assert self.pencil.subcomm[i] == out.pencil.subcomm[i]
+                    assert self.pencil.subshape[i] == out.pencil.subshape[i]
+        p1, transfer = self.get_pencil_and_transfer(axis)
+        if out is None:
+            out = DistArray(self.global_shape, subcomm=p1.subcomm, dtype=self.dtype,
+                            alignment=axis, rank=self.rank)
+        if self.rank == 0:
+            transfer.forward(self.v, out.v)
+        elif self.rank == 1:
+            for i in range(self.shape[0]):
+                transfer.forward(self.v[i], out.v[i])
+        elif self.rank == 2:
+            for i in range(self.shape[0]):
+                for j in range(self.shape[1]):
+                    transfer.forward(self.v[i, j], out.v[i, j])
+        transfer.destroy()
+        return out
+
+    def get(self, gslice=None):
+        if gslice is None:
+            return DeviceArray.get(self)
+        raise NotImplementedError('global-slice gather goes through HDF5 in the reference '
+                                  '(distarray.py:182-241); storage I/O is outside this path')
+
+    def write(self, *a, **k):
+        raise NotImplementedError('HDF5/NetCDF output is outside the PFFT hot path')
+
+    read = write
+
+
+def newDistArray(pfft, forward_output=True, val=0, rank=0, view=False):
+    """A new DistArray shaped and typed as the input (``forward_output=False``) or output of
+    ``pfft.forward`` (distarray.py:442-485)."""
+    global_shape = pfft.global_shape(forward_output)
+    p0 = pfft.pencil[forward_output]
+    if forward_output is True:
+        dtype = pfft.forward.output_array.dtype
+    else:
+        dtype = pfft.forward.input_array.dtype
+    global_shape = (len(global_shape),) * rank + tuple(global_shape)
+    z = DistArray(global_shape, subcomm=p0.subcomm, val=val, dtype=dtype, alignment=p0.axis, rank=rank)
+    return z.v if view else z
+
+
+def Function(*args, **kwargs):  # deprecated alias kept by the reference (distarray.py:487-493)
+    import warnings
+    warnings.warn("Function() is deprecated; use newDistArray().", FutureWarning)
+    if 'tensor' in kwargs:
+        kwargs['rank'] = 1
+        del kwargs['tensor']
+    return newDistArray(*args, **kwargs)

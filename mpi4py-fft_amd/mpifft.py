@@ -1,0 +1,266 @@
+"""Parallel FFT orchestration: ``PFFT`` and ``Transform``.
+
+Same public behaviour as mpi4py_fft/mpifft.py (constructor arguments, ``forward``/``backward``
+callables, ``shape/local_slice/global_shape/dimensions/dtype`` queries, pencils, axes groups,
+grid rules, collapse, padding).  The plan it builds drives device objects: one
+:class:`libfft.FFT` per axis group (HIP kernels) and one :class:`pencil.Transfer` per change of
+alignment (pack kernel + RCCL all-to-all + unpack kernel).
+
+Two things are done differently because they only cost time in the reference:
+  * a ``Transfer`` over a single-rank communicator is a whole-array self copy there
+    (mpifft.py:324-331 builds one per axis group regardless).  Here the next
+    stage's input array *is* the previous stage's output array, so nothing is copied;
+  * forward normalisation is fused into the FFT kernels (see libfft.py).
+"""
+import numpy as np
+
+from .libfft import FFT
+from .pencil import Pencil, Subcomm
+from . import comm as _comm
+
+
+class Transform:
+    """A parallel transform, forward or backward: serial transforms interleaved with global
+    redistributions (mpifft.py:8-79)."""
+    def __init__(self, xfftn, transfer, pencil):
+        assert len(xfftn) == len(transfer) + 1 and len(pencil) == 2
+        self._xfftn = tuple(xfftn)
+        self._transfer = tuple(transfer)
+        self._pencil = tuple(pencil)
+
+    @property
+    def input_array(self):
+        return self._xfftn[0].input_array
+
+    @property
+    def output_array(self):
+        return self._xfftn[-1].output_array
+
+    @property
+    def input_pencil(self):
+        return self._pencil[0]
+
+    @property
+    def output_pencil(self):
+        return self._pencil[1]
+
+    def __call__(self, input_array=None, output_array=None, **kw):
+        """Compute the transform.  Without arguments it works on the planned arrays and returns
+        the planned output array (aliasing is part of the contract, mpifft.py:75-79).
+        ``normalize=True/False`` overrides the default (forward normalised, backward not)."""
+        if input_array is not None:
+            self.input_array[...] = input_array
+        for i in range(len(self._transfer)):
+            self._xfftn[i](**kw)
+            arrayA = self._xfftn[i].output_array
+            arrayB = self._xfftn[i + 1].input_array
+            if arrayA is not arrayB:          # single-rank transfers share the buffer
+                self._transfer[i](arrayA, arrayB)
+        self._xfftn[-1](**kw)
+        if output_array is not None:
+            output_array[...] = self.output_array
+            return output_array
+        return self.output_array
+
+
+class PFFT:
+    """Parallel (pencil/slab decomposed) FFT of a distributed array on MI355X GPUs.
+
+    Parameters  (identical meaning to mpifft.py:202-204)
+    ----------
+    comm : communicator (``mpi4py_fft_amd.comm.world()`` / ``COMM_SELF`` / a ``Subcomm``)
+    shape : global shape of the input array
+    axes : None, int, sequence of ints, or sequence of sequences of ints (axis groups; the LAST
+        group is transformed first and must be undistributed in the input)
+    dtype : 'f', 'd' (real input -> r2c along the first transformed axis), 'F', 'D'
+    grid : processor grid; non-positive entries are wildcards; padded with ones
+    padding : False or per-axis factors (3/2-rule)
+    collapse : merge trailing axis groups that are not distributed into one serial transform
+    backend : accepted for compatibility ('fftw'/'gfft'); there is one engine
+    transforms : optional {axes: (forward planner, backward planner)} from ``fftw``
+    darray : take shape/dtype/distribution from a DistArray
+    """
+    def __init__(self, comm, shape=None, axes=None, dtype=float, grid=None, padding=False,
+                 collapse=False, backend='fftw', transforms=None, darray=None, **kw):
+        if shape is None:
+            assert darray is not None
+            shape = darray.pencil.shape
+
+        if axes is not None:
+            axes = list(axes) if not isinstance(axes, (int, np.integer)) else [int(axes)]
+        else:
+            axes = list(range(len(shape)))
+            if darray is not None:
+                # the array's aligned axis must be transformed first
+                axes = list(np.roll(axes, len(shape) - 1 - darray.alignment))
+                axes = [int(a) for a in axes]
+
+        for i, ax in enumerate(axes):
+            if isinstance(ax, (int, np.integer)):
+                ax = int(ax)
+                if ax < 0:
+                    ax += len(shape)
+                axes[i] = (ax,)
+            else:
+                assert isinstance(ax, (tuple, list))
+                ax = list(ax)
+                for j, a in enumerate(ax):
+                    assert isinstance(a, (int, np.integer))
+                    if a < 0:
+                        ax[j] = int(a) + len(shape)
+                axes[i] = ax
+            assert min(axes[i]) >= 0
+            assert max(axes[i]) < len(shape)
+            assert 0 < len(axes[i]) <= len(shape)
+            assert sorted(axes[i]) == sorted(set(axes[i]))
+
+        self.axes = axes
+        shape = list(shape)
+
+        if darray is None:
+            dtype = np.dtype(dtype)
+            assert dtype.char in 'fdgFDG'
+            if padding is not False:
+                padding = list(padding)
+                assert len(padding) == len(shape)
+                for ax in axes:
+                    if len(ax) == 1 and padding[ax[0]] > 1.0 + 1e-6:
+                        old = float(shape[ax[0]])
+                        shape[ax[0]] = int(np.floor(shape[ax[0]] * padding[ax[0]]))
+                        padding[ax[0]] = shape[ax[0]] / old
+            self._input_shape = tuple(shape)
+            assert len(shape) > 0
+            assert min(shape) > 0
+            slab = kw.pop('slab', False)
+            if grid is not None:
+                assert not isinstance(comm, Subcomm)
+                assert slab is False
+                grid = tuple(grid)
+                assert len(grid) <= len(shape)
+                dims = list(grid) + [1] * (len(shape) - len(grid))
+                comm = Subcomm(comm, dims)
+            if isinstance(comm, Subcomm):
+                assert slab is False
+                assert len(comm) == len(shape)
+                assert np.all([comm[ax].Get_size() == 1 for ax in axes[-1]])
+                self.subcomm = comm
+            else:
+                if slab is False or slab is None:
+                    dims = [0] * len(shape)
+                    for ax in axes[-1]:
+                        dims[ax] = 1
+                else:
+                    if slab is True:
+                        axis = (axes[-1][-1] + 1) % len(shape)
+                    else:
+                        axis = slab
+                        if axis < 0:
+                            axis = axis + len(shape)
+                        assert 0 <= axis < len(shape)
+                    dims = [1] * len(shape)
+                    dims[axis] = comm.Get_size()
+                self.subcomm = Subcomm(comm, dims)
+        else:
+            dtype = darray.dtype
+            self.subcomm = darray.subcomm
+            self._input_shape = tuple(shape)
+            commsizes = darray.commsizes
+            assert np.all([commsizes[ax] == 1 for ax in axes[-1]]), \
+                "Set keyword axes such that axes to transform first are aligned"
+
+        self.collapse = collapse
+        if collapse is True:
+            groups = [[]]
+            for ax in reversed(axes):
+                if np.all([self.subcomm[axis].Get_size() == 1 for axis in ax]):
+                    [groups[0].insert(0, axis) for axis in reversed(ax)]
+                else:
+                    groups.insert(0, ax)
+            axes = groups
+
+        self.axes = tuple(map(tuple, axes))
+        self.xfftn = []
+        self.transfer = []
+        self.pencil = [None, None]
+
+        axes = self.axes[-1]
+        pencil = Pencil(self.subcomm, shape, axes[-1])
+        xfftn = FFT(pencil.subshape, axes, dtype, padding, backend=backend,
+                    transforms=transforms, **kw)
+        self.xfftn.append(xfftn)
+        self.pencil[0] = pencilA = pencil
+        if not shape[axes[-1]] == xfftn.forward.output_array.shape[axes[-1]]:
+            dtype = xfftn.forward.output_array.dtype
+            shape[axes[-1]] = xfftn.forward.output_array.shape[axes[-1]]
+            pencilA = Pencil(self.subcomm, shape, axes[-1])
+
+        for axes in reversed(self.axes[:-1]):
+            pencilB = pencilA.pencil(axes[-1])
+            transAB = pencilA.transfer(pencilB, dtype)
+            # single-rank redistribution: chain the stages through one buffer instead of copying
+            share = None
+            if transAB.comm.Get_size() == 1 and tuple(pencilB.subshape) == tuple(pencilA.subshape):
+                share = self.xfftn[-1].forward.output_array
+            xfftn = FFT(pencilB.subshape, axes, dtype, padding, backend=backend,
+                        transforms=transforms, U=share, **kw)
+            self.xfftn.append(xfftn)
+            self.transfer.append(transAB)
+            pencilA = pencilB
+            if not shape[axes[-1]] == xfftn.forward.output_array.shape[axes[-1]]:
+                dtype = xfftn.forward.output_array.dtype
+                shape[axes[-1]] = xfftn.forward.output_array.shape[axes[-1]]
+                pencilA = Pencil(pencilB.subcomm, shape, axes[-1])
+
+        self.pencil[1] = pencilA
+        self._output_shape = tuple(shape)
+
+        self.forward = Transform(
+            [o.forward for o in self.xfftn],
+            [o.forward for o in self.transfer],
+            self.pencil)
+        self.backward = Transform(
+            [o.backward for o in self.xfftn[::-1]],
+            [o.backward for o in self.transfer[::-1]],
+            self.pencil[::-1])
+
+    def destroy(self):
+        if isinstance(self.subcomm, Subcomm):
+            self.subcomm.destroy()
+        for trans in self.transfer:
+            trans.destroy()
+        for x in self.xfftn:
+            x.destroy()
+
+    def shape(self, forward_output=True):
+        """Local shape of the spectral (True) or physical (False) array (mpifft.py:355-366)."""
+        if forward_output is not True:
+            return self.forward.input_pencil.subshape
+        return self.forward.output_array.shape
+
+    def local_slice(self, forward_output=True):
+        """This rank's slices into the global array (mpifft.py:368-386)."""
+        ip = self.backward.input_pencil if forward_output is True else self.forward.input_pencil
+        return tuple(slice(start, start + n) for start, n in zip(ip.substart, ip.subshape))
+
+    def global_shape(self, forward_output=False):
+        """Global shape in spectral (True) or physical (False) space (mpifft.py:388-400)."""
+        return self._output_shape if forward_output else self._input_shape
+
+    @property
+    def dimensions(self):
+        return len(self.forward.input_array.shape)
+
+    def dtype(self, forward_output=False):
+        if forward_output:
+            return self.forward.output_array.dtype
+        return self.forward.input_array.dtype
+
+    def cost(self):
+        """(flops, algorithmic bytes) of one forward on this rank, summed over the serial stages
+        (the work model of BASELINE.md section 3)."""
+        f = b = 0.0
+        for x in self.xfftn:
+            cf, cb, _ = x.fwd.cost()
+            f += cf
+            b += cb
+        return f, b

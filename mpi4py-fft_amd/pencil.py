@@ -1,0 +1,200 @@
+"""Block decomposition, sub-communicators, pencils and global redistribution on device memory.
+
+Mirrors the public surface of mpi4py_fft/pencil.py (``Subcomm``, ``Pencil``, ``Transfer``,
+``_blockdist``) so callers and tests read the same.  What differs is the engine underneath
+``Transfer``: the reference hands MPI a pair of subarray datatypes per peer and lets
+``Alltoallw`` gather/scatter (pencil.py:12-29,182-183); here a HIP kernel packs the p sub-blocks
+into one contiguous send buffer, RCCL's all-to-all(v) moves them over xGMI
+(``torch.distributed.all_to_all_single`` on the "nccl" backend), and a second kernel unpacks --
+and when the split axis is the outermost axis the pack (or unpack) is skipped because the
+sub-blocks already are contiguous.
+"""
+import numpy as np
+import torch
+
+from . import comm as _comm
+from . import _lib
+from .array import DeviceArray
+
+
+def _blockdist(N, size, rank):
+    """(length, start) of `rank`'s block when N items are dealt to `size` ranks: the first
+    N % size ranks get one extra.  Same rule as pencil.py:5-9."""
+    q, r = divmod(int(N), int(size))
+    return q + (1 if rank < r else 0), rank * q + min(rank, r)
+
+
+class Subcomm(tuple):
+    """Tuple of 1-D sub-communicators of a Cartesian process grid (pencil.py:32-98).
+
+    comm : a communicator (``comm.world()``, ``comm.COMM_SELF``, a Cartesian view) or an int-like
+    dims : None, int or sequence of ints; 0 (or <= 0) entries are free and filled by
+           ``Compute_dims``; e.g. ``[0, 0, 1]`` distributes the first two axes.
+    """
+    def __new__(cls, comm, dims=None, reorder=True):
+        assert not comm.Is_inter()
+        if comm.Get_topology() == _comm.CART:
+            assert comm.Get_dim() > 0
+            assert dims is None
+            cart = comm
+        else:
+            if dims is None:
+                dims = [0]
+            elif np.ndim(dims) > 0:
+                assert len(dims) > 0
+                dims = [max(0, int(d)) for d in dims]
+            else:
+                assert dims > 0
+                dims = [0] * int(dims)
+            dims = _comm.Compute_dims(comm.Get_size(), dims)
+            cart = comm.Create_cart(dims, reorder=reorder)
+        ndim = cart.Get_dim()
+        subs = []
+        for i in range(ndim):
+            keep = [False] * ndim
+            keep[i] = True
+            subs.append(cart.Sub(keep))
+        return super().__new__(cls, subs)
+
+    def destroy(self):
+        for c in self:
+            if c:
+                c.Free()
+
+
+def _is_outermost(shape, axis):
+    return all(s == 1 for s in shape[:axis])
+
+
+class Transfer:
+    """Global redistribution between two pencils over one sub-communicator (pencil.py:101-209).
+
+    ``forward(arrayA, arrayB)`` moves data from the layout aligned on ``axisA`` to the one
+    aligned on ``axisB``; ``backward`` is the inverse.  Arrays are :class:`DeviceArray`.
+    """
+    def __init__(self, comm, shape, dtype, subshapeA, axisA, subshapeB, axisB):
+        self.comm = comm
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.subshapeA, self.axisA = tuple(int(s) for s in subshapeA), int(axisA)
+        self.subshapeB, self.axisB = tuple(int(s) for s in subshapeB), int(axisB)
+        p = comm.Get_size()
+        self._p = p
+        # element counts per peer: A is cut along axisA, B along axisB (pencil.py:12-29)
+        restA = int(np.prod(self.subshapeA, dtype=np.int64)) // max(1, self.subshapeA[self.axisA])
+        restB = int(np.prod(self.subshapeB, dtype=np.int64)) // max(1, self.subshapeB[self.axisB])
+        self._countsA = [restA * _blockdist(self.shape[self.axisA], p, i)[0] for i in range(p)]
+        self._countsB = [restB * _blockdist(self.shape[self.axisB], p, i)[0] for i in range(p)]
+        assert self.subshapeA[self.axisA] == self.shape[self.axisA]
+        assert self.subshapeB[self.axisB] == self.shape[self.axisB]
+        self._stage = {}
+
+    # -- staging buffers in the real scalar type (all-to-all backends want real dtypes)
+    def _real_view(self, t):
+        return torch.view_as_real(t).reshape(-1) if t.is_complex() else t.reshape(-1)
+
+    def _staging(self, like, role):
+        key = (role, like.numel(), str(like.device))
+        buf = self._stage.get(key)
+        if buf is None:
+            buf = self._stage[key] = torch.empty_like(like)
+        return buf
+
+    def _move(self, src, dst, shape_src, axis_src, counts_src, shape_dst, axis_dst, counts_dst):
+        p = self._p
+        eng = _lib.engine()
+        ts, td = src.tensor, dst.tensor
+        assert ts.is_contiguous() and td.is_contiguous()
+        if p == 1:
+            eng.copy(ts, td)
+            return
+        isz = self.dtype.itemsize
+        mult = 2 if self.dtype.kind == 'c' else 1
+        if _is_outermost(shape_src, axis_src):
+            send = ts
+        else:
+            send = self._staging(ts, 'send')
+            eng.pack(ts, send, shape_src, axis_src, p, isz)
+        direct = _is_outermost(shape_dst, axis_dst)
+        recv = td if direct else self._staging(td, 'recv')
+        self.comm.alltoall(self._real_view(send), self._real_view(recv),
+                           [c * mult for c in counts_src], [c * mult for c in counts_dst])
+        if not direct:
+            eng.unpack(recv, td, shape_dst, axis_dst, p, isz)
+
+    def forward(self, arrayA, arrayB):
+        assert self.subshapeA == tuple(arrayA.shape)
+        assert self.subshapeB == tuple(arrayB.shape)
+        assert self.dtype == arrayA.dtype
+        assert self.dtype == arrayB.dtype
+        self._move(arrayA, arrayB, self.subshapeA, self.axisA, self._countsA,
+                   self.subshapeB, self.axisB, self._countsB)
+
+    def backward(self, arrayB, arrayA):
+        assert self.subshapeA == tuple(arrayA.shape)
+        assert self.subshapeB == tuple(arrayB.shape)
+        assert self.dtype == arrayA.dtype
+        assert self.dtype == arrayB.dtype
+        self._move(arrayB, arrayA, self.subshapeB, self.axisB, self._countsB,
+                   self.subshapeA, self.axisA, self._countsA)
+
+    def destroy(self):
+        self._stage = {}
+
+
+class Pencil:
+    """One rank's block of a distributed array, aligned (undivided) along ``axis``
+    (pencil.py:212-354).  ``subcomm[i]`` is the communicator axis i is distributed over."""
+    def __init__(self, subcomm, shape, axis=-1):
+        assert len(shape) >= 2
+        assert min(shape) >= 1
+        assert -len(shape) <= axis < len(shape)
+        assert 1 <= len(subcomm) <= len(shape)
+        if axis < 0:
+            axis += len(shape)
+        if len(subcomm) < len(shape):
+            subcomm = list(subcomm)
+            while len(subcomm) < len(shape) - 1:
+                subcomm.append(_comm.COMM_SELF)
+            subcomm.insert(axis, _comm.COMM_SELF)
+        assert len(subcomm) == len(shape)
+        assert subcomm[axis].Get_size() == 1
+        subshape, substart = [], []
+        for n, c in zip(shape, subcomm):
+            size, rank = c.Get_size(), c.Get_rank()
+            assert n >= size
+            ln, st = _blockdist(n, size, rank)
+            subshape.append(ln)
+            substart.append(st)
+        self.shape = tuple(int(s) for s in shape)
+        self.axis = axis
+        self.subcomm = tuple(subcomm)
+        self.subshape = tuple(subshape)
+        self.substart = tuple(substart)
+
+    def pencil(self, axis):
+        """A pencil of the same global array aligned along `axis`: the two axes exchange their
+        sub-communicators (pencil.py:309-323)."""
+        assert -len(self.shape) <= axis < len(self.shape)
+        if axis < 0:
+            axis += len(self.shape)
+        sub = list(self.subcomm)
+        sub[self.axis], sub[axis] = sub[axis], sub[self.axis]
+        return Pencil(sub, self.shape, axis)
+
+    def transfer(self, pencil, dtype):
+        """The :class:`Transfer` that redistributes from this pencil to `pencil`
+        (pencil.py:325-354)."""
+        penA, penB = self, pencil
+        assert penA.shape == penB.shape
+        assert penA.axis != penB.axis
+        for i in range(len(penA.shape)):
+            if i != penA.axis and i != penB.axis:
+                assert penA.subcomm[i] == penB.subcomm[i]
+                assert penA.subshape[i] == penB.subshape[i]
+        assert penA.subcomm[penB.axis] == penB.subcomm[penA.axis]
+        axis = penB.axis
+        comm = penA.subcomm[axis]
+        shape = list(penA.subshape)
+        shape[axis] = penA.shape[axis]
+        return Transfer(comm, shape, dtype, penA.subshape, penA.axis, penB.subshape, penB.axis)

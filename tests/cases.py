@@ -1,0 +1,160 @@
+"""Shared test bodies: the same PFFT / Transfer checks run against the HIP engine on a GPU
+(-m gpu) and against the host checker engine on CPU (host-logic tests)."""
+import json
+import os
+
+import numpy as np
+
+from oracle import pfft_oracle as O
+from tests import thread_comm
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+
+
+def pfft_case_names():
+    p = load('pfft')
+    return sorted({k.split('/')[0] for k in p.files})
+
+
+def tol_for(dt, n=1):
+    # forward vs oracle: max|d| <= tol * max|ref|   
+    return 2e-10 if dt in 'dD' else 2e-4
+
+
+def run_ranks(P, fn):
+    from mpi4py_fft_amd import comm
+    if P == 1:
+        return [fn(comm.COMM_SELF)]
+    return thread_comm.run(P, fn)
+
+
+def check_pfft_golden(name):
+    """PFFT of the product package on P (thread-)ranks vs the fixture the reference produced."""
+    from mpi4py_fft_amd import PFFT, newDistArray
+    p = load('pfft')
+    P = int(p[name + '/P'])
+    dt = str(p[name + '/dtype'])
+    shape = tuple(int(s) for s in p[name + '/shape'])
+    kw = json.loads(str(p[name + '/kw']))
+    if 'axes' in kw:
+        kw['axes'] = [tuple(a) if isinstance(a, list) else a for a in kw['axes']]
+    gin = p[name + '/input']
+
+    def body(comm):
+        k = {a: (list(b) if isinstance(b, list) else b) for a, b in kw.items()}
+        fft = PFFT(comm, shape, dtype=dt, **k)
+        u = newDistArray(fft, False)
+        u[...] = gin[fft.local_slice(False)]
+        uh = fft.forward(u)
+        uh_host = np.asarray(uh).copy()
+        ub = np.asarray(fft.backward(uh)).copy()
+        pin, pout = fft.pencil
+        info = dict(axes=[list(a) for a in fft.axes], grid=[c.Get_size() for c in fft.subcomm],
+                    in_subshape=list(pin.subshape), in_substart=list(pin.substart), in_axis=pin.axis,
+                    out_subshape=list(pout.subshape), out_substart=list(pout.substart),
+                    out_axis=pout.axis, gshape_in=list(fft.global_shape(False)),
+                    gshape_out=list(fft.global_shape(True)), nxfftn=len(fft.xfftn),
+                    ntransfer=len(fft.transfer),
+                    transfers=[[t.comm.Get_size(), list(t.shape), list(t.subshapeA), t.axisA,
+                                list(t.subshapeB), t.axisB] for t in fft.transfer])
+        # structural asserts of tests/test_mpifft.py:144-164
+        assert fft.dtype(True) == fft.forward.output_array.dtype
+        assert fft.dtype(False) == fft.forward.input_array.dtype
+        assert len(fft.axes) == len(fft.xfftn) == len(fft.transfer) + 1
+        assert fft.forward.input_pencil.subshape == fft.forward.input_array.shape
+        assert fft.forward.output_pencil.subshape == fft.forward.output_array.shape
+        assert fft.backward.input_pencil.subshape == fft.backward.input_array.shape
+        assert fft.backward.output_pencil.subshape == fft.backward.output_array.shape
+        assert fft.dimensions == len(shape)
+        fft.destroy()
+        return info, uh_host, ub
+
+    res = run_ranks(P, body)
+    tol = tol_for(dt)
+    for r, (info, uh, ub) in enumerate(res):
+        ref_info = json.loads(str(p['%s/r%d/info' % (name, r)]))
+        for key in ref_info:
+            assert info[key] == ref_info[key], (name, r, key, info[key], ref_info[key])
+        ref = p['%s/r%d/fwd' % (name, r)]
+        assert uh.shape == ref.shape and uh.dtype == ref.dtype, (name, uh.shape, ref.shape)
+        assert np.abs(uh - ref).max() <= tol * max(np.abs(ref).max(), 1e-30), \
+            (name, r, 'forward', np.abs(uh - ref).max())
+        refb = p['%s/r%d/bwd' % (name, r)]
+        assert ub.shape == refb.shape and ub.dtype == refb.dtype
+        assert np.abs(ub - refb).max() <= 10 * tol * max(np.abs(refb).max(), 1e-30), \
+            (name, r, 'backward', np.abs(ub - refb).max())
+
+
+def check_transfer_golden(ci):
+    """tests/test_pencil.py's chain on the product Transfer vs what the reference's Alltoallw
+    delivered (fixture), plus the fwd.fwd.bwd.bwd identity."""
+    from mpi4py_fft_amd import Subcomm, Pencil, asdevice, zeros
+    t = load('transfer')
+    key = 'transfer%d' % ci
+    P = int(t[key + '/P'])
+    shape = tuple(int(s) for s in t[key + '/shape'])
+    a1, a2, a3 = (int(a) for a in t[key + '/axes'])
+    pdim = int(t[key + '/pdim'])
+    pdim = None if pdim < 0 else pdim
+    G = np.arange(int(np.prod(shape)), dtype='d').reshape(shape)
+
+    def body(comm):
+        subcomm = Subcomm(comm, pdim)
+        p0 = Pencil(subcomm, shape)
+        pA = p0.pencil(a1)
+        pB = pA.pencil(a2)
+        pC = pB.pencil(a3)
+        t1 = Pencil.transfer(pA, pB, 'd')
+        t2 = Pencil.transfer(pB, pC, 'd')
+        sl = tuple(slice(s, s + n) for s, n in zip(pA.substart, pA.subshape))
+        A = asdevice(np.ascontiguousarray(G[sl]))
+        B = zeros(pB.subshape)
+        C = zeros(pC.subshape)
+        t1.forward(A, B)
+        t2.forward(B, C)
+        A2, B2 = zeros(pA.subshape), zeros(pB.subshape)
+        t2.backward(C, B2)
+        t1.backward(B2, A2)
+        geo = np.array([pA.subshape, pA.substart, pB.subshape, pB.substart, pC.subshape, pC.substart])
+        return geo, np.asarray(A), np.asarray(B), np.asarray(C), np.asarray(A2)
+
+    for r, (geo, A, B, C, A2) in enumerate(run_ranks(P, body)):
+        assert np.array_equal(geo, t['%s/r%d/geo' % (key, r)])
+        assert np.array_equal(A, t['%s/r%d/A' % (key, r)])
+        assert np.array_equal(B, t['%s/r%d/B' % (key, r)]), (key, r)
+        assert np.array_equal(C, t['%s/r%d/C' % (key, r)]), (key, r)
+        assert np.array_equal(A2, A)
+
+
+def check_pfft_vs_oracle(P, shape, dt, seed=7, **kw):
+    """Product PFFT on P ranks vs the oracle on the same seeded input: forward values,
+    round trip, and the global-DFT identity for unpadded transforms."""
+    from mpi4py_fft_amd import PFFT, newDistArray
+    offt = O.OPFFT(P, shape, dtype=dt, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+    G = O.rng_array(offt.input_shape, dt, seed)
+    ref = offt.forward(offt.scatter(G))
+
+    def body(comm):
+        k = {a: (list(b) if isinstance(b, list) else b) for a, b in kw.items()}
+        fft = PFFT(comm, shape, dtype=dt, **k)
+        u = newDistArray(fft, False)
+        u[...] = G[fft.local_slice(False)]
+        uh = np.asarray(fft.forward(u)).copy()
+        back = np.asarray(fft.backward()).copy()
+        sl = fft.local_slice(False)
+        fft.destroy()
+        return uh, back, sl
+
+    tol = tol_for(dt)
+    for r, (uh, back, sl) in enumerate(run_ranks(P, body)):
+        assert uh.shape == ref[r].shape and uh.dtype == ref[r].dtype
+        scale = max(np.abs(ref[r]).max(), 1e-30)
+        assert np.abs(uh - ref[r]).max() <= tol * scale, (shape, dt, kw, np.abs(uh - ref[r]).max() / scale)
+        if not kw.get('padding'):
+            d = back - G[sl]
+            rel = np.linalg.norm(d) / np.linalg.norm(G[sl])
+            assert rel <= (1e-10 if dt in 'dD' else 1e-4), (shape, dt, kw, rel)

@@ -1,0 +1,100 @@
+"""CHECKER engine for CPU-only tests of the host logic (TEST INFRASTRUCTURE).
+
+Implements the `_lib.HipEngine` interface with numpy on host tensors so that pencil arithmetic,
+exchange plans, buffer chaining and the communicator layer can be exercised where no GPU exists
+(the `-m "not gpu"` suite, incl. the world_size-2 gloo tests).  It is injected explicitly with
+`_lib.set_engine(HostEngine())` by tests; the package never selects it.  The arithmetic is the
+oracle's (numpy pocketfft), so a test using this engine checks orchestration, not kernels.
+"""
+import numpy as np
+import torch
+
+from oracle import pfft_oracle as O
+
+
+def _np(t):
+    return t.numpy()
+
+
+class HostEngine:
+    name = 'host-checker'
+
+    def require_device(self, tensor):
+        pass
+
+    def plan_create(self, sizes_in, sizes_out, axes, kind, precision):
+        return dict(sizes_in=tuple(sizes_in), sizes_out=tuple(sizes_out), axes=tuple(axes),
+                    kind=kind, precision=precision)
+
+    def plan_execute(self, h, tin, tout, scale):
+        a = _np(tin).reshape(h['sizes_in'])
+        axes, kind = h['axes'], h['kind']
+        if kind == -1:
+            r = np.fft.fftn(a, axes=axes)
+        elif kind == 1:
+            r = np.fft.ifftn(a, axes=axes) * np.prod([a.shape[i] for i in axes])
+        elif kind == -2:
+            r = np.fft.rfftn(a, axes=axes)
+        else:
+            s = [h['sizes_out'][i] for i in axes]
+            r = np.fft.irfftn(a, s=s, axes=axes) * np.prod(s)
+        _np(tout).reshape(h['sizes_out'])[...] = (r * scale).astype(_np(tout).dtype)
+
+    def plan_destroy(self, h):
+        pass
+
+    def plan_describe(self, h):
+        return 'host checker plan %r' % (h,)
+
+    def plan_cost(self, h):
+        return 0.0, 0.0, 0
+
+    def pack(self, tarray, tpacked, shape, axis, nparts, itemsize):
+        a = _np(tarray).reshape(shape)
+        out = _np(tpacked).reshape(-1)
+        pos = 0
+        for i in range(nparts):
+            n, s = O.blockdist(shape[axis], nparts, i)
+            ix = [slice(None)] * len(shape)
+            ix[axis] = slice(s, s + n)
+            blk = np.ascontiguousarray(a[tuple(ix)]).reshape(-1)
+            out[pos:pos + blk.size] = blk
+            pos += blk.size
+
+    def unpack(self, tpacked, tarray, shape, axis, nparts, itemsize):
+        a = _np(tarray).reshape(shape)
+        src = _np(tpacked).reshape(-1)
+        pos = 0
+        for i in range(nparts):
+            n, s = O.blockdist(shape[axis], nparts, i)
+            ix = [slice(None)] * len(shape)
+            ix[axis] = slice(s, s + n)
+            sz = a[tuple(ix)].size
+            a[tuple(ix)] = src[pos:pos + sz].reshape(a[tuple(ix)].shape)
+            pos += sz
+
+    def _offt(self, shape_padded, axis, n_trunc, is_real):
+        # an OFFT whose truncation helpers we borrow: fake a padded transform along `axis`
+        f = O.OFFT.__new__(O.OFFT)
+        f.axes = (axis,)
+        f.real = bool(is_real)
+        full = list(shape_padded)
+        out = list(shape_padded)
+        out[axis] = n_trunc
+        f.full_out_shape, f.out_shape = tuple(full), tuple(out)
+        return f
+
+    def truncate(self, tpadded, ttrunc, shape_padded, axis, n_trunc, is_real, precision, scale):
+        f = self._offt(shape_padded, axis, n_trunc, is_real)
+        r = f._truncate(_np(tpadded).reshape(shape_padded)) * scale
+        _np(ttrunc).reshape(f.out_shape)[...] = r
+
+    def pad(self, ttrunc, tpadded, shape_padded, axis, n_trunc, is_real, precision):
+        f = self._offt(shape_padded, axis, n_trunc, is_real)
+        _np(tpadded).reshape(shape_padded)[...] = f._pad(_np(ttrunc).reshape(f.out_shape))
+
+    def scale(self, t, count, precision, scale):
+        t.mul_(scale)
+
+    def copy(self, tsrc, tdst):
+        tdst.copy_(tsrc)

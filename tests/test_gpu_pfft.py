@@ -1,0 +1,191 @@
+"""GPU parity of PFFT / Transfer / DistArray through the product path (HIP engine), on one GPU
+with thread-ranks standing in for processes (tests/thread_comm.py: the kernels are real, only
+the RCCL wire is replaced by device copies)."""
+import itertools
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import cases
+
+
+@pytest.mark.parametrize('name', cases.pfft_case_names())
+def test_pfft_matches_reference_fixture(name):
+    cases.check_pfft_golden(name)
+
+
+@pytest.mark.parametrize('ci', range(6))
+def test_transfer_matches_reference_fixture(ci):
+    cases.check_transfer_golden(ci)
+
+
+@pytest.mark.parametrize('dt', list('fdFD'))
+def test_pencil_loop(dt):
+    """tests/test_pencil.py: fwd.fwd.bwd.bwd = identity, sizes (7,8,9), 2 and 4 ranks."""
+    from mpi4py_fft_amd import Subcomm, Pencil, asdevice, zeros
+    from tests import thread_comm
+    for P in (2, 4):
+        for dim in (2, 3):
+            for shape in itertools.product(*([(7, 8, 9)] * dim)):
+                axes = list(range(dim))
+                for a1, a2, a3 in itertools.product(axes, axes, axes):
+                    if a1 == a2 or a2 == a3 or min(shape) < P:
+                        continue
+                    if (a1 + a2 + a3 + shape[0]) % 3:      # thin the reference's full product
+                        continue
+                    for pdim in [None] + list(range(1, dim - 1)):
+                        def body(comm):
+                            sub = Subcomm(comm, pdim)
+                            pA = Pencil(sub, shape).pencil(a1)
+                            pB = pA.pencil(a2)
+                            pC = pB.pencil(a3 - len(shape))
+                            t1, t2 = Pencil.transfer(pA, pB, dt), Pencil.transfer(pB, pC, dt)
+                            X = np.random.default_rng(comm.Get_rank()).random(pA.subshape).astype(dt)
+                            A, B, C = asdevice(X), zeros(pB.subshape, dt), zeros(pC.subshape, dt)
+                            t1.forward(A, B)
+                            t2.forward(B, C)
+                            B.fill(0)
+                            t2.backward(C, B)
+                            A.fill(0)
+                            t1.backward(B, A)
+                            return np.array_equal(np.asarray(A), X)
+                        assert all(thread_comm.run(P, body)), (P, shape, a1, a2, a3, pdim)
+
+
+def _allaxes(dim):
+    if dim == 2:
+        return [None, (-1,), (-2,), (-1, -2), (-2, -1), (-1, 0), (0, -1), ((0,), (1,))]
+    if dim == 3:
+        return [None, ((0,), (1, 2)), ((0,), (-2, -1))]
+    return [None, ((0,), (1,), (2,), (3,)), ((0,), (1, 2, 3)), ((0,), (1,), (2, 3))]
+
+
+@pytest.mark.parametrize('P', [1, 2, 4])
+@pytest.mark.parametrize('dt', list('fdFD'))
+def test_mpifft_loop(P, dt):
+    """tests/test_mpifft.py:57-177 (sizes 12/13, dims 2-4, grids, collapse, axes spellings),
+    checking values against the oracle as well as the round trip."""
+    for dim in (2, 3, 4):
+        shapes = list(itertools.product(*([(12, 13)] * dim)))
+        for shape in shapes[::3] if dim == 4 else shapes:
+            if dim < 3:
+                n = min(shape)
+                if dt in 'fd':
+                    n = n // 2 + 1
+                if n < P:
+                    continue
+            for grid in ((None,) if dim == 2 else ((-1,), None)):
+                for collapse in (True, False):
+                    for axes in _allaxes(dim):
+                        g = grid
+                        if grid is not None:
+                            ax = -1
+                            if axes is not None:
+                                ax = axes[-1] if isinstance(axes[-1], int) else axes[-1][-1]
+                            slab = (ax + 1) % len(shape)
+                            g = [1] * (slab + 1)
+                            g[slab] = 0
+                        kw = dict(collapse=collapse)
+                        if axes is not None:
+                            kw['axes'] = axes
+                        if g is not None:
+                            kw['grid'] = g
+                        cases.check_pfft_vs_oracle(P, shape, dt, **kw)
+
+
+@pytest.mark.parametrize('P', [1, 2, 4])
+@pytest.mark.parametrize('dt', list('dDF'))
+def test_mpifft_padding(P, dt):
+    """tests/test_mpifft.py:181-251: padding 1.5, fwd.bwd.fwd idempotence and swapped normalize."""
+    from mpi4py_fft_amd import PFFT, newDistArray
+    from oracle import pfft_oracle as O
+    for shape, axes in (((12, 13), None), ((12, 13), (-2, -1)), ((12, 13, 12), None),
+                        ((13, 12, 12), ((0,), (1,), (2,))), ((12, 12, 13, 12), ((0,), (1,), (2,), (3,)))):
+        if P > 1 and len(shape) == 2 and dt == 'd':
+            continue
+        padding = [1.5] * len(shape)
+        kw = dict(padding=padding)
+        if axes is not None:
+            kw['axes'] = axes
+        cases.check_pfft_vs_oracle(P, shape, dt, **kw)
+
+        def body(comm):
+            fft = PFFT(comm, shape, dtype=dt, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+            U = np.random.default_rng(comm.Get_rank()).random(fft.forward.input_array.shape).astype(dt)
+            F = np.asarray(fft.forward(U)).copy()
+            fft.backward.input_array[...] = F
+            fft.backward()
+            fft.forward()
+            ok1 = np.allclose(np.asarray(fft.forward.output_array), F, rtol=0, atol=2e-10 if dt in 'dD' else 1e-4)
+            fft.backward.input_array[...] = F
+            fft.backward(normalize=True)
+            fft.forward(normalize=False)
+            ok2 = np.allclose(np.asarray(fft.forward.output_array), F, rtol=0, atol=2e-10 if dt in 'dD' else 1e-4)
+            fft.destroy()
+            return ok1 and ok2
+        assert all(cases.run_ranks(P, body)), (shape, axes, dt, P)
+
+
+def test_distarray_redistribute_and_pfft_darray():
+    """tests/test_darray.py: norm conservation under redistribute, rank-1 fields, PFFT(darray=)."""
+    from mpi4py_fft_amd import DistArray, newDistArray, PFFT, Subcomm
+    from tests import thread_comm
+
+    def body(c):
+        N = (8, 10, 12)
+        sub = Subcomm(c, [0, 0, 1])
+        z = DistArray(N, subcomm=sub, dtype=float, alignment=2)
+        z[...] = np.random.default_rng(c.Get_rank()).random(z.shape)
+        n0 = sum(c.allgather_obj(float(np.sum(np.asarray(z) ** 2))))
+        z1 = z.redistribute(1)
+        z0 = z1.redistribute(0)
+        n1 = sum(c.allgather_obj(float(np.sum(np.asarray(z1) ** 2))))
+        n2 = sum(c.allgather_obj(float(np.sum(np.asarray(z0) ** 2))))
+        assert np.isclose(n0, n1) and np.isclose(n0, n2)
+        v = DistArray((3,) + N, subcomm=sub, dtype='D', alignment=2, rank=1)
+        v[...] = np.random.default_rng(5).random(v.shape) + 0j
+        w = v.redistribute(0)
+        m0 = sum(c.allgather_obj(float(np.sum(np.abs(np.asarray(v)) ** 2))))
+        m1 = sum(c.allgather_obj(float(np.sum(np.abs(np.asarray(w)) ** 2))))
+        assert np.isclose(m0, m1)
+        fft = PFFT(c, darray=z1)          # aligned axis 1 must be transformed first
+        u = newDistArray(fft, False)
+        assert u.shape == z1.shape
+        u[...] = z1
+        uh = fft.forward(u)
+        back = fft.backward(uh)
+        assert np.allclose(np.asarray(back), np.asarray(z1), atol=1e-12)
+        return True
+
+    for P in (1, 2, 4):
+        assert all(cases.run_ranks(P, body) if P > 1 else [body(__import__('mpi4py_fft_amd').comm.COMM_SELF)])
+
+
+def test_nccl_world_of_one():
+    """The torch.distributed/RCCL plumbing of comm.TorchComm on the one GPU a test box has."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from mpi4py_fft_amd import comm, PFFT, newDistArray
+    if dist.is_initialized():
+        pytest.skip('process group already initialised')
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29631')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        w = comm.world()
+        assert w.Get_size() == 1
+        fft = PFFT(w, (16, 12, 10), dtype='D')
+        u = newDistArray(fft, False)
+        G = np.random.default_rng(0).random(u.shape) + 0j
+        u[...] = G
+        uh = np.asarray(fft.forward(u))
+        assert np.allclose(uh, np.fft.fftn(G) / G.size, atol=1e-14)
+        t = torch.arange(8, dtype=torch.float64, device='cuda')
+        r = torch.empty_like(t)
+        dist.all_to_all_single(r, t, [8], [8])       # RCCL alltoallv code path
+        assert torch.equal(r, t)
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,177 @@
+"""GPU parity of the serial transforms, called through the C ABI (fftw planners -> libgfft.so),
+against the oracle (numpy pocketfft, pinned to the reference by test_oracle_golden.py).
+Tolerances: fp64 forward max|d| <= 2e-10 max|ref| and round trip <= 1e-10;
+in practice ~1e-15.  fp32: 2e-4 / 1e-4."""
+import itertools
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pfft_oracle as O
+
+
+def _tol(dt):
+    return 2e-10 if dt in 'dD' else 2e-4
+
+
+def _check(shape, axes, dt, seed=0):
+    from mpi4py_fft_amd import FFT, asdevice
+    fft = FFT(shape, axes, dtype=dt)
+    ref = O.OFFT(shape, axes, dt)
+    A = O.rng_array(shape, dt, seed)
+    B = np.asarray(fft.forward(asdevice(A)))
+    Bref = ref.forward(A)
+    assert B.shape == Bref.shape and B.dtype == Bref.dtype
+    err = np.abs(B - Bref).max() / max(np.abs(Bref).max(), 1e-30)
+    assert err <= _tol(dt), (shape, axes, dt, 'fwd', err)
+    A2 = np.asarray(fft.backward(asdevice(Bref)))
+    rt = np.linalg.norm(A2 - A) / np.linalg.norm(A)
+    assert A2.shape == A.shape and A2.dtype == A.dtype
+    assert rt <= (1e-10 if dt in 'dD' else 1e-4), (shape, axes, dt, 'round trip', rt)
+    # tighter than the contract: fp64 should be at rounding level
+    if dt in 'dD':
+        assert err < 1e-13 and rt < 1e-13, (shape, axes, err, rt)
+    fft.destroy()
+
+
+def test_docstring_kats(golden):
+    from mpi4py_fft_amd import fftw
+    k = golden['libfft']
+    A = fftw.aligned(4, dtype='D')
+    plan = fftw.fftn(A, flags=(fftw.FFTW_ESTIMATE,))
+    A[:] = k['kat/fftn_in']
+    B = plan()
+    assert np.allclose(B, k['kat/fftn_out'], atol=1e-14)
+    assert plan.input_array is A and plan.output_array is B
+    A = fftw.aligned(4, dtype='d')
+    plan = fftw.rfftn(A)
+    A[:] = k['kat/rfftn_in']
+    assert np.allclose(plan(), k['kat/rfftn_out'], atol=1e-14)
+    A = fftw.aligned(4, dtype='D')
+    plan = fftw.irfftn(A)
+    A[:] = k['kat/irfftn_in']
+    assert np.allclose(plan(), k['kat/irfftn_out6'], atol=1e-13)
+    plan = fftw.irfftn(A, s=(7,))
+    A[:] = k['kat/irfftn_in']
+    assert np.allclose(plan(), k['kat/irfftn_out7'], atol=1e-7)
+    plan = fftw.fftn(A)
+    A[:] = k['kat/fftn_in']
+    assert np.allclose(plan(normalize=True), k['kat/fftn_out'] / 4, atol=1e-14)
+
+
+@pytest.mark.parametrize('dt', list('dDfF'))
+def test_libfft_loop(dt):
+    """tests/test_libfft.py:24-64: dims 1-3, sizes (7,8,9), contiguous axis subsets."""
+    sizes = (7, 8, 9)
+    for dim in (1, 2, 3):
+        for shape in itertools.product(*([sizes] * dim)):
+            allaxes = tuple(reversed(range(dim)))
+            for i in range(dim):
+                for j in range(i + 1, dim):
+                    for axes in (None, allaxes[i:j]):
+                        _check(shape, axes, dt)
+
+
+@pytest.mark.parametrize('dt', ['D', 'F'])
+@pytest.mark.parametrize('n', [16, 32, 64, 128, 256, 512, 1024, 2048, 4096])
+def test_pow2_rows_and_cols(n, dt):
+    _check((5, n), (1,), dt)          # contiguous axis: ROWS kernels, ragged tile
+    _check((n, 20), (0,), dt)         # strided axis: COLS kernels, ragged tile (20 % 8, 20 % 16)
+    _check((3, n, 9), (1,), dt)       # strided axis in the middle, odd inner
+
+
+@pytest.mark.parametrize('dt', ['d', 'f'])
+@pytest.mark.parametrize('n', [16, 64, 256, 1024, 2048])
+def test_pow2_real(n, dt):
+    _check((6, n), (1,), dt)
+    _check((n, 12), (0,), dt)
+    _check((4, n, 6), (1, 0), dt)
+
+
+@pytest.mark.parametrize('shape,axes', [
+    ((2, 3), None), ((1, 5), (1,)), ((13,), None), ((12, 13), (0, 1)), ((12, 13), (1, 0)),
+    ((100, 3), (0,)), ((3, 100), (1,)), ((6, 35, 4), (1,)), ((243, 2), (0,)), ((2, 625), (1,)),
+    ((4, 1001), (1,)), ((1000, 5), (0,)), ((17, 19, 23), None), ((30, 30, 30), (2, 0, 1)),
+    ((3000, 2), (0,)), ((2, 4095), (1,)), ((127, 3), (0,)), ((3, 509), (1,)),
+])
+@pytest.mark.parametrize('dt', ['D', 'd'])
+def test_generic_sizes(shape, axes, dt):
+    _check(shape, axes, dt)
+
+
+@pytest.mark.parametrize('n', [8192, 16384, 5000, 10000, 1 << 18])
+def test_four_step_1d(n):
+    _check((3, n), (1,), 'D')
+    _check((n, 3), (0,), 'D')
+
+
+def test_four_step_2pow20_batch():
+    """BASELINE config C2 (batched 1-D 2^20, complex128), at a batch the oracle finishes fast."""
+    _check((4, 1 << 20), (1,), 'D')
+    _check((2, 1 << 20), (1,), 'F')
+
+
+def test_in_place_and_implicit_arrays():
+    from mpi4py_fft_amd import fftw, asdevice
+    A = O.rng_array((64, 48), 'D', 3)
+    a = asdevice(A)
+    plan = fftw.fftn(a, axes=(0, 1), output_array=a)       # in place
+    plan()
+    assert np.abs(np.asarray(a) - np.fft.fftn(A)).max() < 1e-12 * np.abs(A).max() * A.size ** 0.5
+    b, c = asdevice(A), fftw.aligned(A.shape, dtype='D')
+    plan2 = fftw.fftn(fftw.aligned(A.shape, dtype='D'), axes=(1,))
+    out = plan2(b, c)                                      # implicit: runs directly on b -> c
+    assert out is c
+    assert np.allclose(np.asarray(c), np.fft.fft(A, axis=1), atol=1e-11)
+    assert np.array_equal(np.asarray(b), A)                # out-of-place c2c preserves its input
+
+
+def test_plan_failure_raises():
+    from mpi4py_fft_amd import fftw
+    with pytest.raises(RuntimeError):
+        fftw.fftn(fftw.aligned((2, 1 << 25), dtype='D'), axes=(1,))   # length >= 2^24
+
+
+@pytest.mark.parametrize('dt', ['D', 'd', 'F'])
+def test_padding_truncation(dt):
+    """tests/test_libfft.py:67-98: fwd . bwd . fwd idempotence + values vs the oracle."""
+    from mpi4py_fft_amd import FFT, asdevice
+    for padding in (1.5, 2.0):
+        for shape in ((12, 9), (9, 12), (13, 8, 12), (18, 7)):
+            for axis in range(len(shape)):
+                shp = list(shape)
+                shp[axis] = int(shp[axis] * padding)
+                fft = FFT(shp, axis, dtype=dt, padding=padding)
+                ref = O.OFFT(shp, axis, dt, padding=padding)
+                A = O.rng_array(shp, dt, 11)
+                B = np.asarray(fft.forward(asdevice(A))).copy()
+                Bref = ref.forward(A)
+                tol = _tol(dt)
+                assert B.shape == Bref.shape
+                assert np.abs(B - Bref).max() <= tol * np.abs(Bref).max(), (shp, axis, padding)
+                A1 = np.asarray(fft.backward(asdevice(B))).copy()
+                assert np.abs(A1 - ref.backward(Bref)).max() <= 10 * tol * np.abs(A).max()
+                B2 = np.asarray(fft.forward(asdevice(A1)))
+                assert np.abs(B2 - B).max() <= 10 * tol * np.abs(B).max()
+                fft.destroy()
+
+
+def test_pack_unpack_blocks():
+    from mpi4py_fft_amd import _lib, asdevice, zeros
+    eng = _lib.engine()
+    rng = np.random.default_rng(0)
+    for shape, axis, p, dt in (((7, 8, 9), 1, 3, 'd'), ((7, 8, 9), 2, 4, 'D'), ((5, 13), 0, 2, 'f'),
+                               ((4, 9, 6), 0, 4, 'D'), ((3, 1025, 4), 1, 2, 'F'), ((16, 16, 16), 2, 8, 'D')):
+        a = rng.standard_normal(shape).astype(dt)
+        d = asdevice(a)
+        packed = zeros(shape, dt)
+        eng.pack(d.tensor, packed.tensor, shape, axis, p, a.itemsize)
+        ref = np.concatenate([np.ascontiguousarray(
+            np.take(a, range(s, s + n), axis=axis)).reshape(-1)
+            for n, s in (O.blockdist(shape[axis], p, i) for i in range(p))])
+        assert np.array_equal(np.asarray(packed).reshape(-1), ref), (shape, axis, p)
+        back = zeros(shape, dt)
+        eng.unpack(packed.tensor, back.tensor, shape, axis, p, a.itemsize)
+        assert np.array_equal(np.asarray(back), a)

@@ -190,3 +190,59 @@ def test_pfft_equals_global_dft():
         uh = fft.forward(fft.scatter(G))
         full = (np.fft.rfftn(G, axes=range(len(shape))) if dt == 'd' else np.fft.fftn(G)) / G.size
         assert np.abs(fft.gather(uh) - full).max() < 1e-15 * G.size
+
+
+# ---- the plain-C restatement (oracle/dft_oracle.c) -------------------------------------------
+def _c_oracle():
+    import ctypes
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle')
+    so = os.path.join(here, 'libdft_oracle.so')
+    if not os.path.exists(so):
+        subprocess.check_call(['make', '-C', here])
+    lib = ctypes.CDLL(so)
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.dft_oracle_xfftn.argtypes = [ctypes.c_int, i64p, dp, i64p, dp, ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+
+    def run(a, axes, kind, out_shape, out_dtype):
+        a = np.ascontiguousarray(a, dtype='D' if a.dtype.kind == 'c' else 'd')
+        out = np.zeros(out_shape, dtype=out_dtype)
+        si = (ctypes.c_int64 * a.ndim)(*a.shape)
+        so_ = (ctypes.c_int64 * a.ndim)(*out_shape)
+        ax = (ctypes.c_int * len(axes))(*axes)
+        rc = lib.dft_oracle_xfftn(a.ndim, si, a.view('d').ctypes.data_as(dp), so_,
+                                  out.view('d').ctypes.data_as(dp), len(axes), ax, kind)
+        assert rc == 0
+        return out
+    return run
+
+
+def test_c_oracle_kats_and_fixtures(golden):
+    run = _c_oracle()
+    k = golden['libfft']
+    assert np.allclose(run(k['kat/fftn_in'], [0], -1, (4,), 'D'), k['kat/fftn_out'], atol=1e-14)
+    assert np.allclose(run(k['kat/rfftn_in'], [0], -2, (3,), 'D'), k['kat/rfftn_out'], atol=1e-14)
+    assert np.allclose(run(k['kat/irfftn_in'], [0], 2, (6,), 'd'), k['kat/irfftn_out6'], atol=1e-13)
+    assert np.allclose(run(k['kat/irfftn_in'], [0], 2, (7,), 'd'), k['kat/irfftn_out7'], atol=1e-7)
+    # unpadded fp64 libfft fixtures: forward (scaled by 1/M in the reference) and backward
+    i = 0
+    checked = 0
+    while 'libfft%d/A' % i in k.files:
+        p = 'libfft%d/' % i
+        i += 1
+        dt = str(k[p + 'dtype'])
+        if float(k[p + 'padding']) or dt in 'fF':
+            continue
+        A, B, A2 = k[p + 'A'], k[p + 'B'], k[p + 'A2']
+        axes = [int(a) for a in k[p + 'axes']]
+        axes = list(range(A.ndim)) if axes == [-99] else axes
+        M = np.prod([A.shape[a] for a in axes])
+        fwd = run(A, axes, -2 if dt == 'd' else -1, B.shape, 'D') / M
+        assert np.abs(fwd - B).max() < 1e-14 * max(1, np.abs(B).max())
+        bwd = run(B, axes, 2 if dt == 'd' else 1, A.shape, dt)
+        assert np.abs(bwd - A2).max() < 1e-13 * max(1, np.abs(A2).max())
+        checked += 1
+    assert checked >= 8
