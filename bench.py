@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 3-D c2c PFFT, 1024^3 complex128, forward + backward per step.
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run,
+                                                        one rank per GPU, RCCL over xGMI)
+
+Prints ONE JSON line (rank 0).  `value` = whole-job GFLOP/s with the work model of BASELINE.md
+section 3 (5 N log2 N flops per 1-D line => 1.6106e11 per 1024^3 transform, fwd + bwd per step),
+inputs resident in HBM before the timed region, barrier + device sync on both sides, max over
+ranks.  `roofline` is for the dominant kernel (the strided-axis pass kernel): algorithmic bytes
+per launch (one read + one write of the local array) / its mean launch duration from HIP events
+recorded on the launch stream inside the timed region.  `cpu_baseline` times the oracle (numpy
+restatement of the reference path; scipy pocketfft on all host cores) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ~5.3-5.6 TB/s
+
+
+def flops_c2c(shape):
+    n = float(np.prod(shape))
+    return 5.0 * n * np.log2(n)
+
+
+def cpu_baseline(cores, budget_s=25.0):
+    """Oracle (port of the reference path) on the host: 3-D c2c fwd+bwd, largest power-of-two
+    cube whose estimated time fits the budget."""
+    from oracle import pfft_oracle as O
+    n = 128
+    best = None
+    while n <= 512:
+        shape = (n, n, n)
+        fft = O.OPFFT(1, shape, dtype='D', workers=cores)
+        u = [O.rng_array(shape, 'D', 1234)]
+        times = []
+        t_all = time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            uh = fft.forward(u)
+            ub = fft.backward(uh)
+            times.append(time.perf_counter() - t0)
+            last = n == 512 or times[0] * 9 > budget_s
+            if not last or len(times) >= 5 or time.perf_counter() - t_all > 0.6 * budget_s:
+                break
+        dt = min(times)
+        err = float(np.linalg.norm(ub[0] - u[0]) / np.linalg.norm(u[0]))
+        best = dict(value=round(2 * flops_c2c(shape) / dt / 1e9, 2), unit='GFLOP/s', cores=cores,
+                    kind='port', sample='%d^3 complex128 fwd+bwd, best of %d, scipy pocketfft workers=%d, '
+                    'round-trip rel err %.1e, %.2f s per fwd+bwd' % (n, len(times), cores, err, dt))
+        del fft, u, uh, ub
+        if times[0] * 9 > budget_s:      # the next cube costs ~9x
+            break
+        n *= 2
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--n', type=int, default=1024, help='cube edge (default: the BASELINE config)')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    args = ap.parse_args()
+
+    from mpi4py_fft_amd import PFFT, comm, _lib
+    world = comm.init_distributed()
+    rank, size = world.Get_rank(), world.Get_size()
+    assert size == args.gpus, 'launched with %d ranks but --gpus %d' % (size, args.gpus)
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback exists)'
+    dev = torch.cuda.current_device()
+
+    n = args.n
+    shape = (n, n, n)
+    fft = PFFT(world, shape, dtype='D')
+    u = fft.forward.input_array
+    g = torch.Generator(device='cuda').manual_seed(1234 + rank)
+    ur = torch.view_as_real(u.tensor)
+    for i in range(0, ur.shape[0], max(1, min(64, ur.shape[0]))):
+        sl = ur[i:i + 64]
+        sl.copy_(torch.randn(sl.shape, generator=g, device='cuda', dtype=torch.float64))
+    u0 = u.tensor.clone()
+
+    def one_step():
+        fft.forward()
+        fft.backward()
+
+    # parity gate (north-star tolerance): forward -> backward round trip on this rank's block
+    one_step()
+    torch.cuda.synchronize()
+    num = float((torch.view_as_real(u.tensor) - torch.view_as_real(u0)).pow(2).sum().item())
+    den = float(torch.view_as_real(u0).pow(2).sum().item())
+    sums = world.allgather_obj((num, den))
+    rt_err = float(np.sqrt(sum(s[0] for s in sums) / sum(s[1] for s in sums)))
+    assert rt_err <= 1e-10, 'round-trip rel err %.3e exceeds 1e-10' % rt_err
+    del u0
+
+    for _ in range(args.warmup):
+        one_step()
+    _lib.set_option('profile', 1)
+    world.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    world.barrier()
+    t1 = time.perf_counter()
+    _lib.set_option('profile', 0)
+    elapsed = world.allreduce_max(t1 - t0)
+
+    # per-kernel launch durations inside the timed region (HIP events on the launch stream)
+    kern = {}
+    plans = list(fft._fused_plans) if fft._fused_plans else \
+        [x.fwd for x in fft.xfftn] + [x.bck for x in fft.xfftn]
+    for p in plans:
+        for name, nbytes, ms, launches in p.profile():
+            if launches:
+                k = kern.setdefault(name, dict(bytes=nbytes, ms=0.0, launches=0))
+                k['ms'] += ms
+                k['launches'] += launches
+    roofline = None
+    if kern:
+        name = max(kern, key=lambda k: kern[k]['ms'])
+        k = kern[name]
+        avg_ms = k['ms'] / k['launches']
+        achieved = k['bytes'] / (avg_ms * 1e-3) / 1e9
+        roofline = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, kernel=name,
+                        avg_launch_ms=round(avg_ms, 4), launches=k['launches'],
+                        algorithmic_bytes_per_launch=k['bytes'],
+                        all_kernels={kk: round(v['ms'] / v['launches'], 4) for kk, v in kern.items()})
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        flops = 2 * flops_c2c(shape)
+        fl_f, bytes_f = fft.cost()
+        whole = dict(gbs=round(2 * bytes_f * size / (elapsed / args.steps) / 1e9, 1))
+        whole['frac_of_peak_per_gpu'] = round(whole['gbs'] / size / HBM_PEAK_GBS, 4)
+        out = {
+            'metric': 'pfft_3d_c2c_%dcubed_fp64_gflops' % n,
+            'value': round(flops / (elapsed / args.steps) / 1e9, 1),
+            'unit': 'GFLOP/s',
+            'n_gpus': size, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'PFFT 3D c2c %d^3 complex128 forward+backward per step' % n,
+                       'grid': [c.Get_size() for c in fft.subcomm],
+                       'round_trip_rel_err': rt_err},
+            'whole_transform_hbm': whole,
+            'roofline': roofline,
+        }
+        if not args.no_cpu:
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+            try:
+                out['cpu_baseline'] = cpu_baseline(cores)
+            except Exception as e:  # the baseline must never sink the GPU number
+                out['cpu_baseline'] = {'value': None, 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
+                                       'sample': 'failed: %r' % (e,)}
+        print(json.dumps(out), flush=True)
+    world.barrier()
+    if size > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

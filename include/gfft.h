@@ -53,7 +53,7 @@ int gfft_version(void);
 int gfft_device_count(int *count);          /* hipGetDeviceCount; GFFT_ERR_NO_DEVICE if none */
 int gfft_device_name(int device, char *buf, size_t len);
 /* tunables consulted when a plan is created: "grid_cap", "variant_rows", "variant_cols",
- * "force_generic" (also readable from the environment as GFFT_<UPPERCASE NAME>) */
+ * "force_generic", "fused3", "profile" (also readable from the environment as GFFT_<UPPERCASE NAME>) */
 int gfft_set_option(const char *key, int value);
 
 /* ---- serial multi-axis transform plan ------------------------------------------------
@@ -108,6 +108,10 @@ int gfft_event_create(void **event);
 int gfft_event_record(void *event, void *stream);
 int gfft_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on `stop` */
 int gfft_event_destroy(void *event);
+/* per-pass kernel timing for the roofline report: set option "profile" to 1, execute, then read
+ * the accumulated milliseconds of each pass (HIP events recorded on the execute stream) */
+int gfft_plan_profile(gfft_plan plan, float *ms, int max_passes, int *executes);
+int gfft_plan_pass_info(gfft_plan plan, int pass, char *buf, size_t len, double *algorithmic_bytes);
 /* streaming-copy probe: dst[i] = src[i] over `bytes` (multiple of 16); the HBM ceiling quoted
  * beside roofline numbers */
 int gfft_probe_copy(const void *d_src, void *d_dst, size_t bytes, void *stream);

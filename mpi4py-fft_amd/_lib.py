@@ -55,6 +55,8 @@ def _declare(lib):
         'gfft_event_record': (c.c_int, [vp, vp]),
         'gfft_event_elapsed_ms': (c.c_int, [vp, vp, c.POINTER(c.c_float)]),
         'gfft_event_destroy': (c.c_int, [vp]),
+        'gfft_plan_profile': (c.c_int, [vp, c.POINTER(c.c_float), c.c_int, ip]),
+        'gfft_plan_pass_info': (c.c_int, [vp, c.c_int, c.c_char_p, c.c_size_t, c.POINTER(c.c_double)]),
         'gfft_probe_copy': (c.c_int, [vp, vp, c.c_size_t, vp]),
         'gfft_probe_tile_copy': (c.c_int, [vp, vp, c.c_int64, c.c_int64, c.c_int64, c.c_int, vp]),
     }
@@ -137,6 +139,20 @@ class HipEngine:
         f, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
         check(lib().gfft_plan_cost(h, ctypes.byref(f), ctypes.byref(b), ctypes.byref(n)))
         return f.value, b.value, n.value
+
+    def plan_profile(self, h, npasses):
+        """[(kernel family, algorithmic bytes per launch, total ms, launches)] per pass since the
+        last call; needs set_option('profile', 1) during the executes."""
+        ms = (ctypes.c_float * npasses)()
+        n = ctypes.c_int()
+        check(lib().gfft_plan_profile(h, ms, npasses, ctypes.byref(n)))
+        out = []
+        for i in range(npasses):
+            buf = ctypes.create_string_buffer(64)
+            b = ctypes.c_double()
+            check(lib().gfft_plan_pass_info(h, i, buf, 64, ctypes.byref(b)))
+            out.append((buf.value.decode(), b.value, float(ms[i]), n.value))
+        return out
 
     def pack(self, tarray, tpacked, shape, axis, nparts, itemsize):
         self.require_device(tarray)

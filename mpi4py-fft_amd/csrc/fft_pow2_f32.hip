@@ -6,7 +6,7 @@
 namespace gfft {
 
 #define P32(N, R, T, COLS, SPLIT, MINW, ...) \
-  launch_pow2_inst<float, N, R, T, COLS, SPLIT, MINW, __VA_ARGS__>(d, in, out, s)
+  launch_pow2_inst<float, N, R, T, COLS, SPLIT, MINW, 0, __VA_ARGS__>(d, in, out, s)
 
 bool pow2_supported_f32(int n) { return n >= 16 && n <= 4096 && (n & (n - 1)) == 0; }
 

@@ -10,7 +10,9 @@ namespace gfft {
 
 //                 real    N  R  T  COLS  SPLIT MINW radices
 #define P64(N, R, T, COLS, MINW, ...) \
-  launch_pow2_inst<double, N, R, T, COLS, true, MINW, __VA_ARGS__>(d, in, out, s)
+  launch_pow2_inst<double, N, R, T, COLS, true, MINW, 0, __VA_ARGS__>(d, in, out, s)
+#define P64F(N, R, T, COLS, MINW, FLAGS, ...) \
+  launch_pow2_inst<double, N, R, T, COLS, true, MINW, FLAGS, __VA_ARGS__>(d, in, out, s)
 
 bool pow2_supported_f64(int n) { return n >= 16 && n <= 4096 && (n & (n - 1)) == 0; }
 
@@ -26,10 +28,15 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
       case 512: return P64(512, 8, 1, false, 1, 8, 8, 8);
       case 1024:
         switch (variant) {
-          default: return P64(1024, 8, 1, false, 1, 8, 8, 8, 2);
-          case 1: return P64(1024, 8, 2, false, 1, 8, 8, 8, 2);
+          default: return P64(1024, 8, 2, false, 1, 8, 8, 8, 2);
+          case 1: return P64(1024, 8, 1, false, 1, 8, 8, 8, 2);
           case 2: return P64(1024, 16, 1, false, 1, 16, 16, 4);
           case 3: return P64(1024, 16, 4, false, 1, 16, 16, 4);
+          case 4: return P64F(1024, 8, 2, false, 1, 3, 8, 8, 8, 2);      // nt loads+stores
+          case 5: return P64F(1024, 8, 2, false, 1, 4, 8, 8, 8, 2);      // access pattern only
+          case 6: return P64F(1024, 8, 2, false, 1, 7, 8, 8, 8, 2);      // access pattern, nt
+          case 7: return P64F(1024, 8, 2, false, 1, 1, 8, 8, 8, 2);      // nt loads
+          case 8: return P64F(1024, 8, 2, false, 1, 2, 8, 8, 8, 2);      // nt stores
         }
       case 2048: return P64(2048, 8, 1, false, 1, 8, 8, 8, 4);
       case 4096: return P64(4096, 8, 1, false, 1, 8, 8, 8, 8);
@@ -48,10 +55,17 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
         }
       case 1024:
         switch (variant) {
-          default: return P64(1024, 8, 4, true, 1, 8, 8, 8, 2);
-          case 1: return P64(1024, 8, 8, true, 1, 8, 8, 8, 2);
+          default: return P64(1024, 8, 8, true, 1, 8, 8, 8, 2);   // 128-byte segments, 1024 threads
+          case 1: return P64(1024, 8, 4, true, 1, 8, 8, 8, 2);    // 64-byte segments (slower)
           case 2: return P64(1024, 16, 8, true, 1, 16, 16, 4);
           case 3: return P64(1024, 16, 4, true, 1, 16, 16, 4);
+          case 4: return P64F(1024, 8, 8, true, 1, 3, 8, 8, 8, 2);
+          case 5: return P64F(1024, 8, 8, true, 1, 4, 8, 8, 8, 2);
+          case 6: return P64F(1024, 8, 8, true, 1, 7, 8, 8, 8, 2);
+          case 7: return P64F(1024, 8, 8, true, 1, 1, 8, 8, 8, 2);
+          case 8: return P64F(1024, 8, 8, true, 1, 2, 8, 8, 8, 2);
+          case 9: return P64(1024, 16, 16, true, 4, 16, 16, 4);           // T=16 in 128 VGPRs (spills)
+          case 10: return P64F(1024, 16, 16, true, 4, 4, 16, 16, 4);      // its access pattern only
         }
       case 2048: return P64(2048, 8, 4, true, 1, 8, 8, 8, 4);
       case 4096: return P64(4096, 8, 2, true, 1, 8, 8, 8, 8);

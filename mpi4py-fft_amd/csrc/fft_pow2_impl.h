@@ -230,7 +230,30 @@ struct Stage<real, N, R, SPLIT, Ns, r, REST...> {
 // Tile-specialised load/store.  MODE is compile time (no per-element branches), BIGTW too.
 // Conjugation (inverse transforms) is a sign on the imaginary part: on load one multiply, on
 // store it is folded into the scale (scale_y = +-scale), so backward costs what forward does.
-template <typename real, int MODE>
+template <typename real> struct Vec2;
+template <> struct Vec2<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct Vec2<float> { typedef float type __attribute__((ext_vector_type(2))); };
+
+template <typename real, bool NT>
+__device__ __forceinline__ cx<real> ldc(const cx<real> *p) {
+  if constexpr (NT) {
+    typename Vec2<real>::type t = __builtin_nontemporal_load(reinterpret_cast<const typename Vec2<real>::type *>(p));
+    return {t.x, t.y};
+  } else {
+    return *p;
+  }
+}
+template <typename real, bool NT>
+__device__ __forceinline__ void stc(cx<real> *p, cx<real> v) {
+  if constexpr (NT) {
+    typename Vec2<real>::type t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<typename Vec2<real>::type *>(p));
+  } else {
+    *p = v;
+  }
+}
+
+template <typename real, int MODE, bool NT>
 __device__ __forceinline__ cx<real> tile_load(const PassDesc &d, const void *__restrict__ in,
                                               int64_t base, int e, real sy) {
   cx<real> v;
@@ -241,16 +264,16 @@ __device__ __forceinline__ cx<real> tile_load(const PassDesc &d, const void *__r
     const int h = d.n >> 1;
     const bool mirror = e > h;
     const int ee = mirror ? d.n - e : e;
-    v = reinterpret_cast<const cx<real> *>(in)[base + (int64_t)ee * d.in_es];
+    v = ldc<real, NT>(reinterpret_cast<const cx<real> *>(in) + base + (int64_t)ee * d.in_es);
     v.y *= mirror ? -sy : sy;
   } else {
-    v = reinterpret_cast<const cx<real> *>(in)[base + (int64_t)e * d.in_es];
+    v = ldc<real, NT>(reinterpret_cast<const cx<real> *>(in) + base + (int64_t)e * d.in_es);
     v.y *= sy;
   }
   return v;
 }
 
-template <typename real, int MODE, bool BIGTW>
+template <typename real, int MODE, bool BIGTW, bool NT>
 __device__ __forceinline__ void tile_store(const PassDesc &d, void *__restrict__ out, int64_t base,
                                            int e, unsigned mid, cx<real> v, real sx, real sy) {
   if constexpr (BIGTW) {
@@ -264,13 +287,14 @@ __device__ __forceinline__ void tile_store(const PassDesc &d, void *__restrict__
   if constexpr (MODE == MODE_C2R) {
     reinterpret_cast<real *>(out)[base + (int64_t)e * d.out_es] = v.x;
   } else if constexpr (MODE == MODE_R2C) {
-    if (e <= (d.n >> 1)) reinterpret_cast<cx<real> *>(out)[base + (int64_t)e * d.out_es] = v;
+    if (e <= (d.n >> 1)) stc<real, NT>(reinterpret_cast<cx<real> *>(out) + base + (int64_t)e * d.out_es, v);
   } else {
-    reinterpret_cast<cx<real> *>(out)[base + (int64_t)e * d.out_es] = v;
+    stc<real, NT>(reinterpret_cast<cx<real> *>(out) + base + (int64_t)e * d.out_es, v);
   }
 }
 
-template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int MODE, bool BIGTW, int... RADS>
+// FLAGS: 1 = non-temporal loads, 2 = non-temporal stores, 4 = skip the transform (access-pattern probe)
+template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int MODE, bool BIGTW, int... RADS>
 __global__ void __launch_bounds__(T *(N / R), MINW)
 fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
   static_assert(SPLIT || sizeof(real) == 4, "fp64 exchanges split planes");
@@ -301,29 +325,29 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     cx<real> v[R];
     if (valid) {
 #pragma unroll
-      for (int q = 0; q < R; ++q) v[q] = tile_load<real, MODE>(d, in, in0, t + q * NT, sy_in);
+      for (int q = 0; q < R; ++q) v[q] = tile_load<real, MODE, (FLAGS & 1) != 0>(d, in, in0, t + q * NT, sy_in);
     } else {
 #pragma unroll
       for (int q = 0; q < R; ++q) v[q] = {0, 0};
     }
-    Stage<real, N, R, SPLIT, 1, RADS...>::run(v, t, col, tw);
+    if constexpr (!(FLAGS & 4)) Stage<real, N, R, SPLIT, 1, RADS...>::run(v, t, col, tw);
     if (valid) {
 #pragma unroll
-      for (int q = 0; q < R; ++q) tile_store<real, MODE, BIGTW>(d, out, out0, t + q * NT, m, v[q], sx_out, sy_out);
+      for (int q = 0; q < R; ++q) tile_store<real, MODE, BIGTW, (FLAGS & 2) != 0>(d, out, out0, t + q * NT, m, v[q], sx_out, sy_out);
     }
   }
 }
 
 // ---- launch helpers ------------------------------------------------------------------------
 
-template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int MODE, bool BIGTW, int... RADS>
+template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int MODE, bool BIGTW, int... RADS>
 hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStream_t s) {
   constexpr int NT = N / R;
   constexpr int threads = T * NT;
   static_assert(threads >= 64 && threads <= 1024, "workgroup size");
   constexpr size_t lds = (sizeof...(RADS) > 1) ? (size_t)T * Lds<N, COLS>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  auto kern = fft_pow2_kernel<real, N, R, T, COLS, SPLIT, MINW, MODE, BIGTW, RADS...>;
+  auto kern = fft_pow2_kernel<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE, BIGTW, RADS...>;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -339,16 +363,20 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
 }
 
 // runtime (mode, four-step twiddle) -> instantiation
-template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int... RADS>
+template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int... RADS>
 hipError_t launch_pow2_inst(const PassDesc &d, const void *in, void *out, hipStream_t s) {
   if (d.tw_hi) {
+    if (d.mode != MODE_C2C || FLAGS != 0) return hipErrorInvalidValue;
+    return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, true, RADS...>(d, in, out, s);
+  }
+  if constexpr (FLAGS != 0) {
     if (d.mode != MODE_C2C) return hipErrorInvalidValue;
-    return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, MODE_C2C, true, RADS...>(d, in, out, s);
+    return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, false, RADS...>(d, in, out, s);
   }
   switch (d.mode) {
-    case MODE_C2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, MODE_C2C, false, RADS...>(d, in, out, s);
-    case MODE_R2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, MODE_R2C, false, RADS...>(d, in, out, s);
-    case MODE_C2R: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, MODE_C2R, false, RADS...>(d, in, out, s);
+    case MODE_C2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, false, RADS...>(d, in, out, s);
+    case MODE_R2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_R2C, false, RADS...>(d, in, out, s);
+    case MODE_C2R: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2R, false, RADS...>(d, in, out, s);
   }
   return hipErrorInvalidValue;
 }

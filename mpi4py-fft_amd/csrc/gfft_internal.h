@@ -66,6 +66,7 @@ hipError_t launch_trunc(const void *src, void *dst, int64_t outer, int64_t npad,
                         int64_t ntrunc, int64_t inner, int is_real, int precision, double scale,
                         bool pad_direction, hipStream_t s);
 hipError_t launch_scale(void *data, int64_t count, int precision, double scale, hipStream_t s);
+extern int g_copy_nt;
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s);
 hipError_t launch_tile_copy(const void *src, void *dst, int64_t outer, int64_t n, int64_t inner,
                             int tcols, hipStream_t s);

@@ -170,15 +170,41 @@ hipError_t launch_scale(void *data, int64_t count, int precision, double scale, 
 }
 
 // ---- probes ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(MV_THREADS) copy_kernel(const u128 *__restrict__ src, u128 *__restrict__ dst, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * MV_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * MV_THREADS)
-    dst[i] = src[i];
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__global__ void __launch_bounds__(MV_THREADS) copy_kernel(const u4 *__restrict__ src, u4 *__restrict__ dst, int64_t n) {
+  // 4 x 16 B per thread in flight, each a fully coalesced 4 KiB per workgroup
+  const int64_t chunk = 4 * MV_THREADS;
+  for (int64_t base = (int64_t)blockIdx.x * chunk; base < n; base += (int64_t)gridDim.x * chunk) {
+    u4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = base + k * MV_THREADS + threadIdx.x;
+      if (i < n) v[k] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = base + k * MV_THREADS + threadIdx.x;
+      if (i < n) {
+        if (NT) __builtin_nontemporal_store(v[k], dst + i);
+        else dst[i] = v[k];
+      }
+    }
+  }
 }
+
+int g_copy_nt = 0;
 
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s) {
   const int64_t n = (int64_t)(bytes / 16);
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(copy_kernel, dim3(MV_MAX_BLOCKS), dim3(MV_THREADS), 0, s, (const u128 *)src, (u128 *)dst, n);
+  int64_t blocks = (n + 4 * MV_THREADS - 1) / (4 * MV_THREADS);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (g_copy_nt)
+    hipLaunchKernelGGL(copy_kernel<true>, dim3((int)blocks), dim3(MV_THREADS), 0, s, (const u4 *)src, (u4 *)dst, n);
+  else
+    hipLaunchKernelGGL(copy_kernel<false>, dim3((int)blocks), dim3(MV_THREADS), 0, s, (const u4 *)src, (u4 *)dst, n);
   return hipGetLastError();
 }
 

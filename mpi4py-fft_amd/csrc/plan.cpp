@@ -60,11 +60,15 @@ struct Options {
   int variant_rows = 0;
   int variant_cols = 0;
   int force_generic = 0;
+  int profile = 0;           // record HIP events around every pass (bench.py roofline leg)
+  int fused3 = 1;            // reorder + padded-pitch workspace for 3-D all-axes plans
+  int64_t fused3_min_bytes = 32 << 20;
   Options() {
     if (const char *s = getenv("GFFT_GRID_CAP")) grid_cap = atoi(s);
     if (const char *s = getenv("GFFT_VARIANT_ROWS")) variant_rows = atoi(s);
     if (const char *s = getenv("GFFT_VARIANT_COLS")) variant_cols = atoi(s);
     if (const char *s = getenv("GFFT_FORCE_GENERIC")) force_generic = atoi(s);
+    if (const char *s = getenv("GFFT_FUSED3")) fused3 = atoi(s);
   }
 };
 Options &opts() {
@@ -147,7 +151,7 @@ int get_bigtw(int64_t big_n, int precision, BigTw *out) {
 }
 
 // ---- plan -------------------------------------------------------------------------------
-enum Buf { BUF_IN = 0, BUF_OUT = 1 };
+enum Buf { BUF_IN = 0, BUF_OUT = 1, BUF_WS = 2 };
 
 struct Pass {
   PassDesc d{};
@@ -194,6 +198,8 @@ struct gfft_plan_s {
   size_t workspace_bytes = 0, need_workspace_bytes = 0;
   double flops = 0, bytes = 0;
   int variant_rows = 0, variant_cols = 0;
+  bool fused3 = false;
+  std::vector<std::vector<hipEvent_t>> prof;   // per execute: events before pass 0 and after each pass
 };
 
 namespace {
@@ -334,6 +340,108 @@ int plan_axis(gfft_plan_s *pl, int axis, int mode, bool inverse, const std::vect
   return GFFT_OK;
 }
 
+
+// ---- 3-D all-axes plans on one GPU: pass order + padded-pitch workspace --------------------
+// Strided passes over power-of-two pitches alias onto few HBM channels (measured on MI355X,
+// 1024^3 c128: the axis-0 pass takes 11.0 ms on natural strides, 7.4 ms when rows are pitched
+// 256 B wider).  User-visible arrays must stay C-contiguous, so the plan routes the data through
+// one internal workspace W whose rows carry that extra pitch, and orders the passes so that each
+// user array is touched by the pass that tolerates its layout best:
+//   forward / r2c :  axis2 (rows)  IN -> W | axis0 (far cols) W -> W in place | axis1 (near cols) W -> OUT
+//   backward / c2r:  axis1 (near)  IN -> W | axis0 (far cols) W -> W in place | axis2 (rows)      W -> OUT
+// Each pass still reads and writes every element exactly once (algorithmic traffic only).
+bool fused3_applicable(const gfft_plan_s *pl) {
+  if (!opts().fused3 || pl->ndims != 3 || pl->axes.size() != 3) return false;
+  const bool real = pl->kind == GFFT_R2C || pl->kind == GFFT_C2R;
+  if (real && pl->axes.back() != 2) return false;
+  const std::vector<int64_t> &full = (pl->kind == GFFT_C2R) ? pl->sizes_out : pl->sizes_in;
+  for (int i = 0; i < 3; ++i)
+    if (!pow2_ok(full[i], pl->precision)) return false;
+  const int64_t bytes = full[0] * full[1] * full[2] * (real ? 1 : 2) * pl->precision;
+  return bytes >= opts().fused3_min_bytes;
+}
+
+int plan_fused3(gfft_plan_s *pl) {
+  const int prec = pl->precision;
+  const bool real = pl->kind == GFFT_R2C || pl->kind == GFFT_C2R;
+  const bool inverse = pl->kind == GFFT_C2C_BACKWARD || pl->kind == GFFT_C2R;
+  const std::vector<int64_t> &full = (pl->kind == GFFT_C2R) ? pl->sizes_out : pl->sizes_in;
+  const int64_t n0 = full[0], n1 = full[1], n2 = full[2];
+  const int64_t nc = real ? n2 / 2 + 1 : n2;           // complex entries per row
+  const int64_t esz = 2 * prec;
+  const int64_t P = nc + (((nc * esz) % 2048 == 0) ? 256 / esz : 0);   // workspace row pitch
+  pl->need_workspace_bytes = (size_t)(n0 * n1 * P * esz);
+
+  auto base = [&](int n, int mode) {
+    Pass p;
+    p.pow2 = true;
+    p.d.n = n;
+    p.d.mode = mode;
+    p.d.conj_in = inverse ? 1 : 0;
+    p.d.conj_out = (inverse && mode != MODE_C2R) ? 1 : 0;
+    p.d.scale = 1.0;
+    p.d.mid = 1;
+    p.d.inner = 1;
+    p.d.in_ms = p.d.out_ms = 0;
+    p.d.in_is = p.d.out_is = 1;
+    return p;
+  };
+  // rows: transform along axis 2; pitches in elements of each side's own type
+  auto rows = [&](int mode, int64_t pin, int64_t pout, int src, int dst) {
+    Pass p = base((int)n2, mode);
+    p.cols = false;
+    p.d.batch = n0 * n1;
+    p.d.in_os = pin;  p.d.in_es = 1;
+    p.d.out_os = pout; p.d.out_es = 1;
+    p.src = src; p.dst = dst;
+    return p;
+  };
+  auto axis1 = [&](int64_t pin, int64_t pout, int src, int dst) {
+    Pass p = base((int)n1, MODE_C2C);
+    p.cols = true;
+    p.d.batch = n0 * nc;
+    p.d.inner = nc;
+    p.d.in_os = n1 * pin;  p.d.in_es = pin;
+    p.d.out_os = n1 * pout; p.d.out_es = pout;
+    p.src = src; p.dst = dst;
+    return p;
+  };
+  auto axis0 = [&](int64_t pin, int64_t pout, int src, int dst) {
+    Pass p = base((int)n0, MODE_C2C);
+    p.cols = true;
+    p.d.batch = n1 * nc;
+    p.d.mid = n1;
+    p.d.inner = nc;
+    p.d.in_os = 0;  p.d.in_ms = pin;  p.d.in_es = n1 * pin;
+    p.d.out_os = 0; p.d.out_ms = pout; p.d.out_es = n1 * pout;
+    p.src = src; p.dst = dst;
+    return p;
+  };
+  std::vector<Pass> seq;
+  if (!inverse) {
+    seq.push_back(rows(real ? MODE_R2C : MODE_C2C, n2, P, BUF_IN, BUF_WS));
+    seq.push_back(axis0(P, P, BUF_WS, BUF_WS));
+    seq.push_back(axis1(P, nc, BUF_WS, BUF_OUT));
+  } else {
+    seq.push_back(axis1(nc, P, BUF_IN, BUF_WS));
+    seq.push_back(axis0(P, P, BUF_WS, BUF_WS));
+    seq.push_back(rows(real ? MODE_C2R : MODE_C2C, P, n2, BUF_WS, BUF_OUT));
+  }
+  for (Pass &p : seq) {
+    int rc = get_twiddles(p.d.n, prec, &p.d.tw);
+    if (rc) return rc;
+    const double lines = (double)p.d.batch;
+    const double n = p.d.n;
+    pl->flops += (p.d.mode == MODE_C2C ? 1.0 : 0.5) * 5.0 * n * std::log2(n) * lines;
+    const double ein = p.d.mode == MODE_R2C ? prec : esz, eout = p.d.mode == MODE_C2R ? prec : esz;
+    const double nin = p.d.mode == MODE_C2R ? (double)nc : n, nout = p.d.mode == MODE_R2C ? (double)nc : n;
+    pl->bytes += lines * (nin * ein + nout * eout);
+    pl->passes.push_back(p);
+  }
+  pl->fused3 = true;
+  return GFFT_OK;
+}
+
 hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d, const void *in, void *out, hipStream_t s) {
   if (p.pow2) {
     const int variant = p.cols ? pl->variant_cols : pl->variant_rows;
@@ -392,6 +500,10 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "variant_rows")) opts().variant_rows = value;
   else if (!strcmp(key, "variant_cols")) opts().variant_cols = value;
   else if (!strcmp(key, "force_generic")) opts().force_generic = value;
+  else if (!strcmp(key, "copy_nt")) gfft::g_copy_nt = value;
+  else if (!strcmp(key, "fused3")) opts().fused3 = value;
+  else if (!strcmp(key, "profile")) opts().profile = value;
+  else if (!strcmp(key, "fused3_min_mib")) opts().fused3_min_bytes = (int64_t)value << 20;
   else return fail(GFFT_ERR_INVALID, std::string("unknown option ") + key);
   return GFFT_OK;
 }
@@ -436,7 +548,9 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
   pl->variant_cols = opts().variant_cols;
 
   rc = GFFT_OK;
-  if (kind == GFFT_C2C_FORWARD || kind == GFFT_C2C_BACKWARD) {
+  if (fused3_applicable(pl)) {
+    rc = plan_fused3(pl);
+  } else if (kind == GFFT_C2C_FORWARD || kind == GFFT_C2C_BACKWARD) {
     const bool inv = kind == GFFT_C2C_BACKWARD;
     for (int i = naxes - 1; i >= 0 && !rc; --i)
       rc = plan_axis(pl, ax[i], MODE_C2C, inv, pl->sizes_in, pl->sizes_in, i == naxes - 1 ? BUF_IN : BUF_OUT, BUF_OUT);
@@ -464,7 +578,37 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
   if ((pl->kind == GFFT_R2C || pl->kind == GFFT_C2R) && d_in == d_out)
     return fail(GFFT_ERR_INVALID, "in-place real transforms are not supported");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  void *bufs[2] = {const_cast<void *>(d_in), d_out};
+  void *bufs[3] = {const_cast<void *>(d_in), d_out, nullptr};
+  if (pl->fused3) {
+    if (pl->workspace_bytes < pl->need_workspace_bytes) {
+      if (pl->workspace) HIP_TRY(hipFree(pl->workspace));
+      pl->workspace = nullptr;
+      pl->workspace_bytes = 0;
+      hipError_t e = hipMalloc(&pl->workspace, pl->need_workspace_bytes);
+      if (e == hipErrorOutOfMemory) return fail(GFFT_ERR_NOMEM, "workspace allocation failed");
+      HIP_TRY(e);
+      pl->workspace_bytes = pl->need_workspace_bytes;
+    }
+    bufs[2] = pl->workspace;
+  }
+  std::vector<hipEvent_t> *ev = nullptr;
+  if (opts().profile) {
+    pl->prof.emplace_back();
+    ev = &pl->prof.back();
+    hipEvent_t e0;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventRecord(e0, s));
+    ev->push_back(e0);
+  }
+  auto mark = [&]() -> hipError_t {
+    if (!ev) return hipSuccess;
+    hipEvent_t e;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) return rc;
+    rc = hipEventRecord(e, s);
+    ev->push_back(e);
+    return rc;
+  };
   for (size_t i = 0; i < pl->passes.size(); ++i) {
     const Pass &p = pl->passes[i];
     PassDesc d = p.d;
@@ -487,11 +631,52 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
         mid = pl->workspace;
       }
       HIP_TRY(run_pass(pl, p, d, src, mid, s));
+      HIP_TRY(mark());
       HIP_TRY(run_pass(pl, p2, d2, mid, dst, s));
+      HIP_TRY(mark());
       ++i;
       continue;
     }
     HIP_TRY(run_pass(pl, p, d, src, dst, s));
+    HIP_TRY(mark());
+  }
+  return GFFT_OK;
+}
+
+/* Accumulated per-pass kernel time since the last call (needs option "profile" = 1 while
+ * executing): ms[i] = total milliseconds of pass i, *executes = number of executes summed.
+ * Synchronises on the recorded events and frees them. */
+int gfft_plan_profile(gfft_plan pl, float *ms, int max_passes, int *executes) {
+  if (!pl || !ms) return fail(GFFT_ERR_INVALID, "null argument");
+  for (int i = 0; i < max_passes; ++i) ms[i] = 0.f;
+  int n = 0;
+  for (auto &ev : pl->prof) {
+    if (ev.empty()) continue;
+    HIP_TRY(hipEventSynchronize(ev.back()));
+    for (size_t i = 0; i + 1 < ev.size(); ++i) {
+      float t = 0.f;
+      HIP_TRY(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      if ((int)i < max_passes) ms[i] += t;
+    }
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    ++n;
+  }
+  pl->prof.clear();
+  if (executes) *executes = n;
+  return GFFT_OK;
+}
+
+/* text name of the kernel family behind pass i ("pow2-rows", "pow2-cols", "generic") */
+int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *bytes) {
+  if (!pl || i < 0 || i >= (int)pl->passes.size()) return fail(GFFT_ERR_INVALID, "bad pass index");
+  const Pass &p = pl->passes[i];
+  snprintf(buf, len, "%s n=%d", p.pow2 ? (p.cols ? "pow2-cols" : "pow2-rows") : "generic", p.d.n);
+  if (bytes) {
+    const double esz = 2.0 * pl->precision;
+    const double nc = p.d.mode == MODE_C2C ? p.d.n : p.d.n / 2 + 1;
+    const double ein = p.d.mode == MODE_R2C ? p.d.n * (double)pl->precision : nc * esz;
+    const double eout = p.d.mode == MODE_C2R ? p.d.n * (double)pl->precision : nc * esz;
+    *bytes = (double)p.d.batch * (ein + eout);
   }
   return GFFT_OK;
 }
@@ -509,8 +694,8 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
   char line[256];
   const char *kn = pl->kind == GFFT_C2C_FORWARD ? "c2c-forward" : pl->kind == GFFT_C2C_BACKWARD ? "c2c-backward"
                    : pl->kind == GFFT_R2C ? "r2c" : "c2r";
-  snprintf(line, sizeof line, "gfft plan: %s %s, %d dims, %zu passes\n", kn, pl->precision == 8 ? "f64" : "f32",
-           pl->ndims, pl->passes.size());
+  snprintf(line, sizeof line, "gfft plan: %s %s, %d dims, %zu passes%s\n", kn, pl->precision == 8 ? "f64" : "f32",
+           pl->ndims, pl->passes.size(), pl->fused3 ? " [3-D schedule: padded-pitch workspace]" : "");
   s += line;
   for (const Pass &p : pl->passes) {
     snprintf(line, sizeof line, "  n=%d batch=%lld (mid=%lld inner=%lld) es_in=%lld es_out=%lld kernel=%s%s%s\n", p.d.n,
@@ -621,6 +806,31 @@ int gfft_event_elapsed_ms(void *start, void *stop, float *ms) {
   return GFFT_OK;
 }
 int gfft_event_destroy(void *event) { HIP_TRY(hipEventDestroy((hipEvent_t)event)); return GFFT_OK; }
+
+/* developer probe: run ONE power-of-two pass with explicit batch geometry and strides
+ * (element units), bypassing the planner.  geom = {n, outer, mid, inner, in_os, in_ms, in_is,
+ * in_es, out_os, out_ms, out_is, out_es}.  Not part of the drop-in boundary. */
+int gfft_debug_pass(const int64_t *geom, int precision, int cols, int variant, int inverse,
+                    const void *d_in, void *d_out, void *stream) {
+  int rc = check_device();
+  if (rc) return rc;
+  PassDesc d{};
+  d.n = (int)geom[0];
+  d.mode = MODE_C2C;
+  d.conj_in = d.conj_out = inverse;
+  d.mid = geom[2];
+  d.inner = geom[3];
+  d.batch = geom[1] * geom[2] * geom[3];
+  d.in_os = geom[4]; d.in_ms = geom[5]; d.in_is = geom[6]; d.in_es = geom[7];
+  d.out_os = geom[8]; d.out_ms = geom[9]; d.out_is = geom[10]; d.out_es = geom[11];
+  d.scale = 1.0;
+  rc = get_twiddles(d.n, precision, &d.tw);
+  if (rc) return rc;
+  hipError_t e = precision == 8 ? launch_pow2_f64(d, cols != 0, variant, d_in, d_out, (hipStream_t)stream)
+                                : launch_pow2_f32(d, cols != 0, variant, d_in, d_out, (hipStream_t)stream);
+  HIP_TRY(e);
+  return GFFT_OK;
+}
 
 int gfft_probe_copy(const void *d_src, void *d_dst, size_t bytes, void *stream) {
   int rc = check_device();

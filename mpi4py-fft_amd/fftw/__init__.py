@@ -94,6 +94,10 @@ class FFT:
         """(flops, algorithmic bytes, kernel launches) of one execution."""
         return self._eng.plan_cost(self._plan)
 
+    def profile(self):
+        """Per-pass (family, algorithmic bytes/launch, total ms, launches) since the last call."""
+        return self._eng.plan_profile(self._plan, self.cost()[2])
+
     def update_arrays(self, input_array, output_array):
         assert self.input_shape == tuple(input_array.shape)
         assert self.input_strides == input_array.strides

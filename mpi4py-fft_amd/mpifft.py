@@ -22,11 +22,13 @@ from . import comm as _comm
 class Transform:
     """A parallel transform, forward or backward: serial transforms interleaved with global
     redistributions (mpifft.py:8-79)."""
-    def __init__(self, xfftn, transfer, pencil):
+    def __init__(self, xfftn, transfer, pencil, fused=None):
         assert len(xfftn) == len(transfer) + 1 and len(pencil) == 2
         self._xfftn = tuple(xfftn)
         self._transfer = tuple(transfer)
         self._pencil = tuple(pencil)
+        # single-rank shortcut: one all-axes plan from input_array to output_array (see PFFT)
+        self._fused = fused
 
     @property
     def input_array(self):
@@ -50,6 +52,12 @@ class Transform:
         ``normalize=True/False`` overrides the default (forward normalised, backward not)."""
         if input_array is not None:
             self.input_array[...] = input_array
+        if self._fused is not None:
+            self._fused(**kw)
+            if output_array is not None:
+                output_array[...] = self.output_array
+                return output_array
+            return self.output_array
         for i in range(len(self._transfer)):
             self._xfftn[i](**kw)
             arrayA = self._xfftn[i].output_array
@@ -198,11 +206,13 @@ class PFFT:
             pencilB = pencilA.pencil(axes[-1])
             transAB = pencilA.transfer(pencilB, dtype)
             # single-rank redistribution: chain the stages through one buffer instead of copying
-            share = None
+            share = shareV = None
             if transAB.comm.Get_size() == 1 and tuple(pencilB.subshape) == tuple(pencilA.subshape):
                 share = self.xfftn[-1].forward.output_array
+                if padding is False and np.dtype(dtype).kind == 'c':
+                    shareV = share        # complex stage on one rank: transform in place
             xfftn = FFT(pencilB.subshape, axes, dtype, padding, backend=backend,
-                        transforms=transforms, U=share, **kw)
+                        transforms=transforms, U=share, V=shareV, **kw)
             self.xfftn.append(xfftn)
             self.transfer.append(transAB)
             pencilA = pencilB
@@ -214,14 +224,48 @@ class PFFT:
         self.pencil[1] = pencilA
         self._output_shape = tuple(shape)
 
+        fused_fwd = fused_bck = None
+        self._fused_plans = None
+        local = all(t.comm.Get_size() == 1 for t in self.transfer)
+        if (local and padding is False and transforms is None and len(self.xfftn) > 1
+                and kw.get('fuse', True)):
+            fused_fwd, fused_bck = self._plan_fused()
+
         self.forward = Transform(
             [o.forward for o in self.xfftn],
             [o.forward for o in self.transfer],
-            self.pencil)
+            self.pencil, fused_fwd)
         self.backward = Transform(
             [o.backward for o in self.xfftn[::-1]],
             [o.backward for o in self.transfer[::-1]],
-            self.pencil[::-1])
+            self.pencil[::-1], fused_bck)
+
+    def _plan_fused(self):
+        """All ranks-local case (one GPU): every stage's redistribution is the identity, so the
+        whole transform is ONE serial multi-axis plan from the first stage's input array to the
+        last stage's output array.  libgfft is then free to order the axis passes and route them
+        through its padded workspace (plan.cpp, plan_fused3); results are those of the staged
+        path up to rounding."""
+        from . import fftw
+        U = self.xfftn[0].forward.input_array
+        V = self.xfftn[-1].forward.output_array
+        flat = [a for g in self.axes for a in g]
+        real = np.dtype(U.dtype).kind == 'f'
+        s = tuple(np.take(U.shape, flat))
+        fwd = (fftw.rfftn if real else fftw.fftn)(U, s=s, axes=flat, output_array=V)
+        bck = (fftw.irfftn if real else fftw.ifftn)(V, s=s, axes=flat, output_array=U)
+        self._fused_plans = (fwd, bck)
+        M = fwd.get_normalization()
+
+        def forward(**kw):
+            normalize = kw.pop('normalize', True)
+            fwd.execute_scaled(U, V, M if normalize else 1.0)
+
+        def backward(**kw):
+            normalize = kw.pop('normalize', False)
+            bck.execute_scaled(V, U, M if normalize else 1.0)
+
+        return forward, backward
 
     def destroy(self):
         if isinstance(self.subcomm, Subcomm):
@@ -230,6 +274,9 @@ class PFFT:
             trans.destroy()
         for x in self.xfftn:
             x.destroy()
+        if self._fused_plans:
+            for p in self._fused_plans:
+                p.destroy()
 
     def shape(self, forward_output=True):
         """Local shape of the spectral (True) or physical (False) array (mpifft.py:355-366)."""
@@ -258,6 +305,9 @@ class PFFT:
     def cost(self):
         """(flops, algorithmic bytes) of one forward on this rank, summed over the serial stages
         (the work model of BASELINE.md section 3)."""
+        if self._fused_plans:
+            cf, cb, _ = self._fused_plans[0].cost()
+            return cf, cb
         f = b = 0.0
         for x in self.xfftn:
             cf, cb, _ = x.fwd.cost()
