@@ -347,8 +347,8 @@ int plan_axis(gfft_plan_s *pl, int axis, int mode, bool inverse, const std::vect
 // 256 B wider).  User-visible arrays must stay C-contiguous, so the plan routes the data through
 // one internal workspace W whose rows carry that extra pitch, and orders the passes so that each
 // user array is touched by the pass that tolerates its layout best:
-//   forward / r2c :  axis2 (rows)  IN -> W | axis0 (far cols) W -> W in place | axis1 (near cols) W -> OUT
-//   backward / c2r:  axis1 (near)  IN -> W | axis0 (far cols) W -> W in place | axis2 (rows)      W -> OUT
+//   forward / r2c :  axis2 (rows) IN -> W | axis0 (cols) W -> W in place | axis1 (cols) W -> OUT
+//   backward / c2r:  axis1 (cols) IN -> W | axis0 (cols) W -> W in place | axis2 (rows) W -> OUT
 // Each pass still reads and writes every element exactly once (algorithmic traffic only).
 bool fused3_applicable(const gfft_plan_s *pl) {
   if (!opts().fused3 || pl->ndims != 3 || pl->axes.size() != 3) return false;
@@ -386,46 +386,54 @@ int plan_fused3(gfft_plan_s *pl) {
     p.d.in_is = p.d.out_is = 1;
     return p;
   };
-  // rows: transform along axis 2; pitches in elements of each side's own type
-  auto rows = [&](int mode, int64_t pin, int64_t pout, int src, int dst) {
+  // Workspace layout W[i1][i0][c] (row pitch P): axis 0 is the NEAR strided axis inside W
+  // (stride P), axis 1 the far one (stride n0*P).  The in-place middle pass then runs on near
+  // strides on both its sides, and the pass that touches the user's natural array does so along
+  // axis 1, the near axis of the natural layout (measured: near pad->pad 7.2 ms, far 7.9 ms).
+  const int64_t w_i0 = P, w_i1 = n0 * P;
+  // rows: transform along axis 2; batch (o = i0, i = i1); strides in elements of each side's type
+  auto rows = [&](int mode, bool in_ws, bool out_ws, int src, int dst) {
     Pass p = base((int)n2, mode);
     p.cols = false;
     p.d.batch = n0 * n1;
-    p.d.in_os = pin;  p.d.in_es = 1;
-    p.d.out_os = pout; p.d.out_es = 1;
+    p.d.inner = n1;
+    const int64_t nat_in = (mode == MODE_R2C) ? n2 : nc, nat_out = (mode == MODE_C2R) ? n2 : nc;
+    p.d.in_os = in_ws ? w_i0 : n1 * nat_in;   p.d.in_is = in_ws ? w_i1 : nat_in;   p.d.in_es = 1;
+    p.d.out_os = out_ws ? w_i0 : n1 * nat_out; p.d.out_is = out_ws ? w_i1 : nat_out; p.d.out_es = 1;
     p.src = src; p.dst = dst;
     return p;
   };
-  auto axis1 = [&](int64_t pin, int64_t pout, int src, int dst) {
+  // axis 1: batch (o = i0, i = c)
+  auto axis1 = [&](bool in_ws, bool out_ws, int src, int dst) {
     Pass p = base((int)n1, MODE_C2C);
     p.cols = true;
     p.d.batch = n0 * nc;
     p.d.inner = nc;
-    p.d.in_os = n1 * pin;  p.d.in_es = pin;
-    p.d.out_os = n1 * pout; p.d.out_es = pout;
+    p.d.in_os = in_ws ? w_i0 : n1 * nc;   p.d.in_es = in_ws ? w_i1 : nc;
+    p.d.out_os = out_ws ? w_i0 : n1 * nc; p.d.out_es = out_ws ? w_i1 : nc;
     p.src = src; p.dst = dst;
     return p;
   };
-  auto axis0 = [&](int64_t pin, int64_t pout, int src, int dst) {
+  // axis 0 inside the workspace: batch (o = i1, i = c)
+  auto axis0 = [&](int src, int dst) {
     Pass p = base((int)n0, MODE_C2C);
     p.cols = true;
     p.d.batch = n1 * nc;
-    p.d.mid = n1;
     p.d.inner = nc;
-    p.d.in_os = 0;  p.d.in_ms = pin;  p.d.in_es = n1 * pin;
-    p.d.out_os = 0; p.d.out_ms = pout; p.d.out_es = n1 * pout;
+    p.d.in_os = w_i1;  p.d.in_es = w_i0;
+    p.d.out_os = w_i1; p.d.out_es = w_i0;
     p.src = src; p.dst = dst;
     return p;
   };
   std::vector<Pass> seq;
   if (!inverse) {
-    seq.push_back(rows(real ? MODE_R2C : MODE_C2C, n2, P, BUF_IN, BUF_WS));
-    seq.push_back(axis0(P, P, BUF_WS, BUF_WS));
-    seq.push_back(axis1(P, nc, BUF_WS, BUF_OUT));
+    seq.push_back(rows(real ? MODE_R2C : MODE_C2C, false, true, BUF_IN, BUF_WS));
+    seq.push_back(axis0(BUF_WS, BUF_WS));
+    seq.push_back(axis1(true, false, BUF_WS, BUF_OUT));
   } else {
-    seq.push_back(axis1(nc, P, BUF_IN, BUF_WS));
-    seq.push_back(axis0(P, P, BUF_WS, BUF_WS));
-    seq.push_back(rows(real ? MODE_C2R : MODE_C2C, P, n2, BUF_WS, BUF_OUT));
+    seq.push_back(axis1(false, true, BUF_IN, BUF_WS));
+    seq.push_back(axis0(BUF_WS, BUF_WS));
+    seq.push_back(rows(real ? MODE_C2R : MODE_C2C, true, false, BUF_WS, BUF_OUT));
   }
   for (Pass &p : seq) {
     int rc = get_twiddles(p.d.n, prec, &p.d.tw);
