@@ -129,6 +129,14 @@ def main():
                 k = kern.setdefault(name, dict(bytes=nbytes, ms=0.0, launches=0))
                 k['ms'] += ms
                 k['launches'] += launches
+    # HBM traffic per launch from the committed PMC profile of this same command (rocprofv3 cannot
+    # run inside the timed region); only quoted when kernel and problem size match
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            pmc = json.load(f)
+    except Exception:
+        pass
     roofline = None
     if kern:
         name = max(kern, key=lambda k: kern[k]['ms'])
@@ -136,7 +144,11 @@ def main():
         avg_ms = k['ms'] / k['launches']
         achieved = k['bytes'] / (avg_ms * 1e-3) / 1e9
         roofline = dict(bound='hbm', achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None, kernel=name,
+                        frac=round(achieved / HBM_PEAK_GBS, 4),
+                        traffic=(pmc.get(name, {}).get('hbm_bytes_per_launch')
+                                 if (n == 1024 and size == 1) else None),
+                        traffic_source=(pmc.get(name, {}).get('source') if (n == 1024 and size == 1) else None),
+                        kernel=name,
                         avg_launch_ms=round(avg_ms, 4), launches=k['launches'],
                         algorithmic_bytes_per_launch=k['bytes'],
                         all_kernels={kk: round(v['ms'] / v['launches'], 4) for kk, v in kern.items()})

@@ -1,0 +1,58 @@
+"""Worker for tests/test_gloo_distributed.py: one process per rank over torch.distributed (gloo).
+Exercises the REAL communicator path (comm.TorchComm: Cartesian sub-groups via new_group,
+all_to_all_single with uneven splits) under the product PFFT / Transfer / DistArray classes.
+The arithmetic comes from the CPU checker engine (tests/host_engine.py) because this container has
+no GPU; on GPUs the same code runs with the HIP engine over the nccl (RCCL) backend."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+
+def main():
+    from mpi4py_fft_amd import comm, _lib, PFFT, newDistArray, DistArray, Subcomm
+    from tests.host_engine import HostEngine
+    from oracle import pfft_oracle as O
+    _lib.set_engine(HostEngine())
+    world = comm.init_distributed('gloo')
+    P, r = world.Get_size(), world.Get_rank()
+    cases = [((16, 12, 10), 'D', {}), ((13, 12, 10), 'd', {}), ((7, 8, 9), 'D', {}),
+             ((12, 13), 'D', {}), ((16, 12, 10), 'd', dict(padding=[1.5, 1.5, 1.5])),
+             ((12, 10, 8), 'D', dict(grid=(-1,))), ((12, 9, 8, 6), 'd', dict(axes=((0,), (1,), (2, 3))))]
+    for shape, dt, kw in cases:
+        ref = O.OPFFT(P, shape, dtype=dt, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+        G = O.rng_array(ref.input_shape, dt, 42)
+        want = ref.forward(ref.scatter(G))[r]
+        fft = PFFT(world, shape, dtype=dt, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+        assert [c.Get_size() for c in fft.subcomm] == list(ref.dims), (shape, kw)
+        u = newDistArray(fft, False)
+        assert tuple(u.shape) == ref.pencil_in[r].subshape
+        u[...] = G[fft.local_slice(False)]
+        uh = np.asarray(fft.forward(u))
+        assert uh.shape == want.shape, (uh.shape, want.shape)
+        assert np.abs(uh - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (shape, dt, kw)
+        if not kw.get('padding'):
+            back = np.asarray(fft.backward())
+            assert np.abs(back - G[fft.local_slice(False)]).max() < 1e-12
+        fft.destroy()
+    # DistArray.redistribute over the real communicator (tests/test_darray.py:50-57)
+    N = (8, 10, 12)
+    sub = Subcomm(world, [0, 0, 1])
+    z = DistArray(N, subcomm=sub, dtype=float, alignment=2)
+    z[...] = np.random.default_rng(r).random(z.shape)
+    n0 = sum(world.allgather_obj(float(np.sum(np.asarray(z) ** 2))))
+    z1 = z.redistribute(1)
+    n1 = sum(world.allgather_obj(float(np.sum(np.asarray(z1) ** 2))))
+    assert np.isclose(n0, n1)
+    world.barrier()
+    if r == 0:
+        print('GLOO_WORKER_OK ranks=%d' % P)
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
