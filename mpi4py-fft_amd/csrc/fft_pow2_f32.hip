@@ -25,6 +25,19 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 2048: return P32(2048, 16, 1, false, false, 1, 16, 16, 8);
       case 4096: return P32(4096, 16, 1, false, false, 1, 16, 16, 16);
     }
+  } else if (d.mode != MODE_C2C || d.tw_hi || d.out_es == 1 || d.in_es == 1) {
+    // real modes along a strided axis and the four-step passes: lean R = 8 plans
+    switch (d.n) {
+      case 16: return P32(16, 4, 16, true, false, 1, 4, 4);
+      case 32: return P32(32, 8, 16, true, false, 1, 8, 4);
+      case 64: return P32(64, 8, 16, true, false, 1, 8, 8);
+      case 128: return P32(128, 8, 16, true, false, 1, 8, 8, 2);
+      case 256: return P32(256, 8, 16, true, false, 1, 8, 8, 4);
+      case 512: return P32(512, 8, 16, true, true, 1, 8, 8, 8);
+      case 1024: return P32(1024, 8, 8, true, false, 1, 8, 8, 8, 2);
+      case 2048: return P32(2048, 8, 4, true, false, 1, 8, 8, 8, 4);
+      case 4096: return P32(4096, 8, 2, true, false, 1, 8, 8, 8, 8);
+    }
   } else {
     switch (d.n) {
       case 16: return P32(16, 4, 16, true, false, 1, 4, 4);
@@ -33,9 +46,9 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 128: return P32(128, 8, 16, true, false, 1, 8, 8, 2);
       case 256: return P32(256, 16, 16, true, false, 1, 16, 16);
       case 512: return P32(512, 8, 16, true, true, 1, 8, 8, 8);
-      case 1024: return P32(1024, 16, 8, true, false, 1, 16, 16, 4);
-      case 2048: return P32(2048, 16, 8, true, true, 1, 16, 16, 8);
-      case 4096: return P32(4096, 16, 4, true, true, 1, 16, 16, 16);
+      case 1024: return P32(1024, 16, 16, true, true, 1, 16, 16, 4);
+      case 2048: return P32(2048, 16, 8, true, true, 4, 16, 16, 8);
+      case 4096: return P32(4096, 16, 4, true, true, 4, 16, 16, 16);
     }
   }
   return hipErrorInvalidValue;

@@ -41,34 +41,48 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
       case 2048: return P64(2048, 8, 1, false, 1, 8, 8, 8, 4);
       case 4096: return P64(4096, 8, 1, false, 1, 8, 8, 8, 8);
     }
-  } else {
+  } else if (d.mode != MODE_C2C || d.tw_hi || d.out_es == 1 || d.in_es == 1) {
+    // Strided passes that are not plain c2c column passes -- r2c / c2r along a strided axis
+    // (halved axis is not the array's last axis) and the four-step passes (fused big twiddle,
+    // transposed store) -- take the register-lean R = 8 plans with 128-byte segments.
     switch (d.n) {
       case 16: return P64(16, 4, 16, true, 1, 4, 4);
       case 32: return P64(32, 8, 16, true, 1, 8, 4);
       case 64: return P64(64, 8, 8, true, 1, 8, 8);
       case 128: return P64(128, 8, 8, true, 1, 8, 8, 2);
       case 256: return P64(256, 8, 8, true, 1, 8, 8, 4);
+      case 512: return P64(512, 8, 8, true, 1, 8, 8, 8);
+      case 1024: return P64(1024, 8, 8, true, 1, 8, 8, 8, 2);
+      case 2048: return P64(2048, 8, 4, true, 1, 8, 8, 8, 4);
+      case 4096: return P64(4096, 8, 2, true, 1, 8, 8, 8, 8);
+    }
+  } else {
+    // strided axis: 16 adjacent columns = 256-byte segments wherever the thread budget allows
+    switch (d.n) {
+      case 16: return P64F(16, 4, 16, true, 1, 8, 4, 4);
+      case 32: return P64F(32, 8, 16, true, 1, 8, 8, 4);
+      case 64: return P64F(64, 8, 16, true, 1, 8, 8, 8);
+      case 128: return P64F(128, 8, 16, true, 1, 8, 8, 8, 2);
+      case 256: return P64F(256, 8, 16, true, 1, 8, 8, 8, 4);
       case 512:
         switch (variant) {
-          default: return P64(512, 8, 8, true, 1, 8, 8, 8);
-          case 1: return P64(512, 8, 4, true, 1, 8, 8, 8);
+          default: return P64F(512, 8, 16, true, 1, 8, 8, 8, 8);
+          case 1: return P64F(512, 8, 8, true, 1, 8, 8, 8, 8);
         }
       case 1024:
         switch (variant) {
-          default: return P64(1024, 8, 8, true, 1, 8, 8, 8, 2);   // 128-byte segments, 1024 threads
-          case 1: return P64(1024, 8, 4, true, 1, 8, 8, 8, 2);    // 64-byte segments (slower)
-          case 2: return P64(1024, 16, 8, true, 1, 16, 16, 4);
-          case 3: return P64(1024, 16, 4, true, 1, 16, 16, 4);
-          case 4: return P64F(1024, 8, 8, true, 1, 3, 8, 8, 8, 2);
-          case 5: return P64F(1024, 8, 8, true, 1, 4, 8, 8, 8, 2);
-          case 6: return P64F(1024, 8, 8, true, 1, 7, 8, 8, 8, 2);
-          case 7: return P64F(1024, 8, 8, true, 1, 1, 8, 8, 8, 2);
-          case 8: return P64F(1024, 8, 8, true, 1, 2, 8, 8, 8, 2);
-          case 9: return P64(1024, 16, 16, true, 4, 16, 16, 4);           // T=16 in 128 VGPRs (spills)
-          case 10: return P64F(1024, 16, 16, true, 4, 4, 16, 16, 4);      // its access pattern only
+          default: return P64F(1024, 16, 16, true, 4, 8, 16, 16, 4);  // 256-B segments, 1024 threads, <=128 VGPRs
+          case 1: return P64F(1024, 8, 8, true, 1, 8, 8, 8, 8, 2);    // 128-B segments, 1024 threads, 86 VGPRs
+          case 2: return P64F(1024, 16, 8, true, 1, 8, 16, 16, 4);    // 512 threads, ~134 VGPRs: 1 tile/CU
+          case 3: return P64F(1024, 16, 8, true, 4, 8, 16, 16, 4);    // capped at 128 VGPRs: 2 tiles/CU
+          case 4: return P64F(1024, 8, 4, true, 1, 8, 8, 8, 8, 2);    // 64-B segments
+          case 5: return P64F(1024, 8, 8, true, 1, 4, 8, 8, 8, 2);      // access pattern only, T=8
+          case 6: return P64F(1024, 8, 8, true, 1, 7, 8, 8, 8, 2);      // ... with nt loads/stores
+          case 10: return P64F(1024, 16, 16, true, 4, 4, 16, 16, 4);    // access pattern only, T=16
+          case 12: return P64F(1024, 16, 16, true, 4, 8, 8, 8, 8, 2);
         }
-      case 2048: return P64(2048, 8, 4, true, 1, 8, 8, 8, 4);
-      case 4096: return P64(4096, 8, 2, true, 1, 8, 8, 8, 8);
+      case 2048: return P64F(2048, 16, 8, true, 4, 8, 16, 16, 8);
+      case 4096: return P64F(4096, 16, 4, true, 4, 8, 16, 16, 16);
     }
   }
   return hipErrorInvalidValue;

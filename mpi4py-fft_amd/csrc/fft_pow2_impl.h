@@ -253,12 +253,16 @@ __device__ __forceinline__ void stc(cx<real> *p, cx<real> v) {
   }
 }
 
+// `idx` = element index of (column, e) = base + e*in_es, built incrementally by the caller (one
+// 64-bit add per element from a workgroup-uniform step: nothing per-element is loop invariant,
+// so nothing gets hoisted out of the tile loop into long-lived VGPRs -- that hoisting cost
+// 2 VGPRs per element per side, 64 VGPRs at R = 16).
 template <typename real, int MODE, bool NT>
 __device__ __forceinline__ cx<real> tile_load(const PassDesc &d, const void *__restrict__ in,
-                                              int64_t base, int e, real sy) {
+                                              int64_t base, int64_t idx, int e, real sy) {
   cx<real> v;
   if constexpr (MODE == MODE_R2C) {
-    v.x = reinterpret_cast<const real *>(in)[base + (int64_t)e * d.in_es];
+    v.x = reinterpret_cast<const real *>(in)[idx];
     v.y = 0;
   } else if constexpr (MODE == MODE_C2R) {
     const int h = d.n >> 1;
@@ -267,14 +271,14 @@ __device__ __forceinline__ cx<real> tile_load(const PassDesc &d, const void *__r
     v = ldc<real, NT>(reinterpret_cast<const cx<real> *>(in) + base + (int64_t)ee * d.in_es);
     v.y *= mirror ? -sy : sy;
   } else {
-    v = ldc<real, NT>(reinterpret_cast<const cx<real> *>(in) + base + (int64_t)e * d.in_es);
+    v = ldc<real, NT>(reinterpret_cast<const cx<real> *>(in) + idx);
     v.y *= sy;
   }
   return v;
 }
 
 template <typename real, int MODE, bool BIGTW, bool NT>
-__device__ __forceinline__ void tile_store(const PassDesc &d, void *__restrict__ out, int64_t base,
+__device__ __forceinline__ void tile_store(const PassDesc &d, void *__restrict__ out, int64_t idx,
                                            int e, unsigned mid, cx<real> v, real sx, real sy) {
   if constexpr (BIGTW) {
     const unsigned x = mid * (unsigned)e;          // < big_n <= 2^24
@@ -285,11 +289,11 @@ __device__ __forceinline__ void tile_store(const PassDesc &d, void *__restrict__
   v.x *= sx;
   v.y *= sy;
   if constexpr (MODE == MODE_C2R) {
-    reinterpret_cast<real *>(out)[base + (int64_t)e * d.out_es] = v.x;
+    reinterpret_cast<real *>(out)[idx] = v.x;
   } else if constexpr (MODE == MODE_R2C) {
-    if (e <= (d.n >> 1)) stc<real, NT>(reinterpret_cast<cx<real> *>(out) + base + (int64_t)e * d.out_es, v);
+    if (e <= (d.n >> 1)) stc<real, NT>(reinterpret_cast<cx<real> *>(out) + idx, v);
   } else {
-    stc<real, NT>(reinterpret_cast<cx<real> *>(out) + base + (int64_t)e * d.out_es, v);
+    stc<real, NT>(reinterpret_cast<cx<real> *>(out) + idx, v);
   }
 }
 
@@ -308,32 +312,66 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   const int t = COLS ? (tid / T) : (tid % NT);
   void *col = smem + (size_t)c * CS * WORD;
   const unsigned batch = (unsigned)d.batch, inner = (unsigned)d.inner, mid = (unsigned)d.mid;
-  const unsigned ntiles = (batch + T - 1) / T;
+  // COLS: a tile is T adjacent columns of ONE row of the batch (never straddles a row, so
+  // segments keep their alignment when `inner` is not a multiple of T, e.g. 513-wide half
+  // spectra); the (row, chunk) split is workgroup-uniform scalar arithmetic.
+  // ROWS: the batch is flat (each column is itself a contiguous row of the array).
+  // (four-step passes -- BIGTW -- run their columns along `mid` and use the flat form too.)
+  constexpr bool ROWTILES = COLS && !BIGTW;
+  const unsigned chunks = ROWTILES ? (inner + T - 1) / T : 1;
+  const unsigned ntiles = ROWTILES ? (batch / inner) * chunks : (batch + T - 1) / T;
   const real sy_in = d.conj_in ? (real)-1 : (real)1;
   const real sx_out = (real)d.scale;
   const real sy_out = d.conj_out ? -sx_out : sx_out;
+  const int64_t t_in = (int64_t)t * d.in_es, t_out = (int64_t)t * d.out_es;   // per thread
+  const int64_t q_in = (int64_t)NT * d.in_es, q_out = (int64_t)NT * d.out_es; // uniform steps
 
   for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const unsigned b = tile * T + c;
-    const bool valid = b < batch;
-    // b = (o * mid + m) * inner + i
-    const unsigned bb = valid ? b : 0;
-    const unsigned bm = bb / inner, i = bb - bm * inner;
-    const unsigned o = bm / mid, m = bm - o * mid;
+    bool valid;
+    unsigned o, m, i;
+    if constexpr (ROWTILES) {
+      const unsigned row = tile / chunks, j = tile - row * chunks;
+      i = j * T + c;
+      valid = i < inner;
+      if (!valid) i = 0;
+      o = row / mid;
+      m = row - o * mid;
+    } else {
+      const unsigned b = tile * T + c;
+      valid = b < batch;
+      const unsigned bb = valid ? b : 0;
+      const unsigned bm = bb / inner;
+      i = bb - bm * inner;
+      o = bm / mid;
+      m = bm - o * mid;
+    }
     const int64_t in0 = (int64_t)o * d.in_os + (int64_t)m * d.in_ms + (int64_t)i * d.in_is;
     const int64_t out0 = (int64_t)o * d.out_os + (int64_t)m * d.out_ms + (int64_t)i * d.out_is;
     cx<real> v[R];
     if (valid) {
+      int64_t idx = in0 + t_in;
 #pragma unroll
-      for (int q = 0; q < R; ++q) v[q] = tile_load<real, MODE, (FLAGS & 1) != 0>(d, in, in0, t + q * NT, sy_in);
+      for (int q = 0; q < R; ++q) {
+        v[q] = tile_load<real, MODE, (FLAGS & 1) != 0>(d, in, in0, idx, t + q * NT, sy_in);
+        idx += q_in;
+      }
     } else {
 #pragma unroll
       for (int q = 0; q < R; ++q) v[q] = {0, 0};
     }
-    if constexpr (!(FLAGS & 4)) Stage<real, N, R, SPLIT, 1, RADS...>::run(v, t, col, tw);
+    // Launder the (loop-invariant) twiddle table pointer once per tile: otherwise LICM hoists every
+    // stage's twiddle loads out of the tile loop and parks them in VGPRs for the whole kernel
+    // (40 VGPRs at fp64 n=1024), costing a wave of occupancy per SIMD.
+    const cx<real> *twl = tw;
+    asm volatile("" : "+s"(twl));
+    if constexpr (!(FLAGS & 4)) Stage<real, N, R, SPLIT, 1, RADS...>::run(v, t, col, twl);
     if (valid) {
+      int64_t idx = out0 + t_out;
 #pragma unroll
-      for (int q = 0; q < R; ++q) tile_store<real, MODE, BIGTW, (FLAGS & 2) != 0>(d, out, out0, t + q * NT, m, v[q], sx_out, sy_out);
+      for (int q = 0; q < R; ++q) {
+        tile_store<real, MODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, t + q * NT, m, v[q], sx_out, sy_out);
+        idx += q_out;
+      }
     }
   }
 }
@@ -355,7 +393,7 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int64_t ntiles = (d.batch + T - 1) / T;
+  const int64_t ntiles = (COLS && !BIGTW) ? (d.batch / d.inner) * ((d.inner + T - 1) / T) : (d.batch + T - 1) / T;
   const int64_t cap = pow2_grid_cap();
   const int grid = (int)(ntiles < cap ? ntiles : cap);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, d, in, out);
@@ -365,9 +403,14 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
 // runtime (mode, four-step twiddle) -> instantiation
 template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int... RADS>
 hipError_t launch_pow2_inst(const PassDesc &d, const void *in, void *out, hipStream_t s) {
+  // FLAGS & 8: complex-to-complex, no four-step twiddle (fewer instantiations of fat configurations)
   if (d.tw_hi) {
-    if (d.mode != MODE_C2C || FLAGS != 0) return hipErrorInvalidValue;
-    return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, true, RADS...>(d, in, out, s);
+    if constexpr (FLAGS != 0) {
+      return hipErrorInvalidValue;
+    } else {
+      if (d.mode != MODE_C2C) return hipErrorInvalidValue;
+      return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, true, RADS...>(d, in, out, s);
+    }
   }
   if constexpr (FLAGS != 0) {
     if (d.mode != MODE_C2C) return hipErrorInvalidValue;

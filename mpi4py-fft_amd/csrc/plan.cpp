@@ -369,7 +369,10 @@ int plan_fused3(gfft_plan_s *pl) {
   const int64_t n0 = full[0], n1 = full[1], n2 = full[2];
   const int64_t nc = real ? n2 / 2 + 1 : n2;           // complex entries per row
   const int64_t esz = 2 * prec;
-  const int64_t P = nc + (((nc * esz) % 2048 == 0) ? 256 / esz : 0);   // workspace row pitch
+  // workspace row pitch: rows start on 128-B lines; +256 B when the pitch would be a multiple of 2 KiB
+  const int64_t seg = 128 / esz;
+  int64_t P = (nc + seg - 1) / seg * seg;
+  if ((P * esz) % 2048 == 0) P += 256 / esz;
   pl->need_workspace_bytes = (size_t)(n0 * n1 * P * esz);
 
   auto base = [&](int n, int mode) {
