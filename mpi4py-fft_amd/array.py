@@ -32,6 +32,7 @@ def torch_dtype(dtype):
 
 class DeviceArray:
     __array_priority__ = 100.0
+    __array_ufunc__ = None      # numpy defers `ndarray (op) DeviceArray` to the reflected methods below
 
     def __init__(self, shape, dtype=float, device=None, tensor=None, val=None):
         if np.ndim(shape) == 0:
@@ -178,6 +179,13 @@ class DeviceArray:
 
     def __truediv__(self, other):
         return self._new(self._t / self._bin(other))
+
+    def __rsub__(self, other):
+        return self._new(self._bin(other) - self._t)
+
+    def sum(self, axis=None):
+        r = self._t.sum() if axis is None else self._t.sum(dim=axis)
+        return r.item() if r.ndim == 0 else self._new(r)
 
     def __neg__(self):
         return self._new(-self._t)

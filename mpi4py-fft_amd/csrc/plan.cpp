@@ -199,6 +199,8 @@ struct gfft_plan_s {
   double flops = 0, bytes = 0;
   int variant_rows = 0, variant_cols = 0;
   bool fused3 = false;
+  bool uses_ws = false;        // some pass reads/writes BUF_WS
+  size_t c2r_ws_bytes = 0, fourstep_off = 0;
   std::vector<std::vector<hipEvent_t>> prof;   // per execute: events before pass 0 and after each pass
 };
 
@@ -569,14 +571,27 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
     rc = plan_axis(pl, last, MODE_R2C, false, pl->sizes_in, pl->sizes_out, BUF_IN, BUF_OUT);
     for (int i = naxes - 2; i >= 0 && !rc; --i)
       rc = plan_axis(pl, ax[i], MODE_C2C, false, pl->sizes_out, pl->sizes_out, BUF_OUT, BUF_OUT);
-  } else {  // C2R: complex passes in place on the input, then the real pass
+  } else {  // C2R: complex passes first (into / inside a workspace: the input is never written,
+            // unlike FFTW's multi-dimensional c2r), then the real pass
     for (int i = 0; i <= naxes - 2 && !rc; ++i)
-      rc = plan_axis(pl, ax[i], MODE_C2C, true, pl->sizes_in, pl->sizes_in, BUF_IN, BUF_IN);
-    if (!rc) rc = plan_axis(pl, last, MODE_C2R, true, pl->sizes_in, pl->sizes_out, BUF_IN, BUF_OUT);
+      rc = plan_axis(pl, ax[i], MODE_C2C, true, pl->sizes_in, pl->sizes_in, i == 0 ? BUF_IN : BUF_WS, BUF_WS);
+    if (!rc) rc = plan_axis(pl, last, MODE_C2R, true, pl->sizes_in, pl->sizes_out, naxes > 1 ? BUF_WS : BUF_IN, BUF_OUT);
+    if (naxes > 1) {
+      size_t bytes = 2 * (size_t)precision;
+      for (int i = 0; i < ndims; ++i) bytes *= (size_t)sizes_in[i];
+      pl->uses_ws = true;
+      pl->c2r_ws_bytes = bytes;
+    }
   }
   if (rc) {
     delete pl;
     return rc;
+  }
+  if (pl->uses_ws && !pl->fused3) {
+    // workspace layout: [complex passes of a multi-axis c2r][scratch of an in-place four-step axis]
+    const size_t fs = pl->need_workspace_bytes;
+    pl->fourstep_off = fs ? pl->c2r_ws_bytes : 0;
+    pl->need_workspace_bytes = pl->c2r_ws_bytes + fs;
   }
   // the scale factor rides on the last pass
   pl->passes.back().real_scaled = true;
@@ -590,7 +605,8 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
     return fail(GFFT_ERR_INVALID, "in-place real transforms are not supported");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   void *bufs[3] = {const_cast<void *>(d_in), d_out, nullptr};
-  if (pl->fused3) {
+  void *ws4 = nullptr;   // second scratch for a four-step axis that runs inside the workspace
+  if (pl->fused3 || pl->uses_ws) {
     if (pl->workspace_bytes < pl->need_workspace_bytes) {
       if (pl->workspace) HIP_TRY(hipFree(pl->workspace));
       pl->workspace = nullptr;
@@ -601,6 +617,7 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
       pl->workspace_bytes = pl->need_workspace_bytes;
     }
     bufs[2] = pl->workspace;
+    if (pl->fourstep_off) ws4 = static_cast<char *>(pl->workspace) + pl->fourstep_off;
   }
   std::vector<hipEvent_t> *ev = nullptr;
   if (opts().profile) {
@@ -632,7 +649,9 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
       PassDesc d2 = p2.d;
       if (p2.real_scaled) d2.scale = scale;
       void *mid = dst;
-      if (src == dst) {
+      if (src == dst && ws4) {
+        mid = ws4;
+      } else if (src == dst) {
         if (pl->workspace_bytes < pl->need_workspace_bytes) {
           if (pl->workspace) HIP_TRY(hipFree(pl->workspace));
           pl->workspace = nullptr;

@@ -121,20 +121,26 @@ class FFT(FFTBase):
         return abs(self.padding_factor - 1.0) > 1e-8
 
     def _forward(self, **kw):
+        # `src`: read the input directly from a caller's device array of the planned layout
+        # (no plan of this package writes to its input when run out of place)
         normalize = kw.pop('normalize', True)
+        src = kw.pop('src', None)
+        src = self.fwd.input_array if src is None else src
         scale = self.M if normalize else 1.0
         if not self._padded:
-            self.fwd.execute_scaled(self.fwd.input_array, self.fwd.output_array, scale)
+            self.fwd.execute_scaled(src, self.fwd.output_array, scale)
         else:
-            self.fwd.execute_scaled(self.fwd.input_array, self.fwd.output_array, 1.0)
+            self.fwd.execute_scaled(src, self.fwd.output_array, 1.0)
             self._truncation_forward(self.fwd.output_array, self.forward.output_array, scale)
         return self.forward.output_array
 
     def _backward(self, **kw):
         normalize = kw.pop('normalize', False)
+        src = kw.pop('src', None)
         if self._padded:
-            self._padding_backward(self.backward.input_array, self.bck.input_array)
-        self.bck.execute_scaled(self.bck.input_array, self.bck.output_array,
+            self._padding_backward(self.backward.input_array if src is None else src, self.bck.input_array)
+            src = None
+        self.bck.execute_scaled(self.bck.input_array if src is None else src, self.bck.output_array,
                                 self.M if normalize else 1.0)
         return self.backward.output_array
 

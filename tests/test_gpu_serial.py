@@ -175,3 +175,31 @@ def test_pack_unpack_blocks():
         back = zeros(shape, dt)
         eng.unpack(packed.tensor, back.tensor, shape, axis, p, a.itemsize)
         assert np.array_equal(np.asarray(back), a)
+
+
+def test_callers_input_is_read_in_place_and_preserved():
+    """PFFT.forward(u) / backward(uh) read a caller's device array directly (no copy-in) and never
+    write it -- including multi-axis c2r, which FFTW would clobber."""
+    from mpi4py_fft_amd import PFFT, newDistArray, comm, asdevice, FFT
+    for shape, dt in (((16, 12, 10), 'd'), ((64, 64, 64), 'D'), ((12, 13), 'd'), ((256, 256, 256), 'd')):
+        fft = PFFT(comm.COMM_SELF, shape, dtype=dt)
+        G = O.rng_array(shape, dt, 3)
+        u = newDistArray(fft, False)
+        u[...] = G
+        uh = fft.forward(u)
+        assert np.array_equal(np.asarray(u), G)                      # input untouched
+        ref = O.OPFFT(1, shape, dtype=dt).forward([G])[0]
+        assert np.abs(np.asarray(uh) - ref).max() <= 1e-13 * np.abs(ref).max()
+        vh = newDistArray(fft, True)
+        vh[...] = ref
+        back = fft.backward(vh)
+        assert np.array_equal(np.asarray(vh), ref)                   # spectral input untouched
+        assert np.abs(np.asarray(back) - G).max() <= 1e-12
+        fft.destroy()
+    # serial multi-axis c2r through libfft.FFT
+    f = FFT((12, 10, 8), (0, 1, 2), dtype='d')
+    A = O.rng_array((12, 10, 8), 'd', 1)
+    B = np.asarray(f.forward(asdevice(A))).copy()
+    b = asdevice(B)
+    A2 = np.asarray(f.backward(b))
+    assert np.array_equal(np.asarray(b), B) and np.abs(A2 - A).max() < 1e-12
