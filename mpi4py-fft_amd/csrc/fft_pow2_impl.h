@@ -326,7 +326,17 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   const int64_t t_in = (int64_t)t * d.in_es, t_out = (int64_t)t * d.out_es;   // per thread
   const int64_t q_in = (int64_t)NT * d.in_es, q_out = (int64_t)NT * d.out_es; // uniform steps
 
-  for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Tile order.  Plain: tile = block + k*grid (adjacent tiles run at the same time on different
+  // XCDs).  XCD-contiguous (d.swizzle, grid % 8 == 0): blocks are dealt to XCDs round-robin by
+  // the dispatcher (block b -> XCD b % 8), so XCD x walks its own contiguous eighth of the tiles:
+  // neighbouring column chunks then share one L2, which merges their partial cache lines when
+  // rows are not line aligned (e.g. 513-wide half spectra).  Placement only affects speed.
+  const unsigned per_xcd = (ntiles + 7) / 8;
+  const unsigned kstep = d.swizzle ? gridDim.x / 8 : gridDim.x;
+  const unsigned kend = d.swizzle ? per_xcd : ntiles;
+  for (unsigned k = d.swizzle ? blockIdx.x / 8 : blockIdx.x; k < kend; k += kstep) {
+    const unsigned tile = d.swizzle ? (blockIdx.x % 8) * per_xcd + k : k;
+    if (tile >= ntiles) continue;
     bool valid;
     unsigned o, m, i;
     if constexpr (ROWTILES) {
@@ -395,8 +405,12 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   }
   const int64_t ntiles = (COLS && !BIGTW) ? (d.batch / d.inner) * ((d.inner + T - 1) / T) : (d.batch + T - 1) / T;
   const int64_t cap = pow2_grid_cap();
-  const int grid = (int)(ntiles < cap ? ntiles : cap);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, d, in, out);
+  int grid = (int)(ntiles < cap ? ntiles : cap);
+  PassDesc dd = d;
+  if (dd.swizzle) {
+    if (grid >= 64) grid = grid / 8 * 8; else dd.swizzle = 0;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, dd, in, out);
   return hipGetLastError();
 }
 

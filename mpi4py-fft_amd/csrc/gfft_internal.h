@@ -28,6 +28,7 @@ struct PassDesc {
   int mode;       // PassMode
   int conj_in;    // conjugate on load   (inverse transform = conj . forward . conj)
   int conj_out;   // conjugate on store
+  int swizzle;    // XCD-contiguous tile order (speed only)
   int64_t batch;  // number of columns = outer * mid * inner
   int64_t mid, inner;
   int64_t in_os, in_ms, in_is, in_es;
