@@ -181,6 +181,14 @@ class TorchComm(Comm):
         self._dist.all_to_all_single(recv, send, [int(c) for c in recv_counts],
                                      [int(c) for c in send_counts], group=self._pg)
 
+    def alltoall_async(self, send, recv, send_counts, recv_counts):
+        """Non-blocking variant: returns a handle with ``wait()``.  On the nccl backend the
+        exchange runs on RCCL's own stream after the work already queued on the current stream;
+        ``wait()`` makes the current stream wait for it (no host synchronisation)."""
+        return self._dist.all_to_all_single(recv, send, [int(c) for c in recv_counts],
+                                            [int(c) for c in send_counts], group=self._pg,
+                                            async_op=True)
+
 
 class _CartView(Comm):
     """Cartesian topology over a parent communicator (row-major rank order)."""

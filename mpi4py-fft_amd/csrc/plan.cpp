@@ -202,6 +202,7 @@ struct gfft_plan_s {
   int variant_rows = 0, variant_cols = 0, xcd_swizzle = 0;
   bool fused3 = false;
   bool uses_ws = false;        // some pass reads/writes BUF_WS
+  bool has_fourstep = false;
   size_t c2r_ws_bytes = 0, fourstep_off = 0;
   std::vector<std::vector<hipEvent_t>> prof;   // per execute: events before pass 0 and after each pass
 };
@@ -290,6 +291,11 @@ int plan_axis(gfft_plan_s *pl, int axis, int mode, bool inverse, const std::vect
   BigTw bt;
   int rc = get_bigtw(n, prec, &bt);
   if (rc) return rc;
+  // The intermediate lives in the plan workspace as tmp[o][i2][k1][i] with the i2-stride S2
+  // padded off the power of two (same channel-aliasing argument as the 3-D workspace).
+  const int64_t esz = 2 * prec;
+  int64_t S2 = n1 * inner;
+  if ((S2 * esz) % 2048 == 0) S2 += 256 / esz;
   // step 1: length-n1 transforms over i1 (stride n2*inner) for every (o, i2, i); output transposed
   Pass a = p;
   a.first_of_fourstep = true;
@@ -301,8 +307,8 @@ int plan_axis(gfft_plan_s *pl, int axis, int mode, bool inverse, const std::vect
   a.d.in_ms = inner;
   a.d.in_is = 1;
   a.d.in_es = n2 * inner;
-  a.d.out_os = n * inner;
-  a.d.out_ms = n1 * inner;
+  a.d.out_os = n2 * S2;
+  a.d.out_ms = S2;
   a.d.out_is = 1;
   a.d.out_es = inner;
   a.d.conj_in = inverse ? 1 : 0;
@@ -311,16 +317,16 @@ int plan_axis(gfft_plan_s *pl, int axis, int mode, bool inverse, const std::vect
   a.d.tw_lo = bt.lo;
   a.d.tw_L = bt.L;
   a.d.big_n = n;
-  // step 2: length-n2 transforms over i2 (stride n1*inner) for every (o, k1, i); natural output
+  // step 2: length-n2 transforms over i2 (stride S2) for every (o, k1, i); natural output
   Pass b = p;
   b.second_of_fourstep = true;
   b.d.n = (int)n2;
   b.d.batch = outer * n1 * inner;
   b.d.mid = 1;
   b.d.inner = n1 * inner;
-  b.d.in_os = n * inner;
+  b.d.in_os = n2 * S2;
   b.d.in_is = 1;
-  b.d.in_es = n1 * inner;
+  b.d.in_es = S2;
   b.d.out_os = n * inner;
   b.d.out_is = 1;
   b.d.out_es = n1 * inner;
@@ -337,8 +343,9 @@ int plan_axis(gfft_plan_s *pl, int axis, int mode, bool inverse, const std::vect
     rc = get_twiddles(m, prec, &q->d.tw);
     if (rc) return rc;
   }
-  size_t bytes = (size_t)outer * n * inner * 2 * prec;
+  size_t bytes = (size_t)outer * n2 * S2 * esz;
   if (bytes > pl->need_workspace_bytes) pl->need_workspace_bytes = bytes;
+  pl->has_fourstep = true;
   pl->passes.push_back(a);
   pl->passes.push_back(b);
   return GFFT_OK;
@@ -602,7 +609,7 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
   if (pl->uses_ws && !pl->fused3) {
     // workspace layout: [complex passes of a multi-axis c2r][scratch of an in-place four-step axis]
     const size_t fs = pl->need_workspace_bytes;
-    pl->fourstep_off = fs ? pl->c2r_ws_bytes : 0;
+    pl->fourstep_off = pl->has_fourstep ? pl->c2r_ws_bytes : 0;
     pl->need_workspace_bytes = pl->c2r_ws_bytes + fs;
   }
   // the scale factor rides on the last pass
@@ -629,7 +636,7 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
       pl->workspace_bytes = pl->need_workspace_bytes;
     }
     bufs[2] = pl->workspace;
-    if (pl->fourstep_off) ws4 = static_cast<char *>(pl->workspace) + pl->fourstep_off;
+    if (pl->has_fourstep && pl->uses_ws && !pl->fused3) ws4 = static_cast<char *>(pl->workspace) + pl->fourstep_off;
   }
   std::vector<hipEvent_t> *ev = nullptr;
   if (opts().profile) {
@@ -660,14 +667,15 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
       const Pass &p2 = pl->passes[i + 1];
       PassDesc d2 = p2.d;
       if (p2.real_scaled) d2.scale = scale;
-      void *mid = dst;
-      if (src == dst && ws4) {
-        mid = ws4;
-      } else if (src == dst) {
+      void *mid = ws4;
+      if (!mid) {
         if (pl->workspace_bytes < pl->need_workspace_bytes) {
           if (pl->workspace) HIP_TRY(hipFree(pl->workspace));
           pl->workspace = nullptr;
-          HIP_TRY(hipMalloc(&pl->workspace, pl->need_workspace_bytes));
+          pl->workspace_bytes = 0;
+          hipError_t e = hipMalloc(&pl->workspace, pl->need_workspace_bytes);
+          if (e == hipErrorOutOfMemory) return fail(GFFT_ERR_NOMEM, "workspace allocation failed");
+          HIP_TRY(e);
           pl->workspace_bytes = pl->need_workspace_bytes;
         }
         mid = pl->workspace;

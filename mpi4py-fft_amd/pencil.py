@@ -100,6 +100,48 @@ class Transfer:
             buf = self._stage[key] = torch.empty_like(like)
         return buf
 
+    # Chunked pipeline: when array axis 0 takes no part in the exchange (it is neither split nor
+    # gathered -- e.g. the first transfer of a 3-D pencil decomposition), slabs of axis 0 are
+    # independent smaller redistributions of contiguous sub-arrays.  Each slab's all-to-all is
+    # issued asynchronously (RCCL runs it on its own HIP stream), so pack(k+1) and unpack(k-1)
+    # overlap the wire time of slab k.  CHUNK_MIN_BYTES / CHUNKS are tunables.
+    CHUNKS = 4
+    CHUNK_MIN_BYTES = 64 << 20
+
+    def _nchunks(self, shape_src, axis_src, axis_dst, nbytes):
+        if self._p == 1 or 0 in (axis_src, axis_dst) or nbytes < self.CHUNK_MIN_BYTES:
+            return 1
+        if not hasattr(self.comm, 'alltoall_async'):
+            return 1
+        return max(1, min(self.CHUNKS, shape_src[0]))
+
+    def _move_chunked(self, src, dst, shape_src, axis_src, shape_dst, axis_dst, K):
+        p = self._p
+        eng = _lib.engine()
+        ts, td = src.tensor, dst.tensor
+        isz = self.dtype.itemsize
+        mult = 2 if self.dtype.kind == 'c' else 1
+        n0 = shape_src[0]
+        bounds = [(k * n0) // K for k in range(K + 1)]
+        send = self._staging(ts, 'send')
+        recv = self._staging(td, 'recv')
+        works = []
+        for k in range(K):
+            lo, hi = bounds[k], bounds[k + 1]
+            sshape = (hi - lo,) + tuple(shape_src[1:])
+            dshape = (hi - lo,) + tuple(shape_dst[1:])
+            s_sub, snd = ts[lo:hi], send[lo:hi]
+            eng.pack(s_sub, snd, sshape, axis_src, p, isz)
+            rest_s = int(np.prod(sshape, dtype=np.int64)) // sshape[axis_src]
+            rest_d = int(np.prod(dshape, dtype=np.int64)) // dshape[axis_dst]
+            cs = [rest_s * _blockdist(shape_src[axis_src], p, i)[0] * mult for i in range(p)]
+            cd = [rest_d * _blockdist(shape_dst[axis_dst], p, i)[0] * mult for i in range(p)]
+            works.append((self.comm.alltoall_async(self._real_view(snd), self._real_view(recv[lo:hi]), cs, cd),
+                          recv[lo:hi], td[lo:hi], dshape))
+        for work, rcv, d_sub, dshape in works:
+            work.wait()
+            eng.unpack(rcv, d_sub, dshape, axis_dst, p, isz)
+
     def _move(self, src, dst, shape_src, axis_src, counts_src, shape_dst, axis_dst, counts_dst):
         p = self._p
         eng = _lib.engine()
@@ -110,6 +152,10 @@ class Transfer:
             return
         isz = self.dtype.itemsize
         mult = 2 if self.dtype.kind == 'c' else 1
+        K = self._nchunks(shape_src, axis_src, axis_dst, ts.numel() * isz)
+        if K > 1:
+            self._move_chunked(src, dst, shape_src, axis_src, shape_dst, axis_dst, K)
+            return
         if _is_outermost(shape_src, axis_src):
             send = ts
         else:

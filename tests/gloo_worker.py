@@ -19,7 +19,10 @@ def main():
     _lib.set_engine(HostEngine())
     world = comm.init_distributed('gloo')
     P, r = world.Get_size(), world.Get_rank()
-    cases = [((16, 12, 10), 'D', {}), ((13, 12, 10), 'd', {}), ((7, 8, 9), 'D', {}),
+    from mpi4py_fft_amd import pencil
+    pencil.Transfer.CHUNK_MIN_BYTES = 0     # exercise the chunked asynchronous exchange over gloo
+    pencil.Transfer.CHUNKS = 3
+    cases = [((16, 12, 10), "D", {}), ((13, 12, 10), "d", {}), ((7, 8, 9), "D", {}),
              ((12, 13), 'D', {}), ((16, 12, 10), 'd', dict(padding=[1.5, 1.5, 1.5])),
              ((12, 10, 8), 'D', dict(grid=(-1,))), ((12, 9, 8, 6), 'd', dict(axes=((0,), (1,), (2, 3))))]
     for shape, dt, kw in cases:

@@ -189,3 +189,16 @@ def test_nccl_world_of_one():
         assert torch.equal(r, t)
     finally:
         dist.destroy_process_group()
+
+
+def test_chunked_transfer_pipeline_on_device(monkeypatch):
+    """Slab-chunked asynchronous exchange with the real pack/unpack kernels."""
+    from mpi4py_fft_amd import pencil
+    monkeypatch.setattr(pencil.Transfer, 'CHUNK_MIN_BYTES', 0)
+    monkeypatch.setattr(pencil.Transfer, 'CHUNKS', 3)
+    for ci in range(6):
+        cases.check_transfer_golden(ci)
+    for name in ('c2c_16x16x16_p8', 'r2c_16x16x18_p8', 'r2c_13x12x10_p4', 'c2c_6x7x8x9_p4'):
+        cases.check_pfft_golden(name)
+    cases.check_pfft_vs_oracle(8, (32, 48, 40), 'D')
+    cases.check_pfft_vs_oracle(4, (33, 20, 18), 'd')

@@ -81,3 +81,16 @@ def test_misuse_raises():
     with pytest.raises(NotImplementedError):
         from mpi4py_fft_amd import fftw
         fftw.dctn(None)
+
+
+def test_chunked_transfer_pipeline(monkeypatch):
+    """The slab-chunked asynchronous exchange (pencil.Transfer._move_chunked) gives the same
+    result as the single exchange; forced on by lowering the size threshold."""
+    from mpi4py_fft_amd import pencil
+    monkeypatch.setattr(pencil.Transfer, 'CHUNK_MIN_BYTES', 0)
+    monkeypatch.setattr(pencil.Transfer, 'CHUNKS', 3)
+    for ci in range(6):
+        cases.check_transfer_golden(ci)
+    cases.check_pfft_golden('c2c_16x16x16_p8')
+    cases.check_pfft_golden('r2c_16x16x18_p8')
+    cases.check_pfft_golden('r2c_13x12x10_p4')

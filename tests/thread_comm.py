@@ -91,6 +91,19 @@ class ThreadComm(C.Comm):
         self._g['barrier'].wait()
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def _alltoall_async(self, send, recv, send_counts, recv_counts):
+    self.alltoall(send, recv, send_counts, recv_counts)
+    return _Done()
+
+
+ThreadComm.alltoall_async = _alltoall_async
+
+
 class _ThreadCart(C._CartView):
     def Sub(self, remdims):
         remdims = tuple(bool(r) for r in remdims)
