@@ -105,18 +105,60 @@ template <typename real, int S> __device__ __forceinline__ void dft16(cx<real> *
     }
 }
 
+template <typename real> __device__ __forceinline__ void bf3(cx<real> &a, cx<real> &b, cx<real> &c) {
+  const real h = (real)0.86602540378443864676372317075294;   // sin(pi/3)
+  cx<real> t1 = b + c;
+  cx<real> t2 = {a.x - (real)0.5 * t1.x, a.y - (real)0.5 * t1.y};
+  cx<real> t3 = {(b.x - c.x) * h, (b.y - c.y) * h};
+  a = a + t1;
+  b = {t2.x + t3.y, t2.y - t3.x};      // t2 - i*t3
+  c = {t2.x - t3.y, t2.y + t3.x};      // t2 + i*t3
+}
+
+template <typename real, int S> __device__ __forceinline__ void dft3(cx<real> *v) { bf3(v[0], v[S], v[2 * S]); }
+
+template <typename real, int S> __device__ __forceinline__ void dft12(cx<real> *v) {
+  // x[n] = v[n*S], n = i + 3a (i < 3, a < 4); X[k1 + 4*k2] = sum_i W3^(i k2) W12^(i k1) sum_a x[i+3a] W4^(a k1)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) bf4(v[i * S], v[(i + 3) * S], v[(i + 6) * S], v[(i + 9) * S]);   // Y_i[k1] at i + 3*k1
+  const real h = (real)0.86602540378443864676372317075294;
+  v[4 * S] = mul_c(v[4 * S], h, (real)-0.5);             // i=1,k1=1: W12^1
+  v[7 * S] = mul_c(v[7 * S], (real)0.5, -h);             // i=1,k1=2: W12^2
+  v[10 * S] = mul_mi(v[10 * S]);                         // i=1,k1=3: W12^3 = -i
+  v[5 * S] = mul_c(v[5 * S], (real)0.5, -h);             // i=2,k1=1: W12^2
+  v[8 * S] = mul_c(v[8 * S], (real)-0.5, -h);            // i=2,k1=2: W12^4
+  v[11 * S] = {-v[11 * S].x, -v[11 * S].y};              // i=2,k1=3: W12^6 = -1
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) bf3(v[(3 * k1) * S], v[(3 * k1 + 1) * S], v[(3 * k1 + 2) * S]);  // X[k1+4k2] at 3*k1 + k2
+  cx<real> o[12];
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < 3; ++k2) o[k1 + 4 * k2] = v[(3 * k1 + k2) * S];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) v[k * S] = o[k];
+}
+
 template <typename real, int r, int S> __device__ __forceinline__ void dft(cx<real> *v) {
+  static_assert(r == 2 || r == 3 || r == 4 || r == 8 || r == 12 || r == 16, "radix");
   if constexpr (r == 2) dft2<real, S>(v);
+  else if constexpr (r == 3) dft3<real, S>(v);
   else if constexpr (r == 4) dft4<real, S>(v);
   else if constexpr (r == 8) dft8<real, S>(v);
+  else if constexpr (r == 12) dft12<real, S>(v);
   else dft16<real, S>(v);
 }
 
 // ---- LDS layout -----------------------------------------------------------------------------
-__host__ __device__ constexpr int pad_slot(int e) { return e + (e >> 4); }
+__host__ __device__ constexpr bool is_pow2_c(int n) { return n > 0 && (n & (n - 1)) == 0; }
+// slot padding: power-of-two sizes insert one word per 16 (breaks the power-of-two scatter
+// strides); sizes with a factor 3 scatter with odd multiples and need none.  PAD is a
+// compile-time property of N so that pad(a + b) splits into pad(a) + constant (see Stage::run).
+template <bool PAD> __host__ __device__ constexpr int pad_slot(int e) { return PAD ? e + (e >> 4) : e; }
 
 template <int N, bool COLS> struct Lds {
-  static constexpr int NP = N + N / 16 + 1;
+  static constexpr bool PAD = is_pow2_c(N);
+  static constexpr int NP = PAD ? N + N / 16 + 1 : N + 1;
   // COLS: column stride == 2 (mod 16) words so that 8 adjacent columns x 2 rows cover the banks
   static constexpr int CS = COLS ? ((NP + 15) / 16) * 16 + 2 : NP;
 };
@@ -127,7 +169,22 @@ __device__ __forceinline__ void twiddle(cx<real> *v, int k, const cx<real> *__re
   constexpr int step = N / (Ns * r);
   const cx<real> w1 = tw[k * step];
   v[1 * S] = cmul(v[1 * S], w1);
-  if constexpr (r >= 4) {
+  if constexpr (r == 3) {
+    v[2 * S] = cmul(v[2 * S], tw[2 * k * step]);
+  } else if constexpr (r == 12) {
+    const cx<real> w2 = tw[2 * k * step], w4 = tw[4 * k * step], w8 = tw[8 * k * step];
+    const cx<real> w3 = cmul(w1, w2);
+    v[2 * S] = cmul(v[2 * S], w2);
+    v[3 * S] = cmul(v[3 * S], w3);
+    v[4 * S] = cmul(v[4 * S], w4);
+    v[5 * S] = cmul(v[5 * S], cmul(w1, w4));
+    v[6 * S] = cmul(v[6 * S], cmul(w2, w4));
+    v[7 * S] = cmul(v[7 * S], cmul(w3, w4));
+    v[8 * S] = cmul(v[8 * S], w8);
+    v[9 * S] = cmul(v[9 * S], cmul(w1, w8));
+    v[10 * S] = cmul(v[10 * S], cmul(w2, w8));
+    v[11 * S] = cmul(v[11 * S], cmul(w3, w8));
+  } else if constexpr (r >= 4) {
     const cx<real> w2 = tw[2 * k * step];
     const cx<real> w3 = cmul(w1, w2);
     v[2 * S] = cmul(v[2 * S], w2);
@@ -171,7 +228,7 @@ struct Stage<real, N, R, SPLIT, Ns, r, REST...> {
     if constexpr (Ns > 1) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int k = (t + i * NT) & (Ns - 1);
+        const int k = (t + i * NT) % Ns;
         twiddle<real, N, r, Ns, NB>(v + i, k, tw);
       }
     }
@@ -181,31 +238,32 @@ struct Stage<real, N, R, SPLIT, Ns, r, REST...> {
       // scatter: butterfly j = t + i*NT, output m -> index j0 + m*Ns, j0 = (j/Ns)*Ns*r + j%Ns.
       // pad_slot(j0 + m*Ns) == pad_slot(j0) + woff(m) and pad_slot(t + q*NT) == pad_slot(t) + roff(q)
       // for power-of-two Ns, NT: one address register per butterfly, the rest are DS immediates.
+      constexpr bool PAD = is_pow2_c(N);
       int wbase[NB];
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int j = t + i * NT;
-        wbase[i] = pad_slot((j / Ns) * (Ns * r) + (j & (Ns - 1)));
+        wbase[i] = pad_slot<PAD>((j / Ns) * (Ns * r) + (j % Ns));
       }
-      const int rbase = pad_slot(t);
+      const int rbase = pad_slot<PAD>(t);
       if constexpr (SPLIT) {
         real *w = reinterpret_cast<real *>(col);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
-          for (int m = 0; m < r; ++m) w[wbase[i] + m * Ns + ((m * Ns) >> 4)] = v[i + m * NB].x;
+          for (int m = 0; m < r; ++m) w[wbase[i] + pad_slot<PAD>(m * Ns)] = v[i + m * NB].x;
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q].x = w[rbase + q * NT + ((q * NT) >> 4)];
+        for (int q = 0; q < R; ++q) v[q].x = w[rbase + pad_slot<PAD>(q * NT)];
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
-          for (int m = 0; m < r; ++m) w[wbase[i] + m * Ns + ((m * Ns) >> 4)] = v[i + m * NB].y;
+          for (int m = 0; m < r; ++m) w[wbase[i] + pad_slot<PAD>(m * Ns)] = v[i + m * NB].y;
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q].y = w[rbase + q * NT + ((q * NT) >> 4)];
+        for (int q = 0; q < R; ++q) v[q].y = w[rbase + pad_slot<PAD>(q * NT)];
       } else {
         float2 *w = reinterpret_cast<float2 *>(col);
         __syncthreads();
@@ -213,11 +271,11 @@ struct Stage<real, N, R, SPLIT, Ns, r, REST...> {
         for (int i = 0; i < NB; ++i)
 #pragma unroll
           for (int m = 0; m < r; ++m)
-            w[wbase[i] + m * Ns + ((m * Ns) >> 4)] = make_float2(v[i + m * NB].x, v[i + m * NB].y);
+            w[wbase[i] + pad_slot<PAD>(m * Ns)] = make_float2(v[i + m * NB].x, v[i + m * NB].y);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-          float2 f = w[rbase + q * NT + ((q * NT) >> 4)];
+          float2 f = w[rbase + pad_slot<PAD>(q * NT)];
           v[q].x = f.x;
           v[q].y = f.y;
         }

@@ -60,6 +60,10 @@ bool pow2_supported_f32(int n);
 hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void *in, void *out, hipStream_t s);
 hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void *in, void *out, hipStream_t s);
 int pow2_grid_cap();
+// lengths 3^b * 2^k handled by the same register-resident kernel with R = 12 (fft_mix3_*.hip)
+bool mix3_supported(int n);
+hipError_t launch_mix3_f64(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
+hipError_t launch_mix3_f32(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
 
 hipError_t launch_pack(const void *src, void *dst, int64_t outer, int64_t naxis, int64_t inner,
                        int nparts, int itemsize, bool unpack, hipStream_t s);

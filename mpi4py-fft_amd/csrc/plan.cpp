@@ -166,9 +166,11 @@ struct Pass {
 
 bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 
+// lengths served by the register-resident kernels: powers of two 16..4096 and 3^b*2^k 48..3456
 bool pow2_ok(int64_t n, int precision) {
   if (opts().force_generic) return false;
   if (n > 4096) return false;
+  if (mix3_supported((int)n)) return true;
   return precision == 8 ? pow2_supported_f64((int)n) : pow2_supported_f32((int)n);
 }
 
@@ -473,6 +475,9 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   const int64_t esz_out = (d.mode == MODE_C2R ? 1 : 2) * (int64_t)pl->precision;
   d.swizzle = pl->xcd_swizzle >= 0 ? pl->xcd_swizzle
                                    : (p.cols && ((d.out_es * esz_out) % 128 != 0) ? 1 : 0);
+  if (p.pow2 && mix3_supported(d.n)) {
+    return pl->precision == 8 ? launch_mix3_f64(d, p.cols, in, out, s) : launch_mix3_f32(d, p.cols, in, out, s);
+  }
   if (p.pow2) {
     const int variant = p.cols ? pl->variant_cols : pl->variant_rows;
     return pl->precision == 8 ? launch_pow2_f64(d, p.cols, variant, in, out, s)

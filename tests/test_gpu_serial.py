@@ -203,3 +203,29 @@ def test_callers_input_is_read_in_place_and_preserved():
     b = asdevice(B)
     A2 = np.asarray(f.backward(b))
     assert np.array_equal(np.asarray(b), B) and np.abs(A2 - A).max() < 1e-12
+
+
+MIX3 = [48, 72, 96, 108, 144, 192, 216, 288, 384, 432, 576, 768, 864, 1152, 1296, 1536, 1728, 2304, 2592, 3072, 3456]
+
+
+@pytest.mark.parametrize('n', MIX3)
+def test_mix3_rows_and_cols(n):
+    """Lengths 3^b * 2^k on the register-resident kernels (R = 12): contiguous and strided axes,
+    ragged tiles, both precisions, real and complex."""
+    _check((3, n), (1,), 'D')
+    _check((n, 20), (0,), 'D')
+    _check((2, n, 5), (1,), 'F')
+    _check((3, n), (1,), 'd')
+    _check((n, 6), (0,), 'f')
+
+
+@pytest.mark.parametrize('shape,dt', [((96, 48, 192), 'D'), ((192, 96, 144), 'd'), ((72, 64, 108), 'F'),
+                                      ((384, 384, 384), 'D'), ((768, 96, 64), 'f')])
+def test_mix3_3d(shape, dt):
+    _check(shape, None, dt)
+
+
+def test_four_step_mixed_lengths():
+    _check((2, 3 * 4096), (1,), 'D')      # 12288 = 96 x 128
+    _check((3 * 2048, 2), (0,), 'D')
+    _check((2, 9 * 4096), (1,), 'F')

@@ -64,7 +64,12 @@ pfft_case('    PFFT 1024^3 r2c f64', (1024,) * 3, 'd')
 pfft_case('C5' + "' PFFT 1024^3 r2c f32", (1024,) * 3, 'f')
 pfft_case('    PFFT 2048x1024x1024 r2c f32', (2048, 1024, 1024), 'f')
 pfft_case('    PFFT 1024^3 c128 padded 1.5 (683->1024)', (683, 683, 683), 'D', padding=[1.5, 1.5, 1.5])
-pfft_case('    PFFT 768^3 c128 (generic radix-3)', (768,) * 3, 'D')
+pfft_case('    PFFT 768^3 c128 (R=12 kernels)', (768,) * 3, 'D')
+pfft_case('    PFFT 384^3 c128', (384,) * 3, 'D')
+pfft_case('    PFFT 768^3 r2c f64', (768,) * 3, 'd')
+pfft_case('    PFFT 1536x768x768 c128', (1536, 768, 768), 'D')
+pfft_case('    PFFT 512^3 r2c f64 padded 1.5 (-> 768^3)', (512,) * 3, 'd', padding=[1.5, 1.5, 1.5])
+pfft_case('    PFFT 1152^3 c64', (1152,) * 3, 'F')
 pfft_case('    PFFT 1000^3 c64 (generic)', (1000,) * 3, 'F')
 plan_case('C2  batched 1-D 2^20 c128, B=64', (64, 1 << 20), 'D', (1,))
 plan_case('    batched 1-D 2^20 c64, B=128', (128, 1 << 20), 'F', (1,))
