@@ -43,6 +43,19 @@ struct PassDesc {
   int tw_L;
 };
 
+// pointwise helpers of the embedding fallbacks (Bluestein, long real transforms): lines of the
+// array [outer][nin|nout][inner] are copied into / out of a complex scratch [outer][Lw][inner]
+struct PointDesc {
+  int64_t outer, inner;
+  int64_t n;          // logical transform length
+  int64_t nin, nout;  // entries per line on the input / output side (n, or n/2+1 on a half spectrum)
+  int64_t Lw;         // line length in the scratch (n, or Bluestein's M)
+  int mode;           // PassMode
+  int conj;           // conjugate (embed: on load; extract: on store)
+  const void *chirp;  // cx<real>[n]: exp(-i pi j^2 / n), or null
+  const void *B;      // cx<real>[Lw]: FFT of the wrapped conjugate chirp (PK_MULB)
+};
+
 struct Factors {
   int count;
   int r[24];
@@ -70,6 +83,9 @@ hipError_t launch_pack(const void *src, void *dst, int64_t outer, int64_t naxis,
 hipError_t launch_trunc(const void *src, void *dst, int64_t outer, int64_t npad,
                         int64_t ntrunc, int64_t inner, int is_real, int precision, double scale,
                         bool pad_direction, hipStream_t s);
+hipError_t launch_embed(const PointDesc &p, int precision, const void *in, void *scratch, hipStream_t s);
+hipError_t launch_mulb(const PointDesc &p, int precision, void *scratch, hipStream_t s);
+hipError_t launch_extract(const PointDesc &p, int precision, const void *scratch, void *out, double scale, hipStream_t s);
 hipError_t launch_scale(void *data, int64_t count, int precision, double scale, hipStream_t s);
 extern int g_copy_nt;
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s);

@@ -153,6 +153,97 @@ hipError_t launch_trunc(const void *src, void *dst, int64_t outer, int64_t npad,
   return hipGetLastError();
 }
 
+// ---- embedding fallbacks (Bluestein / long real transforms) -----------------------------------
+template <typename real>
+__global__ void __launch_bounds__(MV_THREADS)
+embed_kernel(PointDesc p, const void *__restrict__ in, cx<real> *__restrict__ W) {
+  const int64_t total = p.outer * p.Lw * p.inner;
+  const cx<real> *chirp = reinterpret_cast<const cx<real> *>(p.chirp);
+  for (int64_t idx = (int64_t)blockIdx.x * MV_THREADS + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * MV_THREADS) {
+    const int64_t o = idx / (p.Lw * p.inner);
+    const int64_t rem = idx - o * p.Lw * p.inner;
+    const int64_t j = rem / p.inner, i = rem - j * p.inner;
+    cx<real> v = {0, 0};
+    if (j < p.n) {
+      if (p.mode == MODE_R2C) {
+        v.x = reinterpret_cast<const real *>(in)[(o * p.nin + j) * p.inner + i];
+      } else if (p.mode == MODE_C2R) {
+        const bool mirror = j > p.n / 2;
+        const int64_t jj = mirror ? p.n - j : j;
+        v = reinterpret_cast<const cx<real> *>(in)[(o * p.nin + jj) * p.inner + i];
+        if (mirror) v.y = -v.y;
+      } else {
+        v = reinterpret_cast<const cx<real> *>(in)[(o * p.nin + j) * p.inner + i];
+      }
+      if (p.conj) v.y = -v.y;
+      if (chirp) v = cmul(v, chirp[j]);
+    }
+    W[idx] = v;
+  }
+}
+
+template <typename real>
+__global__ void __launch_bounds__(MV_THREADS) mulb_kernel(PointDesc p, cx<real> *__restrict__ W) {
+  const int64_t total = p.outer * p.Lw * p.inner;
+  const cx<real> *B = reinterpret_cast<const cx<real> *>(p.B);
+  for (int64_t idx = (int64_t)blockIdx.x * MV_THREADS + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * MV_THREADS) {
+    const int64_t k = (idx / p.inner) % p.Lw;
+    W[idx] = cmul(W[idx], B[k]);
+  }
+}
+
+template <typename real>
+__global__ void __launch_bounds__(MV_THREADS)
+extract_kernel(PointDesc p, const cx<real> *__restrict__ W, void *__restrict__ out, real scale) {
+  const int64_t total = p.outer * p.nout * p.inner;
+  const cx<real> *chirp = reinterpret_cast<const cx<real> *>(p.chirp);
+  for (int64_t idx = (int64_t)blockIdx.x * MV_THREADS + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * MV_THREADS) {
+    const int64_t o = idx / (p.nout * p.inner);
+    const int64_t rem = idx - o * p.nout * p.inner;
+    const int64_t k = rem / p.inner, i = rem - k * p.inner;
+    cx<real> v = W[(o * p.Lw + k) * p.inner + i];
+    if (chirp) v = cmul(v, chirp[k]);
+    if (p.conj) v.y = -v.y;
+    v.x *= scale;
+    v.y *= scale;
+    if (p.mode == MODE_C2R) reinterpret_cast<real *>(out)[idx] = v.x;
+    else reinterpret_cast<cx<real> *>(out)[idx] = v;
+  }
+}
+
+hipError_t launch_embed(const PointDesc &p, int precision, const void *in, void *scratch, hipStream_t s) {
+  const int64_t total = p.outer * p.Lw * p.inner;
+  if (total == 0) return hipSuccess;
+  if (precision == 8)
+    hipLaunchKernelGGL(embed_kernel<double>, dim3(mv_grid(total)), dim3(MV_THREADS), 0, s, p, in, (cx<double> *)scratch);
+  else
+    hipLaunchKernelGGL(embed_kernel<float>, dim3(mv_grid(total)), dim3(MV_THREADS), 0, s, p, in, (cx<float> *)scratch);
+  return hipGetLastError();
+}
+
+hipError_t launch_mulb(const PointDesc &p, int precision, void *scratch, hipStream_t s) {
+  const int64_t total = p.outer * p.Lw * p.inner;
+  if (total == 0) return hipSuccess;
+  if (precision == 8)
+    hipLaunchKernelGGL(mulb_kernel<double>, dim3(mv_grid(total)), dim3(MV_THREADS), 0, s, p, (cx<double> *)scratch);
+  else
+    hipLaunchKernelGGL(mulb_kernel<float>, dim3(mv_grid(total)), dim3(MV_THREADS), 0, s, p, (cx<float> *)scratch);
+  return hipGetLastError();
+}
+
+hipError_t launch_extract(const PointDesc &p, int precision, const void *scratch, void *out, double scale, hipStream_t s) {
+  const int64_t total = p.outer * p.nout * p.inner;
+  if (total == 0) return hipSuccess;
+  if (precision == 8)
+    hipLaunchKernelGGL(extract_kernel<double>, dim3(mv_grid(total)), dim3(MV_THREADS), 0, s, p, (const cx<double> *)scratch, out, scale);
+  else
+    hipLaunchKernelGGL(extract_kernel<float>, dim3(mv_grid(total)), dim3(MV_THREADS), 0, s, p, (const cx<float> *)scratch, out, (float)scale);
+  return hipGetLastError();
+}
+
 // ---- scale ----------------------------------------------------------------------------------
 template <typename real>
 __global__ void __launch_bounds__(MV_THREADS) scale_kernel(real *__restrict__ p, int64_t n, real sc) {

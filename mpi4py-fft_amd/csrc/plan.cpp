@@ -4,9 +4,12 @@
 // fftw_planxfftn.c:10-77): it turns (sizes, axes, kind) into one strided+batched 1-D pass per
 // transformed axis -- {n, element stride, batch dims} exactly as the reference builds FFTW guru
 // iodims (.c:25-47), but 64-bit -- and binds each pass to a kernel family:
-//   * power-of-two n <= 4096        -> fft_pow2 kernels (ROWS if the axis is contiguous, else COLS)
-//   * any other n <= generic limit  -> fft_generic (LDS mixed radix)
-//   * larger composite n            -> four-step: two strided passes + fused twiddle
+//   * n = 2^k (16..4096), 3^b 2^k (48..3456) -> register-resident kernels (fft_pow2_impl.h; ROWS if
+//                                       the axis is contiguous, else COLS)
+//   * other n <= 4096 with small primes  -> fft_generic (LDS mixed radix)
+//   * longer composite n                 -> four-step: two strided passes + fused twiddle
+//   * anything else (large prime factors, long real transforms) -> Bluestein / complex embedding
+//   * 3-D all-axes plans on one rank     -> plan_fused3: pass order + padded-pitch workspace
 #include "../../include/gfft.h"
 #include "gfft_internal.h"
 
@@ -153,21 +156,32 @@ int get_bigtw(int64_t big_n, int precision, BigTw *out) {
 }
 
 // ---- plan -------------------------------------------------------------------------------
-enum Buf { BUF_IN = 0, BUF_OUT = 1, BUF_WS = 2 };
+// Buffers a pass may read/write.  IN/OUT are the caller's arrays; the other three are regions of
+// one plan-owned scratch allocation (made at the first execute):
+//   WS   an array-sized workspace: the padded-pitch W of the 3-D schedule, or the complex staging
+//        of a multi-axis c2r (so the caller's input is never written)
+//   FS   the transposed intermediate of a four-step axis
+//   AUX  the embedding buffer of a Bluestein / real-as-complex axis
+enum Buf { BUF_IN = 0, BUF_OUT = 1, BUF_WS = 2, BUF_FS = 3, BUF_AUX = 4, BUF_COUNT = 5 };
+
+enum PassKind { PK_FFT = 0, PK_EMBED, PK_MULB, PK_EXTRACT };
 
 struct Pass {
+  PassKind kind = PK_FFT;
   PassDesc d{};
   Factors f{};
-  bool pow2 = false, cols = false;
-  bool first_of_fourstep = false, second_of_fourstep = false;
-  int src = BUF_IN, dst = BUF_OUT;   // where the logical axis pass reads / must leave its data
-  bool real_scaled = false;          // this pass carries the plan's scale factor
+  bool regk = false, cols = false;   // register-resident kernel family (else fft_generic); mapping
+  int src = BUF_IN, dst = BUF_OUT;
+  bool carries_scale = false;        // the plan's scale factor is applied by this pass
+  bool logical_first = false;        // first kernel of a transformed axis (profiling/report)
+  PointDesc pt{};                    // PK_EMBED / PK_MULB / PK_EXTRACT geometry
+  double extra_scale = 1.0;          // e.g. 1/M of Bluestein's inverse
 };
 
 bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 
 // lengths served by the register-resident kernels: powers of two 16..4096 and 3^b*2^k 48..3456
-bool pow2_ok(int64_t n, int precision) {
+bool regk_ok(int64_t n, int precision) {
   if (opts().force_generic) return false;
   if (n > 4096) return false;
   if (mix3_supported((int)n)) return true;
@@ -189,7 +203,11 @@ bool factorize(int64_t n, Factors *f, int max_prime) {
   return true;
 }
 
-constexpr int GENERIC_MAX_PRIME = 1024;   // O(r^2) butterfly above this is not worth running
+// the generic kernel evaluates a prime radix r by definition, O(r^2) per butterfly: fine for the
+// small odd primes of everyday sizes, hopeless for big ones -> Bluestein above this
+constexpr int GENERIC_MAX_PRIME = 61;
+
+size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
 
@@ -198,65 +216,296 @@ struct gfft_plan_s {
   std::vector<int64_t> sizes_in, sizes_out;
   std::vector<int> axes;
   std::vector<Pass> passes;
-  void *workspace = nullptr;
-  size_t workspace_bytes = 0, need_workspace_bytes = 0;
+  size_t region_bytes[BUF_COUNT] = {0, 0, 0, 0, 0};   // WS / FS / AUX sizes
+  void *scratch = nullptr;
+  size_t scratch_bytes = 0;
   double flops = 0, bytes = 0;
   int variant_rows = 0, variant_cols = 0, xcd_swizzle = 0;
   bool fused3 = false;
-  bool uses_ws = false;        // some pass reads/writes BUF_WS
-  bool has_fourstep = false;
-  size_t c2r_ws_bytes = 0, fourstep_off = 0;
   std::vector<std::vector<hipEvent_t>> prof;   // per execute: events before pass 0 and after each pass
 };
 
 namespace {
 
-// Build the pass(es) for one transformed axis.  `shape_in/out`: array shapes seen by this pass.
-int plan_axis(gfft_plan_s *pl, int axis, int mode, bool inverse, const std::vector<int64_t> &shape_in,
-              const std::vector<int64_t> &shape_out, int src, int dst) {
-  const int nd = pl->ndims;
+void need(gfft_plan_s *pl, int buf, size_t bytes) {
+  if (bytes > pl->region_bytes[buf]) pl->region_bytes[buf] = bytes;
+}
+
+// A batch of 1-D lines: array [outer][nin -> nout][inner] (row-major), logical length n.
+struct Line {
+  int64_t outer, inner, n, nin, nout;
+  int mode;        // PassMode
+  bool inverse;
+  int src, dst;
+};
+
+int plan_line(gfft_plan_s *pl, const Line &L, bool top);
+
+PassDesc natural_desc(const Line &L) {
+  PassDesc d{};
+  d.n = (int)L.n;
+  d.mode = L.mode;
+  d.conj_in = L.inverse ? 1 : 0;
+  d.conj_out = (L.inverse && L.mode != MODE_C2R) ? 1 : 0;
+  d.batch = L.outer * L.inner;
+  d.mid = 1;
+  d.inner = L.inner;
+  d.in_os = L.nin * L.inner;
+  d.in_is = 1;
+  d.in_es = L.inner;
+  d.out_os = L.nout * L.inner;
+  d.out_is = 1;
+  d.out_es = L.inner;
+  d.scale = 1.0;
+  return d;
+}
+
+// ---- four-step for long composite lengths: n = n1 * n2 (complex) ---------------------------
+int plan_fourstep(gfft_plan_s *pl, const Line &L, int64_t n1, int64_t n2) {
   const int prec = pl->precision;
-  const int64_t n = (mode == MODE_C2R) ? shape_out[axis] : shape_in[axis];
-  int64_t outer = 1, inner = 1;
-  for (int i = 0; i < axis; ++i) outer *= shape_in[i];
-  for (int i = axis + 1; i < nd; ++i) inner *= shape_in[i];
-  const int64_t nin = shape_in[axis], nout = shape_out[axis];
-  const int64_t batch = outer * inner;
+  const int64_t esz = 2 * prec, n = L.n, inner = L.inner, outer = L.outer;
+  BigTw bt;
+  int rc = get_bigtw(n, prec, &bt);
+  if (rc) return rc;
+  // The intermediate tmp[o][i2][k1][i] lives in the FS region with its i2-stride S2 padded off
+  // the power of two (same channel-aliasing argument as the 3-D workspace).
+  int64_t S2 = n1 * inner;
+  if ((S2 * esz) % 2048 == 0) S2 += 256 / esz;
+  Pass a, b;
+  // step 1: length-n1 transforms over i1 (stride n2*inner) for every (o, i2, i); the store
+  // applies W_n^(i2*k1) and writes transposed-within-row
+  a.d = natural_desc(L);
+  a.d.n = (int)n1;
+  a.d.batch = outer * n2 * inner;
+  a.d.mid = n2;
+  a.d.inner = inner;
+  a.d.in_os = n * inner;  a.d.in_ms = inner;  a.d.in_is = 1;  a.d.in_es = n2 * inner;
+  a.d.out_os = n2 * S2;   a.d.out_ms = S2;    a.d.out_is = 1; a.d.out_es = inner;
+  a.d.conj_in = L.inverse ? 1 : 0;
+  a.d.conj_out = 0;
+  a.d.tw_hi = bt.hi;  a.d.tw_lo = bt.lo;  a.d.tw_L = bt.L;  a.d.big_n = n;
+  a.src = L.src;
+  a.dst = BUF_FS;
+  a.logical_first = true;
+  // step 2: length-n2 transforms over i2 (stride S2) for every (o, k1, i); natural output
+  b.d = natural_desc(L);
+  b.d.n = (int)n2;
+  b.d.batch = outer * n1 * inner;
+  b.d.mid = 1;
+  b.d.inner = n1 * inner;
+  b.d.in_os = n2 * S2;   b.d.in_is = 1;  b.d.in_es = S2;
+  b.d.out_os = n * inner; b.d.out_is = 1; b.d.out_es = n1 * inner;
+  b.d.conj_in = 0;
+  b.d.conj_out = L.inverse ? 1 : 0;
+  b.src = BUF_FS;
+  b.dst = L.dst;
+  const int gmax = generic_max_n(prec);
+  for (Pass *q : {&a, &b}) {
+    const int64_t m = q->d.n;
+    if (regk_ok(m, prec)) {
+      q->regk = true;
+      q->cols = true;
+    } else if (!(m <= gmax && factorize(m, &q->f, GENERIC_MAX_PRIME))) {
+      return fail(GFFT_ERR_UNSUPPORTED, "four-step factor not plannable");
+    }
+    rc = get_twiddles(m, prec, &q->d.tw);
+    if (rc) return rc;
+  }
+  need(pl, BUF_FS, (size_t)outer * n2 * S2 * esz);
+  pl->passes.push_back(a);
+  pl->passes.push_back(b);
+  return GFFT_OK;
+}
+
+// Pick n1*n2 = n with both factors plannable in one pass; prefers the register-kernel sizes.
+bool split_fourstep(int64_t n, int prec, int64_t *n1, int64_t *n2) {
+  const int gmax = generic_max_n(prec);
+  if (n >= ((int64_t)1 << 24)) return false;
+  if (is_pow2(n)) {
+    int lg = 0;
+    while (((int64_t)1 << lg) < n) ++lg;
+    *n1 = (int64_t)1 << ((lg + 1) / 2);
+    *n2 = n / *n1;
+    return *n1 <= 4096;
+  }
+  int64_t best = 0;
+  for (int64_t a = (int64_t)std::sqrt((double)n); a >= 2; --a) {
+    if (n % a) continue;
+    const int64_t b = n / a;
+    Factors fa, fb;
+    const bool oka = regk_ok(a, prec) || (a <= gmax && factorize(a, &fa, GENERIC_MAX_PRIME));
+    const bool okb = regk_ok(b, prec) || (b <= gmax && factorize(b, &fb, GENERIC_MAX_PRIME));
+    if (!oka || !okb) continue;
+    if (regk_ok(a, prec) && regk_ok(b, prec)) { best = a; break; }
+    if (!best) best = a;
+  }
+  if (!best) return false;
+  *n1 = n / best;
+  *n2 = best;
+  return true;
+}
+
+// ---- embedding fallbacks: Bluestein, and real transforms beyond the single-pass limit --------
+// Both copy the lines into a complex AUX array [outer][Lw][inner], transform there, and extract.
+//   real-as-complex: Lw = n, the complex engine is whatever plan_line picks for length n
+//   Bluestein      : Lw = M = 2^k >= 2n-1; x_j w_j -> FFT_M -> * B -> IFFT_M -> * w_k / M,
+//                    w_j = exp(-i pi j^2 / n), B = FFT_M(conj chirp, wrapped)
+std::map<std::pair<int64_t, int>, std::pair<void *, void *>> g_blue_cache;   // (n, prec) -> (chirp, B)
+
+void host_fft_pow2(std::vector<long double> &re, std::vector<long double> &im) {
+  const size_t n = re.size();
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+  }
+  const long double PI = 3.14159265358979323846264338327950288L;
+  for (size_t len = 2; len <= n; len <<= 1) {
+    for (size_t k = 0; k < len / 2; ++k) {
+      const long double a = -2.0L * PI * (long double)k / (long double)len;
+      const long double wr = cosl(a), wi = sinl(a);
+      for (size_t i = k; i < n; i += len) {
+        const size_t j = i + len / 2;
+        const long double tr = re[j] * wr - im[j] * wi, ti = re[j] * wi + im[j] * wr;
+        re[j] = re[i] - tr; im[j] = im[i] - ti;
+        re[i] += tr;        im[i] += ti;
+      }
+    }
+  }
+}
+
+int get_bluestein(int64_t n, int64_t M, int prec, const void **chirp, const void **B) {
+  std::lock_guard<std::mutex> lock(g_tw_mutex);
+  auto key = std::make_pair(n, prec);
+  auto it = g_blue_cache.find(key);
+  if (it == g_blue_cache.end()) {
+    const long double PI = 3.14159265358979323846264338327950288L;
+    std::vector<long double> cr(n), ci(n), br(M, 0.0L), bi(M, 0.0L);
+    for (int64_t j = 0; j < n; ++j) {
+      const int64_t q = (j * j) % (2 * n);                  // exact phase reduction
+      const long double a = PI * (long double)q / (long double)n;
+      cr[j] = cosl(a);
+      ci[j] = -sinl(a);                                      // w_j = exp(-i pi j^2 / n)
+      br[j] = cr[j];
+      bi[j] = -ci[j];                                        // b_j = conj(w_j)
+      if (j) { br[M - j] = br[j]; bi[M - j] = bi[j]; }
+    }
+    host_fft_pow2(br, bi);
+    auto upload = [&](const std::vector<long double> &xr, const std::vector<long double> &xi, void **out) -> int {
+      std::vector<unsigned char> h(xr.size() * 2 * prec);
+      for (size_t j = 0; j < xr.size(); ++j) {
+        if (prec == 8) { ((double *)h.data())[2 * j] = (double)xr[j]; ((double *)h.data())[2 * j + 1] = (double)xi[j]; }
+        else { ((float *)h.data())[2 * j] = (float)xr[j]; ((float *)h.data())[2 * j + 1] = (float)xi[j]; }
+      }
+      HIP_TRY(hipMalloc(out, h.size()));
+      HIP_TRY(hipMemcpy(*out, h.data(), h.size(), hipMemcpyHostToDevice));
+      return GFFT_OK;
+    };
+    void *dc = nullptr, *db = nullptr;
+    int rc = upload(cr, ci, &dc);
+    if (rc) return rc;
+    rc = upload(br, bi, &db);
+    if (rc) return rc;
+    it = g_blue_cache.emplace(key, std::make_pair(dc, db)).first;
+  }
+  *chirp = it->second.first;
+  *B = it->second.second;
+  return GFFT_OK;
+}
+
+int plan_embedded(gfft_plan_s *pl, const Line &L, bool bluestein) {
+  const int prec = pl->precision;
+  const int64_t esz = 2 * prec;
+  int64_t Lw = L.n;
+  const void *chirp = nullptr, *B = nullptr;
+  if (bluestein) {
+    Lw = 1;
+    while (Lw < 2 * L.n - 1) Lw <<= 1;
+    if (Lw >= ((int64_t)1 << 24)) return fail(GFFT_ERR_UNSUPPORTED, "transform length too large for Bluestein");
+    int rc = get_bluestein(L.n, Lw, prec, &chirp, &B);
+    if (rc) return rc;
+  }
+  need(pl, BUF_AUX, (size_t)L.outer * Lw * L.inner * esz);
+  PointDesc pt{};
+  pt.outer = L.outer;
+  pt.inner = L.inner;
+  pt.n = L.n;
+  pt.nin = L.nin;
+  pt.nout = L.nout;
+  pt.Lw = Lw;
+  pt.mode = L.mode;
+  pt.chirp = chirp;
+  pt.B = B;
+  Pass e;
+  e.kind = PK_EMBED;
+  e.pt = pt;
+  // inverse transform = conj . forward . conj: the embed conjugates its input.  With Bluestein the
+  // forward machinery runs in between; without it the complex engine does the inverse itself.
+  e.pt.conj = (bluestein && L.inverse) ? 1 : 0;
+  e.src = L.src;
+  e.dst = BUF_AUX;
+  e.logical_first = true;
+  pl->passes.push_back(e);
+  Line C{L.outer, L.inner, Lw, Lw, Lw, MODE_C2C, false, BUF_AUX, BUF_AUX};
+  int rc;
+  if (bluestein) {
+    rc = plan_line(pl, C, false);
+    if (rc) return rc;
+    Pass m;
+    m.kind = PK_MULB;
+    m.pt = pt;
+    m.src = m.dst = BUF_AUX;
+    pl->passes.push_back(m);
+    C.inverse = true;
+    rc = plan_line(pl, C, false);
+    if (rc) return rc;
+  } else {
+    C.inverse = L.inverse;
+    rc = plan_line(pl, C, false);
+    if (rc) return rc;
+  }
+  Pass x;
+  x.kind = PK_EXTRACT;
+  x.pt = pt;
+  x.pt.conj = (bluestein && L.inverse) ? 1 : 0;
+  x.extra_scale = bluestein ? 1.0 / (double)Lw : 1.0;
+  x.src = BUF_AUX;
+  x.dst = L.dst;
+  pl->passes.push_back(x);
+  return GFFT_OK;
+}
+
+int64_t max_prime_factor(int64_t n) {
+  int64_t m = 1;
+  for (int64_t p = 2; p * p <= n; ++p)
+    while (n % p == 0) { m = p; n /= p; }
+  return n > 1 ? n : m;
+}
+
+// Build the kernel passes of one transformed axis.
+int plan_line(gfft_plan_s *pl, const Line &L, bool top) {
+  const int prec = pl->precision;
+  const int64_t n = L.n;
+  const int64_t batch = L.outer * L.inner;
   if (batch >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31))
     return fail(GFFT_ERR_UNSUPPORTED, "batch or length exceeds 2^31");
-  const double lines = (double)batch;
-  pl->flops += (mode == MODE_C2C ? 1.0 : 0.5) * 5.0 * (double)n * std::log2((double)n > 1 ? (double)n : 2.0) * lines * (n > 1 ? 1 : 0);
-  const double esz_in = (mode == MODE_R2C) ? prec : 2.0 * prec;
-  const double esz_out = (mode == MODE_C2R) ? prec : 2.0 * prec;
-  pl->bytes += lines * ((double)nin * esz_in + (double)nout * esz_out);
-
+  if (top) {
+    const double lines = (double)batch;
+    if (n > 1) pl->flops += (L.mode == MODE_C2C ? 1.0 : 0.5) * 5.0 * (double)n * std::log2((double)n) * lines;
+    const double esz_in = (L.mode == MODE_R2C) ? prec : 2.0 * prec;
+    const double esz_out = (L.mode == MODE_C2R) ? prec : 2.0 * prec;
+    pl->bytes += lines * ((double)L.nin * esz_in + (double)L.nout * esz_out);
+  }
   Pass p;
-  p.src = src;
-  p.dst = dst;
-  p.d.n = (int)n;
-  p.d.mode = mode;
-  p.d.conj_in = inverse ? 1 : 0;
-  p.d.conj_out = (inverse && mode != MODE_C2R) ? 1 : 0;
-  p.d.batch = batch;
-  p.d.mid = 1;
-  p.d.inner = inner;
-  p.d.in_os = nin * inner;
-  p.d.in_ms = 0;
-  p.d.in_is = 1;
-  p.d.in_es = inner;
-  p.d.out_os = nout * inner;
-  p.d.out_ms = 0;
-  p.d.out_is = 1;
-  p.d.out_es = inner;
-  p.d.scale = 1.0;
-  p.d.tw_hi = p.d.tw_lo = nullptr;
-  p.d.big_n = 0;
-  p.d.tw_L = 0;
-
+  p.d = natural_desc(L);
+  p.src = L.src;
+  p.dst = L.dst;
+  p.logical_first = true;
   const int gmax = generic_max_n(prec);
-  if (pow2_ok(n, prec)) {
-    p.pow2 = true;
-    p.cols = inner > 1;
+  if (regk_ok(n, prec)) {
+    p.regk = true;
+    p.cols = L.inner > 1;
     int rc = get_twiddles(n, prec, &p.d.tw);
     if (rc) return rc;
     pl->passes.push_back(p);
@@ -268,91 +517,12 @@ int plan_axis(gfft_plan_s *pl, int axis, int mode, bool inverse, const std::vect
     pl->passes.push_back(p);
     return GFFT_OK;
   }
-  // ---- four-step: n = n1 * n2
-  if (mode != MODE_C2C)
-    return fail(GFFT_ERR_UNSUPPORTED, "real transforms longer than the single-pass limit are not planned yet");
-  if (n >= ((int64_t)1 << 24)) return fail(GFFT_ERR_UNSUPPORTED, "transform length >= 2^24");
   int64_t n1 = 0, n2 = 0;
-  if (is_pow2(n)) {
-    int lg = 0;
-    while (((int64_t)1 << lg) < n) ++lg;
-    n1 = (int64_t)1 << ((lg + 1) / 2);
-    n2 = n / n1;
-  } else {
-    for (int64_t a = (int64_t)std::sqrt((double)n); a >= 2; --a)
-      if (n % a == 0) {
-        Factors fa, fb;
-        if (n / a <= gmax && factorize(a, &fa, GENERIC_MAX_PRIME) && factorize(n / a, &fb, GENERIC_MAX_PRIME)) {
-          n1 = n / a;
-          n2 = a;
-          break;
-        }
-      }
-  }
-  if (n1 == 0) return fail(GFFT_ERR_UNSUPPORTED, "length has a prime factor too large for this engine");
-  BigTw bt;
-  int rc = get_bigtw(n, prec, &bt);
-  if (rc) return rc;
-  // The intermediate lives in the plan workspace as tmp[o][i2][k1][i] with the i2-stride S2
-  // padded off the power of two (same channel-aliasing argument as the 3-D workspace).
-  const int64_t esz = 2 * prec;
-  int64_t S2 = n1 * inner;
-  if ((S2 * esz) % 2048 == 0) S2 += 256 / esz;
-  // step 1: length-n1 transforms over i1 (stride n2*inner) for every (o, i2, i); output transposed
-  Pass a = p;
-  a.first_of_fourstep = true;
-  a.d.n = (int)n1;
-  a.d.batch = outer * n2 * inner;
-  a.d.mid = n2;
-  a.d.inner = inner;
-  a.d.in_os = n * inner;
-  a.d.in_ms = inner;
-  a.d.in_is = 1;
-  a.d.in_es = n2 * inner;
-  a.d.out_os = n2 * S2;
-  a.d.out_ms = S2;
-  a.d.out_is = 1;
-  a.d.out_es = inner;
-  a.d.conj_in = inverse ? 1 : 0;
-  a.d.conj_out = 0;
-  a.d.tw_hi = bt.hi;
-  a.d.tw_lo = bt.lo;
-  a.d.tw_L = bt.L;
-  a.d.big_n = n;
-  // step 2: length-n2 transforms over i2 (stride S2) for every (o, k1, i); natural output
-  Pass b = p;
-  b.second_of_fourstep = true;
-  b.d.n = (int)n2;
-  b.d.batch = outer * n1 * inner;
-  b.d.mid = 1;
-  b.d.inner = n1 * inner;
-  b.d.in_os = n2 * S2;
-  b.d.in_is = 1;
-  b.d.in_es = S2;
-  b.d.out_os = n * inner;
-  b.d.out_is = 1;
-  b.d.out_es = n1 * inner;
-  b.d.conj_in = 0;
-  b.d.conj_out = inverse ? 1 : 0;
-  for (Pass *q : {&a, &b}) {
-    const int64_t m = q->d.n;
-    if (pow2_ok(m, prec)) {
-      q->pow2 = true;
-      q->cols = true;
-    } else if (!(m <= gmax && factorize(m, &q->f, GENERIC_MAX_PRIME))) {
-      return fail(GFFT_ERR_UNSUPPORTED, "four-step factor not plannable");
-    }
-    rc = get_twiddles(m, prec, &q->d.tw);
-    if (rc) return rc;
-  }
-  size_t bytes = (size_t)outer * n2 * S2 * esz;
-  if (bytes > pl->need_workspace_bytes) pl->need_workspace_bytes = bytes;
-  pl->has_fourstep = true;
-  pl->passes.push_back(a);
-  pl->passes.push_back(b);
-  return GFFT_OK;
+  const bool splittable = max_prime_factor(n) <= GENERIC_MAX_PRIME && split_fourstep(n, prec, &n1, &n2);
+  if (L.mode == MODE_C2C && splittable) return plan_fourstep(pl, L, n1, n2);
+  if (L.mode != MODE_C2C && splittable) return plan_embedded(pl, L, false);   // real, long, composite
+  return plan_embedded(pl, L, true);                                          // Bluestein
 }
-
 
 // ---- 3-D all-axes plans on one GPU: pass order + padded-pitch workspace --------------------
 // Strided passes over power-of-two pitches alias onto few HBM channels (measured on MI355X,
@@ -369,7 +539,7 @@ bool fused3_applicable(const gfft_plan_s *pl) {
   if (real && pl->axes.back() != 2) return false;
   const std::vector<int64_t> &full = (pl->kind == GFFT_C2R) ? pl->sizes_out : pl->sizes_in;
   for (int i = 0; i < 3; ++i)
-    if (!pow2_ok(full[i], pl->precision)) return false;
+    if (!regk_ok(full[i], pl->precision)) return false;
   const int64_t bytes = full[0] * full[1] * full[2] * (real ? 1 : 2) * pl->precision;
   return bytes >= opts().fused3_min_bytes;
 }
@@ -386,11 +556,12 @@ int plan_fused3(gfft_plan_s *pl) {
   const int64_t seg = 128 / esz;
   int64_t P = (nc + seg - 1) / seg * seg;
   if ((P * esz) % 2048 == 0) P += 256 / esz;
-  pl->need_workspace_bytes = (size_t)(n0 * n1 * P * esz);
+  need(pl, BUF_WS, (size_t)(n0 * n1 * P * esz));
 
   auto base = [&](int n, int mode) {
     Pass p;
-    p.pow2 = true;
+    p.regk = true;
+    p.logical_first = true;
     p.d.n = n;
     p.d.mode = mode;
     p.d.conj_in = inverse ? 1 : 0;
@@ -466,7 +637,11 @@ int plan_fused3(gfft_plan_s *pl) {
   return GFFT_OK;
 }
 
-hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, const void *in, void *out, hipStream_t s) {
+hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, const void *in, void *out,
+                    double scale, hipStream_t s) {
+  if (p.kind == PK_EMBED) return launch_embed(p.pt, pl->precision, in, out, s);
+  if (p.kind == PK_MULB) return launch_mulb(p.pt, pl->precision, out, s);
+  if (p.kind == PK_EXTRACT) return launch_extract(p.pt, pl->precision, in, out, scale * p.extra_scale, s);
   PassDesc d = d0;
   // auto: only where a strided pass writes rows that do not start on 128-byte lines (odd-width
   // half spectra): neighbouring chunks then meet in one L2 and their partial lines merge
@@ -475,10 +650,10 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   const int64_t esz_out = (d.mode == MODE_C2R ? 1 : 2) * (int64_t)pl->precision;
   d.swizzle = pl->xcd_swizzle >= 0 ? pl->xcd_swizzle
                                    : (p.cols && ((d.out_es * esz_out) % 128 != 0) ? 1 : 0);
-  if (p.pow2 && mix3_supported(d.n)) {
+  if (p.regk && mix3_supported(d.n)) {
     return pl->precision == 8 ? launch_mix3_f64(d, p.cols, in, out, s) : launch_mix3_f32(d, p.cols, in, out, s);
   }
-  if (p.pow2) {
+  if (p.regk) {
     const int variant = p.cols ? pl->variant_cols : pl->variant_rows;
     return pl->precision == 8 ? launch_pow2_f64(d, p.cols, variant, in, out, s)
                               : launch_pow2_f32(d, p.cols, variant, in, out, s);
@@ -585,40 +760,49 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
   pl->xcd_swizzle = opts().xcd_swizzle;
 
   rc = GFFT_OK;
+  auto line = [&](int axis, int mode, bool inverse, const std::vector<int64_t> &sin_,
+                  const std::vector<int64_t> &sout_, int src, int dst) {
+    Line L;
+    L.outer = L.inner = 1;
+    for (int i = 0; i < axis; ++i) L.outer *= sin_[i];
+    for (int i = axis + 1; i < ndims; ++i) L.inner *= sin_[i];
+    L.nin = sin_[axis];
+    L.nout = sout_[axis];
+    L.n = (mode == MODE_C2R) ? sout_[axis] : sin_[axis];
+    L.mode = mode;
+    L.inverse = inverse;
+    L.src = src;
+    L.dst = dst;
+    return plan_line(pl, L, true);
+  };
   if (fused3_applicable(pl)) {
     rc = plan_fused3(pl);
   } else if (kind == GFFT_C2C_FORWARD || kind == GFFT_C2C_BACKWARD) {
     const bool inv = kind == GFFT_C2C_BACKWARD;
     for (int i = naxes - 1; i >= 0 && !rc; --i)
-      rc = plan_axis(pl, ax[i], MODE_C2C, inv, pl->sizes_in, pl->sizes_in, i == naxes - 1 ? BUF_IN : BUF_OUT, BUF_OUT);
+      rc = line(ax[i], MODE_C2C, inv, pl->sizes_in, pl->sizes_in, i == naxes - 1 ? BUF_IN : BUF_OUT, BUF_OUT);
   } else if (kind == GFFT_R2C) {
-    rc = plan_axis(pl, last, MODE_R2C, false, pl->sizes_in, pl->sizes_out, BUF_IN, BUF_OUT);
+    rc = line(last, MODE_R2C, false, pl->sizes_in, pl->sizes_out, BUF_IN, BUF_OUT);
     for (int i = naxes - 2; i >= 0 && !rc; --i)
-      rc = plan_axis(pl, ax[i], MODE_C2C, false, pl->sizes_out, pl->sizes_out, BUF_OUT, BUF_OUT);
-  } else {  // C2R: complex passes first (into / inside a workspace: the input is never written,
-            // unlike FFTW's multi-dimensional c2r), then the real pass
+      rc = line(ax[i], MODE_C2C, false, pl->sizes_out, pl->sizes_out, BUF_OUT, BUF_OUT);
+  } else {
+    // C2R: the complex passes run into / inside the WS region, so the caller's input is never
+    // written (FFTW's multi-dimensional c2r destroys it), then the real pass
     for (int i = 0; i <= naxes - 2 && !rc; ++i)
-      rc = plan_axis(pl, ax[i], MODE_C2C, true, pl->sizes_in, pl->sizes_in, i == 0 ? BUF_IN : BUF_WS, BUF_WS);
-    if (!rc) rc = plan_axis(pl, last, MODE_C2R, true, pl->sizes_in, pl->sizes_out, naxes > 1 ? BUF_WS : BUF_IN, BUF_OUT);
+      rc = line(ax[i], MODE_C2C, true, pl->sizes_in, pl->sizes_in, i == 0 ? BUF_IN : BUF_WS, BUF_WS);
+    if (!rc) rc = line(last, MODE_C2R, true, pl->sizes_in, pl->sizes_out, naxes > 1 ? BUF_WS : BUF_IN, BUF_OUT);
     if (naxes > 1) {
       size_t bytes = 2 * (size_t)precision;
       for (int i = 0; i < ndims; ++i) bytes *= (size_t)sizes_in[i];
-      pl->uses_ws = true;
-      pl->c2r_ws_bytes = bytes;
+      need(pl, BUF_WS, bytes);
     }
   }
   if (rc) {
     delete pl;
     return rc;
   }
-  if (pl->uses_ws && !pl->fused3) {
-    // workspace layout: [complex passes of a multi-axis c2r][scratch of an in-place four-step axis]
-    const size_t fs = pl->need_workspace_bytes;
-    pl->fourstep_off = pl->has_fourstep ? pl->c2r_ws_bytes : 0;
-    pl->need_workspace_bytes = pl->c2r_ws_bytes + fs;
-  }
   // the scale factor rides on the last pass
-  pl->passes.back().real_scaled = true;
+  pl->passes.back().carries_scale = true;
   *plan = pl;
   return GFFT_OK;
 }
@@ -628,30 +812,26 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
   if ((pl->kind == GFFT_R2C || pl->kind == GFFT_C2R) && d_in == d_out)
     return fail(GFFT_ERR_INVALID, "in-place real transforms are not supported");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  void *bufs[3] = {const_cast<void *>(d_in), d_out, nullptr};
-  void *ws4 = nullptr;   // second scratch for a four-step axis that runs inside the workspace
-  if (pl->fused3 || pl->uses_ws) {
-    if (pl->workspace_bytes < pl->need_workspace_bytes) {
-      if (pl->workspace) HIP_TRY(hipFree(pl->workspace));
-      pl->workspace = nullptr;
-      pl->workspace_bytes = 0;
-      hipError_t e = hipMalloc(&pl->workspace, pl->need_workspace_bytes);
-      if (e == hipErrorOutOfMemory) return fail(GFFT_ERR_NOMEM, "workspace allocation failed");
-      HIP_TRY(e);
-      pl->workspace_bytes = pl->need_workspace_bytes;
-    }
-    bufs[2] = pl->workspace;
-    if (pl->has_fourstep && pl->uses_ws && !pl->fused3) ws4 = static_cast<char *>(pl->workspace) + pl->fourstep_off;
+  // scratch regions (one allocation, made on first use)
+  size_t off[BUF_COUNT] = {0, 0, 0, 0, 0}, total = 0;
+  for (int b = BUF_WS; b < BUF_COUNT; ++b) {
+    off[b] = total;
+    total += align256(pl->region_bytes[b]);
   }
+  if (total > pl->scratch_bytes) {
+    if (pl->scratch) HIP_TRY(hipFree(pl->scratch));
+    pl->scratch = nullptr;
+    pl->scratch_bytes = 0;
+    hipError_t e = hipMalloc(&pl->scratch, total);
+    if (e == hipErrorOutOfMemory) return fail(GFFT_ERR_NOMEM, "scratch allocation failed");
+    HIP_TRY(e);
+    pl->scratch_bytes = total;
+  }
+  void *bufs[BUF_COUNT] = {const_cast<void *>(d_in), d_out, nullptr, nullptr, nullptr};
+  for (int b = BUF_WS; b < BUF_COUNT; ++b)
+    if (pl->region_bytes[b]) bufs[b] = static_cast<char *>(pl->scratch) + off[b];
+
   std::vector<hipEvent_t> *ev = nullptr;
-  if (opts().profile) {
-    pl->prof.emplace_back();
-    ev = &pl->prof.back();
-    hipEvent_t e0;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventRecord(e0, s));
-    ev->push_back(e0);
-  }
   auto mark = [&]() -> hipError_t {
     if (!ev) return hipSuccess;
     hipEvent_t e;
@@ -661,38 +841,15 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
     ev->push_back(e);
     return rc;
   };
-  for (size_t i = 0; i < pl->passes.size(); ++i) {
-    const Pass &p = pl->passes[i];
+  if (opts().profile) {
+    pl->prof.emplace_back();
+    ev = &pl->prof.back();
+    HIP_TRY(mark());
+  }
+  for (const Pass &p : pl->passes) {
     PassDesc d = p.d;
-    if (p.real_scaled) d.scale = scale;
-    const void *src = bufs[p.src];
-    void *dst = bufs[p.dst];
-    if (p.first_of_fourstep) {
-      // step 1 writes a different layout: never in place
-      const Pass &p2 = pl->passes[i + 1];
-      PassDesc d2 = p2.d;
-      if (p2.real_scaled) d2.scale = scale;
-      void *mid = ws4;
-      if (!mid) {
-        if (pl->workspace_bytes < pl->need_workspace_bytes) {
-          if (pl->workspace) HIP_TRY(hipFree(pl->workspace));
-          pl->workspace = nullptr;
-          pl->workspace_bytes = 0;
-          hipError_t e = hipMalloc(&pl->workspace, pl->need_workspace_bytes);
-          if (e == hipErrorOutOfMemory) return fail(GFFT_ERR_NOMEM, "workspace allocation failed");
-          HIP_TRY(e);
-          pl->workspace_bytes = pl->need_workspace_bytes;
-        }
-        mid = pl->workspace;
-      }
-      HIP_TRY(run_pass(pl, p, d, src, mid, s));
-      HIP_TRY(mark());
-      HIP_TRY(run_pass(pl, p2, d2, mid, dst, s));
-      HIP_TRY(mark());
-      ++i;
-      continue;
-    }
-    HIP_TRY(run_pass(pl, p, d, src, dst, s));
+    if (p.carries_scale) d.scale = scale;
+    HIP_TRY(run_pass(pl, p, d, bufs[p.src], bufs[p.dst], p.carries_scale ? scale : 1.0, s));
     HIP_TRY(mark());
   }
   return GFFT_OK;
@@ -725,7 +882,13 @@ int gfft_plan_profile(gfft_plan pl, float *ms, int max_passes, int *executes) {
 int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *bytes) {
   if (!pl || i < 0 || i >= (int)pl->passes.size()) return fail(GFFT_ERR_INVALID, "bad pass index");
   const Pass &p = pl->passes[i];
-  snprintf(buf, len, "%s n=%d", p.pow2 ? (p.cols ? "pow2-cols" : "pow2-rows") : "generic", p.d.n);
+  static const char *kinds[] = {"", "embed", "mul-B", "extract"};
+  if (p.kind != PK_FFT) {
+    snprintf(buf, len, "%s n=%lld", kinds[p.kind], (long long)p.pt.n);
+    if (bytes) *bytes = 0;
+    return GFFT_OK;
+  }
+  snprintf(buf, len, "%s n=%d", p.regk ? (p.cols ? "pow2-cols" : "pow2-rows") : "generic", p.d.n);
   if (bytes) {
     const double esz = 2.0 * pl->precision;
     const double nc = p.d.mode == MODE_C2C ? p.d.n : p.d.n / 2 + 1;
@@ -738,7 +901,7 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
 
 int gfft_plan_destroy(gfft_plan pl) {
   if (!pl) return GFFT_OK;
-  if (pl->workspace) (void)hipFree(pl->workspace);
+  if (pl->scratch) (void)hipFree(pl->scratch);
   delete pl;
   return GFFT_OK;
 }
@@ -752,12 +915,20 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
   snprintf(line, sizeof line, "gfft plan: %s %s, %d dims, %zu passes%s\n", kn, pl->precision == 8 ? "f64" : "f32",
            pl->ndims, pl->passes.size(), pl->fused3 ? " [3-D schedule: padded-pitch workspace]" : "");
   s += line;
+  static const char *bufn[] = {"IN", "OUT", "WS", "FS", "AUX"};
   for (const Pass &p : pl->passes) {
-    snprintf(line, sizeof line, "  n=%d batch=%lld (mid=%lld inner=%lld) es_in=%lld es_out=%lld kernel=%s%s%s\n", p.d.n,
-             (long long)p.d.batch, (long long)p.d.mid, (long long)p.d.inner, (long long)p.d.in_es,
-             (long long)p.d.out_es, p.pow2 ? (p.cols ? "pow2-cols" : "pow2-rows") : "generic",
-             p.first_of_fourstep ? " [four-step 1/2, fused twiddle]" : p.second_of_fourstep ? " [four-step 2/2]" : "",
-             p.real_scaled ? " [scale]" : "");
+    if (p.kind != PK_FFT) {
+      static const char *kinds[] = {"", "embed (chirp/zero-pad into AUX)", "multiply by B = FFT(chirp)", "extract (chirp, scale)"};
+      snprintf(line, sizeof line, "  %s n=%lld Lw=%lld  %s -> %s\n", kinds[p.kind], (long long)p.pt.n,
+               (long long)p.pt.Lw, bufn[p.src], bufn[p.dst]);
+      s += line;
+      continue;
+    }
+    snprintf(line, sizeof line, "  n=%d batch=%lld (mid=%lld inner=%lld) es_in=%lld es_out=%lld kernel=%s%s%s  %s -> %s\n",
+             p.d.n, (long long)p.d.batch, (long long)p.d.mid, (long long)p.d.inner, (long long)p.d.in_es,
+             (long long)p.d.out_es, p.regk ? (p.cols ? "regs-cols" : "regs-rows") : "generic",
+             p.d.tw_hi ? " [four-step 1/2, fused twiddle]" : "", p.carries_scale ? " [scale]" : "",
+             bufn[p.src], bufn[p.dst]);
     s += line;
   }
   snprintf(buf, len, "%s", s.c_str());

@@ -229,3 +229,32 @@ def test_four_step_mixed_lengths():
     _check((2, 3 * 4096), (1,), 'D')      # 12288 = 96 x 128
     _check((3 * 2048, 2), (0,), 'D')
     _check((2, 9 * 4096), (1,), 'F')
+
+
+@pytest.mark.parametrize('n', [67, 127, 1021, 2042, 2053, 4099, 5003, 3 * 1021])
+def test_bluestein_lengths(n):
+    """Lengths with a large prime factor run through Bluestein (chirp -> FFT_M -> xB -> IFFT_M ->
+    chirp) on the fast kernels; values against the oracle, all kinds."""
+    _check((3, n), (1,), 'D')
+    _check((n, 4), (0,), 'D')
+    _check((2, n), (1,), 'd')
+    _check((n, 3), (0,), 'd')
+    _check((2, n), (1,), 'F')
+
+
+@pytest.mark.parametrize('n', [8192, 6000, 12288, 10000])
+def test_long_real_transforms(n):
+    """r2c / c2r beyond the single-pass limit: complex embedding around the four-step engine."""
+    _check((3, n), (1,), 'd')
+    _check((n, 2), (0,), 'd')
+    _check((2, n), (1,), 'f')
+
+
+def test_plan_description_mentions_engines():
+    from mpi4py_fft_amd import fftw
+    a = fftw.aligned((4, 2053), dtype='D')
+    p = fftw.fftn(a, axes=(1,))
+    d = p._eng.plan_describe(p._plan)
+    assert 'embed' in d and 'multiply by B' in d and 'extract' in d
+    p2 = fftw.fftn(fftw.aligned((4, 16384), dtype='D'), axes=(1,))
+    assert 'four-step' in p2._eng.plan_describe(p2._plan)
