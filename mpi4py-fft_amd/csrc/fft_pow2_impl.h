@@ -139,14 +139,91 @@ template <typename real, int S> __device__ __forceinline__ void dft12(cx<real> *
   for (int k = 0; k < 12; ++k) v[k * S] = o[k];
 }
 
+template <typename real>
+__device__ __forceinline__ void bf5(cx<real> &x0, cx<real> &x1, cx<real> &x2, cx<real> &x3, cx<real> &x4) {
+  const real c1 = (real)0.30901699437494742410229341718282;    // cos(2 pi/5)
+  const real c2 = (real)-0.80901699437494742410229341718282;   // cos(4 pi/5)
+  const real s1 = (real)0.95105651629515357211643933337938;    // sin(2 pi/5)
+  const real s2 = (real)0.58778525229247312916870595463907;    // sin(4 pi/5)
+  const cx<real> t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+  const cx<real> a = {x0.x + c1 * t1.x + c2 * t2.x, x0.y + c1 * t1.y + c2 * t2.y};
+  const cx<real> b = {x0.x + c2 * t1.x + c1 * t2.x, x0.y + c2 * t1.y + c1 * t2.y};
+  const cx<real> s = {s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y};
+  const cx<real> u = {s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y};
+  x0 = x0 + t1 + t2;
+  x1 = {a.x + s.y, a.y - s.x};     // a - i s
+  x4 = {a.x - s.y, a.y + s.x};     // a + i s
+  x2 = {b.x + u.y, b.y - u.x};     // b - i u
+  x3 = {b.x - u.y, b.y + u.x};     // b + i u
+}
+
+template <typename real, int S> __device__ __forceinline__ void dft5(cx<real> *v) {
+  bf5(v[0], v[S], v[2 * S], v[3 * S], v[4 * S]);
+}
+
+// compile-time cos / sin of 2 pi m / 20 for the radix-10/20 internal twiddles
+template <typename real> struct W20 {
+  static constexpr real C[20] = {
+      (real)1.0, (real)0.95105651629515357212, (real)0.80901699437494742410, (real)0.58778525229247312917,
+      (real)0.30901699437494742410, (real)0.0, (real)-0.30901699437494742410, (real)-0.58778525229247312917,
+      (real)-0.80901699437494742410, (real)-0.95105651629515357212, (real)-1.0, (real)-0.95105651629515357212,
+      (real)-0.80901699437494742410, (real)-0.58778525229247312917, (real)-0.30901699437494742410, (real)0.0,
+      (real)0.30901699437494742410, (real)0.58778525229247312917, (real)0.80901699437494742410,
+      (real)0.95105651629515357212};
+  // exp(-2 pi i m / 20) = (C[m], -C[(m + 15) % 20])   since sin(x) = cos(x - pi/2)
+  static __device__ __forceinline__ cx<real> mul(cx<real> a, int m) {
+    const real wx = C[m % 20], wy = -C[(m + 15) % 20];
+    return {a.x * wx - a.y * wy, a.x * wy + a.y * wx};
+  }
+};
+
+template <typename real, int S> __device__ __forceinline__ void dft10(cx<real> *v) {
+  // n = i + 2a (i < 2, a < 5);  X[k1 + 5 k2] = sum_i (-1)^(i k2) W10^(i k1) sum_a x[i + 2a] W5^(a k1)
+  bf5(v[0], v[2 * S], v[4 * S], v[6 * S], v[8 * S]);
+  bf5(v[1 * S], v[3 * S], v[5 * S], v[7 * S], v[9 * S]);
+#pragma unroll
+  for (int k1 = 1; k1 < 5; ++k1) v[(1 + 2 * k1) * S] = W20<real>::mul(v[(1 + 2 * k1) * S], 2 * k1);   // W10^k1
+  cx<real> o[10];
+#pragma unroll
+  for (int k1 = 0; k1 < 5; ++k1) {
+    const cx<real> a = v[(2 * k1) * S], b = v[(2 * k1 + 1) * S];
+    o[k1] = a + b;
+    o[k1 + 5] = a - b;
+  }
+#pragma unroll
+  for (int k = 0; k < 10; ++k) v[k * S] = o[k];
+}
+
+template <typename real, int S> __device__ __forceinline__ void dft20(cx<real> *v) {
+  // n = i + 4a (i < 4, a < 5);  X[k1 + 5 k2] = sum_i W4^(i k2) W20^(i k1) sum_a x[i + 4a] W5^(a k1)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bf5(v[i * S], v[(i + 4) * S], v[(i + 8) * S], v[(i + 12) * S], v[(i + 16) * S]);
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+#pragma unroll
+    for (int k1 = 1; k1 < 5; ++k1) v[(i + 4 * k1) * S] = W20<real>::mul(v[(i + 4 * k1) * S], i * k1);
+#pragma unroll
+  for (int k1 = 0; k1 < 5; ++k1) bf4(v[(4 * k1) * S], v[(4 * k1 + 1) * S], v[(4 * k1 + 2) * S], v[(4 * k1 + 3) * S]);
+  cx<real> o[20];
+#pragma unroll
+  for (int k1 = 0; k1 < 5; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) o[k1 + 5 * k2] = v[(4 * k1 + k2) * S];
+#pragma unroll
+  for (int k = 0; k < 20; ++k) v[k * S] = o[k];
+}
+
 template <typename real, int r, int S> __device__ __forceinline__ void dft(cx<real> *v) {
-  static_assert(r == 2 || r == 3 || r == 4 || r == 8 || r == 12 || r == 16, "radix");
+  static_assert(r == 2 || r == 3 || r == 4 || r == 5 || r == 8 || r == 10 || r == 12 || r == 16 || r == 20, "radix");
   if constexpr (r == 2) dft2<real, S>(v);
   else if constexpr (r == 3) dft3<real, S>(v);
   else if constexpr (r == 4) dft4<real, S>(v);
+  else if constexpr (r == 5) dft5<real, S>(v);
   else if constexpr (r == 8) dft8<real, S>(v);
+  else if constexpr (r == 10) dft10<real, S>(v);
   else if constexpr (r == 12) dft12<real, S>(v);
-  else dft16<real, S>(v);
+  else if constexpr (r == 16) dft16<real, S>(v);
+  else dft20<real, S>(v);
 }
 
 // ---- LDS layout -----------------------------------------------------------------------------
@@ -171,6 +248,35 @@ __device__ __forceinline__ void twiddle(cx<real> *v, int k, const cx<real> *__re
   v[1 * S] = cmul(v[1 * S], w1);
   if constexpr (r == 3) {
     v[2 * S] = cmul(v[2 * S], tw[2 * k * step]);
+  } else if constexpr (r == 5 || r == 10 || r == 20) {
+    // binary bases from the table, the rest composed: w^m = prod over set bits of m
+    const cx<real> w2 = tw[2 * k * step], w4 = tw[4 * k * step];
+    const cx<real> w3 = cmul(w1, w2);
+    v[2 * S] = cmul(v[2 * S], w2);
+    v[3 * S] = cmul(v[3 * S], w3);
+    v[4 * S] = cmul(v[4 * S], w4);
+    if constexpr (r >= 10) {
+      const cx<real> w8 = tw[8 * k * step];
+      v[5 * S] = cmul(v[5 * S], cmul(w1, w4));
+      v[6 * S] = cmul(v[6 * S], cmul(w2, w4));
+      v[7 * S] = cmul(v[7 * S], cmul(w3, w4));
+      v[8 * S] = cmul(v[8 * S], w8);
+      v[9 * S] = cmul(v[9 * S], cmul(w1, w8));
+      if constexpr (r == 20) {
+        const cx<real> w16 = tw[16 * k * step];
+        const cx<real> w12 = cmul(w4, w8);
+        v[10 * S] = cmul(v[10 * S], cmul(w2, w8));
+        v[11 * S] = cmul(v[11 * S], cmul(w3, w8));
+        v[12 * S] = cmul(v[12 * S], w12);
+        v[13 * S] = cmul(v[13 * S], cmul(w1, w12));
+        v[14 * S] = cmul(v[14 * S], cmul(w2, w12));
+        v[15 * S] = cmul(v[15 * S], cmul(w3, w12));
+        v[16 * S] = cmul(v[16 * S], w16);
+        v[17 * S] = cmul(v[17 * S], cmul(w1, w16));
+        v[18 * S] = cmul(v[18 * S], cmul(w2, w16));
+        v[19 * S] = cmul(v[19 * S], cmul(w3, w16));
+      }
+    }
   } else if constexpr (r == 12) {
     const cx<real> w2 = tw[2 * k * step], w4 = tw[4 * k * step], w8 = tw[8 * k * step];
     const cx<real> w3 = cmul(w1, w2);

@@ -77,6 +77,10 @@ int pow2_grid_cap();
 bool mix3_supported(int n);
 hipError_t launch_mix3_f64(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
 hipError_t launch_mix3_f32(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
+// lengths 5^c * 2^k with R = 20 (fft_mix5_*.hip)
+bool mix5_supported(int n);
+hipError_t launch_mix5_f64(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
+hipError_t launch_mix5_f32(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
 
 hipError_t launch_pack(const void *src, void *dst, int64_t outer, int64_t naxis, int64_t inner,
                        int nparts, int itemsize, bool unpack, hipStream_t s);

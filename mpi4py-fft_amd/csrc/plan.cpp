@@ -180,11 +180,11 @@ struct Pass {
 
 bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 
-// lengths served by the register-resident kernels: powers of two 16..4096 and 3^b*2^k 48..3456
+// lengths served by the register-resident kernels: 2^k (16..4096), 3^b 2^k (48..3456), 5^c 2^k (20..4000)
 bool regk_ok(int64_t n, int precision) {
   if (opts().force_generic) return false;
   if (n > 4096) return false;
-  if (mix3_supported((int)n)) return true;
+  if (mix3_supported((int)n) || mix5_supported((int)n)) return true;
   return precision == 8 ? pow2_supported_f64((int)n) : pow2_supported_f32((int)n);
 }
 
@@ -511,13 +511,19 @@ int plan_line(gfft_plan_s *pl, const Line &L, bool top) {
     pl->passes.push_back(p);
     return GFFT_OK;
   }
+  int64_t n1 = 0, n2 = 0;
+  // 2^a 3^b 5^c lengths the single-pass tables miss (960 = 48 x 20, 1920 = 96 x 20, ...): two
+  // register-kernel passes (~2.5 TB/s effective) beat the LDS generic kernel (0.5-1.5 TB/s)
+  if (L.mode == MODE_C2C && n >= 240 && !opts().force_generic) {
+    for (int64_t a = (int64_t)std::sqrt((double)n); a >= 16; --a)
+      if (n % a == 0 && regk_ok(a, prec) && regk_ok(n / a, prec)) return plan_fourstep(pl, L, n / a, a);
+  }
   if (n <= gmax && factorize(n, &p.f, GENERIC_MAX_PRIME)) {
     int rc = get_twiddles(n, prec, &p.d.tw);
     if (rc) return rc;
     pl->passes.push_back(p);
     return GFFT_OK;
   }
-  int64_t n1 = 0, n2 = 0;
   const bool splittable = max_prime_factor(n) <= GENERIC_MAX_PRIME && split_fourstep(n, prec, &n1, &n2);
   if (L.mode == MODE_C2C && splittable) return plan_fourstep(pl, L, n1, n2);
   if (L.mode != MODE_C2C && splittable) return plan_embedded(pl, L, false);   // real, long, composite
@@ -652,6 +658,9 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
                                    : (p.cols && ((d.out_es * esz_out) % 128 != 0) ? 1 : 0);
   if (p.regk && mix3_supported(d.n)) {
     return pl->precision == 8 ? launch_mix3_f64(d, p.cols, in, out, s) : launch_mix3_f32(d, p.cols, in, out, s);
+  }
+  if (p.regk && mix5_supported(d.n)) {
+    return pl->precision == 8 ? launch_mix5_f64(d, p.cols, in, out, s) : launch_mix5_f32(d, p.cols, in, out, s);
   }
   if (p.regk) {
     const int variant = p.cols ? pl->variant_cols : pl->variant_rows;

@@ -258,3 +258,31 @@ def test_plan_description_mentions_engines():
     assert 'embed' in d and 'multiply by B' in d and 'extract' in d
     p2 = fftw.fftn(fftw.aligned((4, 16384), dtype='D'), axes=(1,))
     assert 'four-step' in p2._eng.plan_describe(p2._plan)
+
+
+MIX5 = [20, 40, 80, 100, 160, 200, 320, 400, 500, 640, 800, 1000, 1280, 1600, 2000, 2500, 2560, 3200, 4000]
+
+
+@pytest.mark.parametrize('n', MIX5)
+def test_mix5_rows_and_cols(n):
+    """Lengths 5^c * 2^k on the register-resident kernels (R = 20)."""
+    _check((3, n), (1,), 'D')
+    _check((n, 20), (0,), 'D')
+    _check((2, n, 5), (1,), 'F')
+    _check((3, n), (1,), 'd')
+    _check((n, 6), (0,), 'f')
+
+
+@pytest.mark.parametrize('n', [240, 480, 960, 1920, 3840, 1440, 2880, 720, 3600, 900])
+def test_two_pass_235_lengths(n):
+    """2^a 3^b 5^c lengths outside the single-pass tables: split into two register-kernel passes."""
+    _check((3, n), (1,), 'D')
+    _check((n, 10), (0,), 'D')
+    _check((2, n), (1,), 'd')       # real: generic / embedding
+    _check((2, n, 3), (1,), 'F')
+
+
+@pytest.mark.parametrize('shape,dt', [((100, 80, 160), 'D'), ((200, 40, 100), 'd'), ((1000, 20, 40), 'F'),
+                                      ((320, 200, 400), 'D')])
+def test_mix5_3d(shape, dt):
+    _check(shape, None, dt)
