@@ -11,6 +11,28 @@ namespace gfft {
 
 constexpr int GEN_THREADS = 256;
 
+// radix-P butterfly for a small odd prime, operands and the P roots of unity in registers:
+// P*P constant-index complex multiply-adds instead of the P*P table lookups of the fallback loop
+template <typename real, int P>
+__device__ __forceinline__ void prime_butterfly(const cx<real> *__restrict__ X, cx<real> *__restrict__ Y,
+                                                int j, int j0, int k, int m, int Ns, int tstep, int rstep,
+                                                const cx<real> *__restrict__ tw) {
+  cx<real> x[P], w[P];
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    x[q] = X[j + q * m];
+    if (q && k) x[q] = cmul(x[q], tw[q * k * tstep]);
+    w[q] = tw[q * rstep];
+  }
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    cx<real> acc = x[0];
+#pragma unroll
+    for (int q = 1; q < P; ++q) acc = acc + cmul(x[q], w[(p * q) % P]);
+    Y[j0 + p * Ns] = acc;
+  }
+}
+
 template <typename real>
 __device__ __forceinline__ void generic_butterfly(const cx<real> *__restrict__ X, cx<real> *__restrict__ Y,
                                                   int j, int r, int Ns, int n,
@@ -49,6 +71,14 @@ __device__ __forceinline__ void generic_butterfly(const cx<real> *__restrict__ X
     Y[j0] = a + t1;
     Y[j0 + Ns] = {t2.x + t3.y, t2.y - t3.x};
     Y[j0 + 2 * Ns] = {t2.x - t3.y, t2.y + t3.x};
+  } else if (r == 5) {
+    prime_butterfly<real, 5>(X, Y, j, j0, k, m, Ns, tstep, n / 5, tw);
+  } else if (r == 7) {
+    prime_butterfly<real, 7>(X, Y, j, j0, k, m, Ns, tstep, n / 7, tw);
+  } else if (r == 11) {
+    prime_butterfly<real, 11>(X, Y, j, j0, k, m, Ns, tstep, n / 11, tw);
+  } else if (r == 13) {
+    prime_butterfly<real, 13>(X, Y, j, j0, k, m, Ns, tstep, n / 13, tw);
   } else {
     // y[p] = sum_q x[q] * W_{Ns r}^{q k} * W_r^{p q}
     const int rstep = n / r;
@@ -84,11 +114,11 @@ fft_generic_kernel(PassDesc d, Factors f, int T, const void *__restrict__ in, vo
     const int64_t b0 = tile * T;
     const int ncols = (int)((d.batch - b0) < (int64_t)T ? (d.batch - b0) : (int64_t)T);
     __syncthreads();
-    if (tid < ncols) {
-      ColAddr a = column_address(d, b0 + tid);
-      colbase[tid] = a.in;
-      colbase[T + tid] = a.out;
-      colbase[2 * T + tid] = a.mid;
+    for (int c = tid; c < ncols; c += GEN_THREADS) {
+      ColAddr a = column_address(d, b0 + c);
+      colbase[c] = a.in;
+      colbase[T + c] = a.out;
+      colbase[2 * T + c] = a.mid;
     }
     __syncthreads();
     // ---- load
@@ -146,7 +176,7 @@ template <typename real>
 static hipError_t launch_generic_t(const PassDesc &d, const Factors &f, const void *in, void *out,
                                    hipStream_t s) {
   const size_t esz = sizeof(cx<real>);
-  // columns per tile: aim for ~32 KiB per ping-pong buffer, at least 1, at most 64
+  // columns per tile: aim for ~32 KiB per ping-pong buffer, at least 1, at most 64 (wider tiles measured slower)
   int T = (int)((32 * 1024) / ((size_t)d.n * esz));
   if (T < 1) T = 1;
   if (T > 64) T = 64;

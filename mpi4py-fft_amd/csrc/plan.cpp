@@ -514,9 +514,19 @@ int plan_line(gfft_plan_s *pl, const Line &L, bool top) {
   int64_t n1 = 0, n2 = 0;
   // 2^a 3^b 5^c lengths the single-pass tables miss (960 = 48 x 20, 1920 = 96 x 20, ...): two
   // register-kernel passes (~2.5 TB/s effective) beat the LDS generic kernel (0.5-1.5 TB/s)
+  // ... and lengths with one more small prime (896 = 128 x 7, 1792 = 256 x 7, 1408 = 128 x 11):
+  // a register-kernel pass plus a tiny generic pass.
   if (L.mode == MODE_C2C && n >= 240 && !opts().force_generic) {
-    for (int64_t a = (int64_t)std::sqrt((double)n); a >= 16; --a)
-      if (n % a == 0 && regk_ok(a, prec) && regk_ok(n / a, prec)) return plan_fourstep(pl, L, n / a, a);
+    int64_t both = 0, one = 0;
+    for (int64_t a = (int64_t)std::sqrt((double)n); a >= 2; --a) {
+      if (n % a) continue;
+      const int64_t b = n / a;
+      if (a >= 16 && regk_ok(a, prec) && regk_ok(b, prec)) { both = a; break; }
+      Factors fa;
+      if (!one && a <= 61 && regk_ok(b, prec) && factorize(a, &fa, GENERIC_MAX_PRIME)) one = a;
+    }
+    if (both) return plan_fourstep(pl, L, n / both, both);
+    if (one) return plan_fourstep(pl, L, n / one, one);
   }
   if (n <= gmax && factorize(n, &p.f, GENERIC_MAX_PRIME)) {
     int rc = get_twiddles(n, prec, &p.d.tw);
