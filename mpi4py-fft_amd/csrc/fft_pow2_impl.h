@@ -233,11 +233,16 @@ __host__ __device__ constexpr bool is_pow2_c(int n) { return n > 0 && (n & (n - 
 // compile-time property of N so that pad(a + b) splits into pad(a) + constant (see Stage::run).
 template <bool PAD> __host__ __device__ constexpr int pad_slot(int e) { return PAD ? e + (e >> 4) : e; }
 
-template <int N, bool COLS> struct Lds {
+template <int N, bool COLS, int T> struct Lds {
   static constexpr bool PAD = is_pow2_c(N);
   static constexpr int NP = PAD ? N + N / 16 + 1 : N + 1;
-  // COLS: column stride == 2 (mod 16) words so that 8 adjacent columns x 2 rows cover the banks
-  static constexpr int CS = COLS ? ((NP + 15) / 16) * 16 + 2 : NP;
+  // COLS: lanes run over T adjacent columns first, so the column stride CS (in 8-byte words)
+  // decides the banks.  T <= 8: CS == 2 (mod 16): 8 columns x 2 rows cover the 32 write banks.
+  // T >= 16: CS == 17 (mod 32): 16 columns land on 16 distinct bank pairs for ds_write_b64
+  // (34c mod 32 = 2c) and, with two rows per 32-lane ds_read_b64 group, on 32 distinct pairs of
+  // the 64 read banks.  (With CS == 2 mod 16 the T = 16 kernel measured 48 % of its LDS cycles
+  // as bank conflicts: profiles/r01b_*_pmc_lds.txt.)
+  static constexpr int CS = !COLS ? NP : (T >= 16 ? ((NP + 31) / 32) * 32 + 17 : ((NP + 15) / 16) * 16 + 2);
 };
 
 // multiply v[i + m*S] (m = 1..r-1) by w^(m*k); w = exp(-2 pi i/(Ns*r)); table stride = N/(Ns*r)
@@ -467,7 +472,7 @@ __global__ void __launch_bounds__(T *(N / R), MINW)
 fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
   static_assert(SPLIT || sizeof(real) == 4, "fp64 exchanges split planes");
   constexpr int NT = N / R;
-  constexpr int CS = Lds<N, COLS>::CS;
+  constexpr int CS = Lds<N, COLS, T>::CS;
   constexpr int WORD = SPLIT ? sizeof(real) : 2 * sizeof(real);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const cx<real> *tw = reinterpret_cast<const cx<real> *>(d.tw);
@@ -557,7 +562,7 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   constexpr int NT = N / R;
   constexpr int threads = T * NT;
   static_assert(threads >= 64 && threads <= 1024, "workgroup size");
-  constexpr size_t lds = (sizeof...(RADS) > 1) ? (size_t)T * Lds<N, COLS>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
+  constexpr size_t lds = (sizeof...(RADS) > 1) ? (size_t)T * Lds<N, COLS, T>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = fft_pow2_kernel<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE, BIGTW, RADS...>;
   static bool attr_set = false;
