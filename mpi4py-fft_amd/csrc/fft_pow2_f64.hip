@@ -24,22 +24,22 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
       case 32: return P64(32, 8, 16, false, 1, 8, 4);
       case 64: return P64(64, 8, 8, false, 1, 8, 8);
       case 128: return P64(128, 8, 4, false, 1, 8, 8, 2);
-      case 256: return P64(256, 8, 2, false, 1, 8, 8, 4);
-      case 512: return P64(512, 8, 1, false, 1, 8, 8, 8);
+      case 256: return P64(256, 8, 8, false, 1, 8, 8, 4);
+      case 512: return P64(512, 8, 4, false, 1, 8, 8, 8);
       case 1024:
         switch (variant) {
-          default: return P64(1024, 8, 2, false, 1, 8, 8, 8, 2);
+          default: return P64(1024, 16, 4, false, 1, 16, 16, 4);   // 4 rows / 256 threads, 2 exchanges
           case 1: return P64(1024, 8, 1, false, 1, 8, 8, 8, 2);
           case 2: return P64(1024, 16, 1, false, 1, 16, 16, 4);
-          case 3: return P64(1024, 16, 4, false, 1, 16, 16, 4);
+          case 3: return P64(1024, 8, 2, false, 1, 8, 8, 8, 2);
           case 4: return P64F(1024, 8, 2, false, 1, 3, 8, 8, 8, 2);      // nt loads+stores
           case 5: return P64F(1024, 8, 2, false, 1, 4, 8, 8, 8, 2);      // access pattern only
           case 6: return P64F(1024, 8, 2, false, 1, 7, 8, 8, 8, 2);      // access pattern, nt
           case 7: return P64F(1024, 8, 2, false, 1, 1, 8, 8, 8, 2);      // nt loads
           case 8: return P64F(1024, 8, 2, false, 1, 2, 8, 8, 8, 2);      // nt stores
         }
-      case 2048: return P64(2048, 8, 1, false, 1, 8, 8, 8, 4);
-      case 4096: return P64(4096, 8, 1, false, 1, 8, 8, 8, 8);
+      case 2048: return P64(2048, 16, 2, false, 1, 16, 16, 8);
+      case 4096: return P64(4096, 16, 1, false, 1, 16, 16, 16);
     }
   } else if (d.mode != MODE_C2C || d.tw_hi || d.out_es == 1 || d.in_es == 1) {
     // Strided passes that are not plain c2c column passes -- r2c / c2r along a strided axis

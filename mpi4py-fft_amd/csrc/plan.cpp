@@ -594,15 +594,28 @@ int plan_fused3(gfft_plan_s *pl) {
   // strides on both its sides, and the pass that touches the user's natural array does so along
   // axis 1, the near axis of the natural layout (measured: near pad->pad 7.2 ms, far 7.9 ms).
   const int64_t w_i0 = P, w_i1 = n0 * P;
-  // rows: transform along axis 2; batch (o = i0, i = i1); strides in elements of each side's type
+  // rows: transform along axis 2.  The batch runs fastest along whichever of (i0, i1) makes the
+  // rows it READS consecutive in memory (reading scattered 16-KiB rows measured 6.7 ms per pass,
+  // writing them scattered 5.8 ms): forward reads the natural array -> i1 fastest; backward
+  // reads W[i1][i0][c] -> i0 fastest.  Strides are in elements of each side's own type.
   auto rows = [&](int mode, bool in_ws, bool out_ws, int src, int dst) {
     Pass p = base((int)n2, mode);
     p.cols = false;
     p.d.batch = n0 * n1;
-    p.d.inner = n1;
     const int64_t nat_in = (mode == MODE_R2C) ? n2 : nc, nat_out = (mode == MODE_C2R) ? n2 : nc;
-    p.d.in_os = in_ws ? w_i0 : n1 * nat_in;   p.d.in_is = in_ws ? w_i1 : nat_in;   p.d.in_es = 1;
-    p.d.out_os = out_ws ? w_i0 : n1 * nat_out; p.d.out_is = out_ws ? w_i1 : nat_out; p.d.out_es = 1;
+    const int64_t in_i0 = in_ws ? w_i0 : n1 * nat_in, in_i1 = in_ws ? w_i1 : nat_in;
+    const int64_t out_i0 = out_ws ? w_i0 : n1 * nat_out, out_i1 = out_ws ? w_i1 : nat_out;
+    if (!in_ws) {   // o = i0, i = i1
+      p.d.inner = n1;
+      p.d.in_os = in_i0;   p.d.in_is = in_i1;
+      p.d.out_os = out_i0; p.d.out_is = out_i1;
+    } else {        // o = i1, i = i0
+      p.d.inner = n0;
+      p.d.in_os = in_i1;   p.d.in_is = in_i0;
+      p.d.out_os = out_i1; p.d.out_is = out_i0;
+    }
+    p.d.in_es = 1;
+    p.d.out_es = 1;
     p.src = src; p.dst = dst;
     return p;
   };
