@@ -68,6 +68,12 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
  * input; C2R with naxes > 1 overwrites it (as FFTW does).  */
 int gfft_execute(gfft_plan plan, const void *d_in, void *d_out, double scale, void *stream);
 int gfft_plan_destroy(gfft_plan plan);
+/* Fuse FFTBase._truncation_forward / _padding_backward (libfft.py:263-311) into a single-axis plan:
+ * afterwards gfft_execute writes (forward kinds) / reads (backward kinds) the TRUNCATED array,
+ * n_keep entries along the axis (N on a complex axis, N/2+1 on the real half-axis), with the
+ * reference's Nyquist rules.  GFFT_ERR_UNSUPPORTED = not fusable for this plan (use
+ * gfft_truncate / gfft_pad); the plan is left unchanged. */
+int gfft_plan_set_truncation(gfft_plan plan, int64_t n_keep);
 int gfft_plan_describe(gfft_plan plan, char *buf, size_t len);
 /* flops (5 n log2 n per line, half for real) and algorithmic bytes (one read + one write of
  * the array per 1-D pass) of one execute, and the number of kernel launches it issues */

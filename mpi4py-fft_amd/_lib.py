@@ -38,6 +38,7 @@ def _declare(lib):
         'gfft_plan_create': (c.c_int, [c.POINTER(vp), c.c_int, i64p, i64p, c.c_int, ip, c.c_int, c.c_int]),
         'gfft_execute': (c.c_int, [vp, vp, vp, c.c_double, vp]),
         'gfft_plan_destroy': (c.c_int, [vp]),
+        'gfft_plan_set_truncation': (c.c_int, [vp, c.c_int64]),
         'gfft_plan_describe': (c.c_int, [vp, c.c_char_p, c.c_size_t]),
         'gfft_plan_cost': (c.c_int, [vp, c.POINTER(c.c_double), c.POINTER(c.c_double), ip]),
         'gfft_pack': (c.c_int, [vp, vp, c.c_int, i64p, c.c_int, c.c_int, c.c_int, vp]),
@@ -125,6 +126,14 @@ class HipEngine:
         self.require_device(tin)
         self.require_device(tout)
         check(lib().gfft_execute(h, tin.data_ptr(), tout.data_ptr(), float(scale), current_stream()))
+
+    def plan_set_truncation(self, h, n_keep):
+        """True if the truncation/padding was fused into the plan, False if it cannot be."""
+        rc = lib().gfft_plan_set_truncation(h, int(n_keep))
+        if rc == -2:
+            return False
+        check(rc)
+        return True
 
     def plan_destroy(self, h):
         if h is not None and _lib is not None:

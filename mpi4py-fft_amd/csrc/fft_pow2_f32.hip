@@ -25,7 +25,7 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 2048: return P32(2048, 16, 1, false, false, 1, 16, 16, 8);
       case 4096: return P32(4096, 16, 1, false, false, 1, 16, 16, 16);
     }
-  } else if (d.mode != MODE_C2C || d.tw_hi || d.out_es == 1 || d.in_es == 1) {
+  } else if (d.mode != MODE_C2C || d.tw_hi || d.tr_dir || d.out_es == 1 || d.in_es == 1) {
     // real modes along a strided axis and the four-step passes: lean R = 8 plans
     switch (d.n) {
       case 16: return P32(16, 4, 16, true, false, 1, 4, 4);

@@ -41,7 +41,7 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
       case 2048: return P64(2048, 16, 2, false, 1, 16, 16, 8);
       case 4096: return P64(4096, 16, 1, false, 1, 16, 16, 16);
     }
-  } else if (d.mode != MODE_C2C || d.tw_hi || d.out_es == 1 || d.in_es == 1) {
+  } else if (d.mode != MODE_C2C || d.tw_hi || d.tr_dir || d.out_es == 1 || d.in_es == 1) {
     // Strided passes that are not plain c2c column passes -- r2c / c2r along a strided axis
     // (halved axis is not the array's last axis) and the four-step passes (fused big twiddle,
     // transposed store) -- take the register-lean R = 8 plans with 128-byte segments.

@@ -466,7 +466,56 @@ __device__ __forceinline__ void tile_store(const PassDesc &d, void *__restrict__
   }
 }
 
-// FLAGS: 1 = non-temporal loads, 2 = non-temporal stores, 4 = skip the transform (access-pattern probe)
+// ---- fused 3/2-rule truncation (store side, forward) and zero-padding (load side, backward) ----
+// libfft.py:263-311 as load/store adapters: the padded transform of length n reads from / writes
+// to the TRUNCATED array directly (d.tr_n entries along the axis), so the separate strided copies
+// of the reference (and the full-size padded spectrum) disappear.  d.tr_N = truncated logical
+// length (complex axis; for the real half-axis tr_N = tr_n), d.tr_even = the reference's parity
+// rule (`N0 % 2 == 0`) applies.
+template <typename real, int MODE>
+__device__ __forceinline__ cx<real> tile_load_pad(const PassDesc &d, const void *__restrict__ in,
+                                                  int64_t base, int e, real sy) {
+  cx<real> v = {0, 0};
+  const cx<real> *p = reinterpret_cast<const cx<real> *>(in) + base;
+  if constexpr (MODE == MODE_C2R) {
+    const bool mirror = e > (d.n >> 1);
+    const int ee = mirror ? d.n - e : e;
+    if (ee < d.tr_n) {
+      v = p[(int64_t)ee * d.in_es];
+      if (d.tr_even && ee == d.tr_n - 1) { v.x *= (real)0.5; v.y = 0; }
+    }
+    v.y *= mirror ? -sy : sy;
+  } else {
+    const int h = d.tr_N >> 1;
+    const bool lo = e <= h, hi = h > 0 && e >= d.n - h;
+    if (lo || hi) {
+      v = p[(int64_t)(lo ? e : e - (d.n - d.tr_N)) * d.in_es];
+      if (d.tr_even && (e == h || e == d.n - h)) { v.x *= (real)0.5; v.y *= (real)0.5; }
+    }
+    v.y *= sy;
+  }
+  return v;
+}
+
+template <typename real, int MODE>
+__device__ __forceinline__ void tile_store_trunc(const PassDesc &d, void *__restrict__ out, int64_t base,
+                                                 int e, cx<real> v, real sx, real sy) {
+  cx<real> *p = reinterpret_cast<cx<real> *>(out) + base;
+  if constexpr (MODE == MODE_R2C) {
+    if (e < d.tr_n) {
+      if (d.tr_even && e == d.tr_n - 1) { v.x *= 2; v.y = 0; }
+      p[(int64_t)e * d.out_es] = {v.x * sx, v.y * sy};
+    }
+  } else {
+    const int h = d.tr_N >> 1;
+    const bool lo = e <= h, hi = h > 0 && e >= d.n - h;
+    if (d.tr_even && e == d.n - h) return;            // folded onto entry h by the kernel body
+    if (lo || hi) p[(int64_t)(lo ? e : e - (d.n - d.tr_N)) * d.out_es] = {v.x * sx, v.y * sy};
+  }
+}
+
+// FLAGS: 1 = non-temporal loads, 2 = non-temporal stores, 4 = skip the transform (access-pattern
+// probe), 8 = c2c only, 16 = fused truncation / padding adapters (d.tr_dir: 1 store, 2 load)
 template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int MODE, bool BIGTW, int... RADS>
 __global__ void __launch_bounds__(T *(N / R), MINW)
 fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
@@ -531,7 +580,12 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
       int64_t idx = in0 + t_in;
 #pragma unroll
       for (int q = 0; q < R; ++q) {
-        v[q] = tile_load<real, MODE, (FLAGS & 1) != 0>(d, in, in0, idx, t + q * NT, sy_in);
+        if constexpr ((FLAGS & 16) != 0) {
+          v[q] = d.tr_dir == 2 ? tile_load_pad<real, MODE>(d, in, in0, t + q * NT, sy_in)
+                               : tile_load<real, MODE, false>(d, in, in0, idx, t + q * NT, sy_in);
+        } else {
+          v[q] = tile_load<real, MODE, (FLAGS & 1) != 0>(d, in, in0, idx, t + q * NT, sy_in);
+        }
         idx += q_in;
       }
     } else {
@@ -544,11 +598,33 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     const cx<real> *twl = tw;
     asm volatile("" : "+s"(twl));
     if constexpr (!(FLAGS & 4)) Stage<real, N, R, SPLIT, 1, RADS...>::run(v, t, col, twl);
+    if constexpr ((FLAGS & 16) != 0 && MODE == MODE_C2C) {
+      // complex truncation with even N: entries h = N/2 and n - h of the padded spectrum both land
+      // on truncated entry h (libfft.py:281-284).  They live in different threads: pass the upper
+      // one through LDS.  (uniform branch: every thread of the workgroup takes it or none does)
+      if (d.tr_dir == 1 && d.tr_even) {
+        cx<real> *fold = reinterpret_cast<cx<real> *>(smem);
+        const int h = d.tr_N >> 1;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+          if (t + q * NT == d.n - h) fold[c] = v[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+          if (t + q * NT == h) v[q] = v[q] + fold[c];
+      }
+    }
     if (valid) {
       int64_t idx = out0 + t_out;
 #pragma unroll
       for (int q = 0; q < R; ++q) {
-        tile_store<real, MODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, t + q * NT, m, v[q], sx_out, sy_out);
+        if constexpr ((FLAGS & 16) != 0) {
+          if (d.tr_dir == 1) tile_store_trunc<real, MODE>(d, out, out0, t + q * NT, v[q], sx_out, sy_out);
+          else tile_store<real, MODE, false, false>(d, out, idx, t + q * NT, m, v[q], sx_out, sy_out);
+        } else {
+          tile_store<real, MODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, t + q * NT, m, v[q], sx_out, sy_out);
+        }
         idx += q_out;
       }
     }
@@ -562,7 +638,9 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   constexpr int NT = N / R;
   constexpr int threads = T * NT;
   static_assert(threads >= 64 && threads <= 1024, "workgroup size");
-  constexpr size_t lds = (sizeof...(RADS) > 1) ? (size_t)T * Lds<N, COLS, T>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
+  constexpr size_t lds_x = (sizeof...(RADS) > 1) ? (size_t)T * Lds<N, COLS, T>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
+  constexpr size_t lds_f = (FLAGS & 16) ? (size_t)T * 2 * sizeof(real) : 0;
+  constexpr size_t lds = lds_x > lds_f ? lds_x : lds_f;
   static_assert(lds <= 160 * 1024, "LDS budget");
   auto kern = fft_pow2_kernel<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE, BIGTW, RADS...>;
   static bool attr_set = false;
@@ -596,8 +674,14 @@ hipError_t launch_pow2_inst(const PassDesc &d, const void *in, void *out, hipStr
     }
   }
   if constexpr (FLAGS != 0) {
-    if (d.mode != MODE_C2C) return hipErrorInvalidValue;
+    if (d.mode != MODE_C2C || d.tr_dir) return hipErrorInvalidValue;
     return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, false, RADS...>(d, in, out, s);
+  } else {
+    if (d.tr_dir == 1 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2C, false, RADS...>(d, in, out, s);
+    if (d.tr_dir == 1 && d.mode == MODE_R2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_R2C, false, RADS...>(d, in, out, s);
+    if (d.tr_dir == 2 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2C, false, RADS...>(d, in, out, s);
+    if (d.tr_dir == 2 && d.mode == MODE_C2R) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2R, false, RADS...>(d, in, out, s);
+    if (d.tr_dir) return hipErrorInvalidValue;
   }
   switch (d.mode) {
     case MODE_C2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, false, RADS...>(d, in, out, s);

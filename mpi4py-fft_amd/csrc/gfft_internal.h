@@ -29,6 +29,8 @@ struct PassDesc {
   int conj_in;    // conjugate on load   (inverse transform = conj . forward . conj)
   int conj_out;   // conjugate on store
   int swizzle;    // XCD-contiguous tile order (speed only)
+  // fused 3/2-rule adapters (register kernels): 0 none, 1 truncate on store, 2 zero-pad on load
+  int tr_dir, tr_n, tr_N, tr_even;
   int64_t batch;  // number of columns = outer * mid * inner
   int64_t mid, inner;
   int64_t in_os, in_ms, in_is, in_es;

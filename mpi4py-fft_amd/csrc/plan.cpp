@@ -931,6 +931,43 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
   return GFFT_OK;
 }
 
+/* Fuse the 3/2-rule truncation (forward kinds) or zero-padding (backward kinds) of
+ * libfft.py:263-311 into a single-axis plan: the truncated array (n_keep entries along the axis:
+ * N for a complex axis, N/2+1 for the real half-axis) becomes the plan's output (input).
+ * Returns GFFT_ERR_UNSUPPORTED, leaving the plan unchanged, when the plan is not one
+ * register-kernel pass (the caller then uses gfft_truncate / gfft_pad). */
+int gfft_plan_set_truncation(gfft_plan pl, int64_t n_keep) {
+  if (!pl) return fail(GFFT_ERR_INVALID, "null plan");
+  if (pl->passes.size() != 1 || pl->axes.size() != 1 || pl->fused3)
+    return fail(GFFT_ERR_UNSUPPORTED, "truncation fuses into single-pass plans only");
+  Pass &p = pl->passes[0];
+  if (p.kind != PK_FFT || !p.regk || p.d.mid != 1 || p.d.tw_hi)
+    return fail(GFFT_ERR_UNSUPPORTED, "truncation fuses into register-kernel passes only");
+  const int axis = pl->axes[0];
+  const bool fwd = pl->kind == GFFT_C2C_FORWARD || pl->kind == GFFT_R2C;
+  const bool real = pl->kind == GFFT_R2C || pl->kind == GFFT_C2R;
+  const int64_t full = real ? p.d.n / 2 + 1 : p.d.n;
+  if (n_keep < 1 || n_keep > full) return fail(GFFT_ERR_INVALID, "bad truncated length");
+  int64_t inner = 1;
+  for (int i = axis + 1; i < pl->ndims; ++i) inner *= pl->sizes_in[i];
+  const double esz = 2.0 * pl->precision;
+  const double lines = (double)p.d.batch;
+  if (fwd) {
+    p.d.tr_dir = 1;
+    p.d.out_os = n_keep * inner;
+    pl->bytes -= lines * (double)full * esz;
+  } else {
+    p.d.tr_dir = 2;
+    p.d.in_os = n_keep * inner;
+    pl->bytes -= lines * (double)full * esz;
+  }
+  pl->bytes += lines * (double)n_keep * esz;
+  p.d.tr_n = (int)n_keep;
+  p.d.tr_N = (int)n_keep;
+  p.d.tr_even = (n_keep % 2 == 0) ? 1 : 0;
+  return GFFT_OK;
+}
+
 int gfft_plan_destroy(gfft_plan pl) {
   if (!pl) return GFFT_OK;
   if (pl->scratch) (void)hipFree(pl->scratch);

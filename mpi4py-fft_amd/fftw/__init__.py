@@ -98,6 +98,11 @@ class FFT:
         """Per-pass (family, algorithmic bytes/launch, total ms, launches) since the last call."""
         return self._eng.plan_profile(self._plan, self.cost()[2])
 
+    def set_truncation(self, n_keep):
+        """Fuse the 3/2-rule truncation (forward kinds) / zero padding (backward kinds) into this
+        single-axis plan; returns False when the engine cannot (see gfft_plan_set_truncation)."""
+        return self._eng.plan_set_truncation(self._plan, n_keep)
+
     def update_arrays(self, input_array, output_array):
         assert self.input_shape == tuple(input_array.shape)
         assert self.input_strides == input_array.strides
@@ -154,7 +159,8 @@ def get_planned_FFT(input_array, output_array, axes=(-1,), kind=FFTW_FORWARD, th
 
 
 def _check_in(a):
-    assert isinstance(a, DeviceArray), 'planner functions take device arrays (see fftw.aligned)'
+    assert isinstance(a, DeviceArray) or all(hasattr(a, k) for k in ('shape', 'dtype', 'strides')), \
+        'planner functions take device arrays (see fftw.aligned)'
 
 
 def fftn(input_array, s=None, axes=(-1,), threads=1, flags=(FFTW_MEASURE,), output_array=None):

@@ -40,6 +40,18 @@ class _Xfftn_wrap:
         return self._output_array
 
 
+class _ShapeOnly:
+    """Stand-in for an array that is only planned against (shape / dtype / strides), never touched."""
+    def __init__(self, shape, dtype):
+        self.shape = tuple(int(n) for n in shape)
+        self.dtype = np.dtype(dtype)
+        st, acc = [], self.dtype.itemsize
+        for n in reversed(self.shape):
+            st.insert(0, acc)
+            acc *= n
+        self.strides = tuple(st)
+
+
 class FFTBase:
     """Argument normalisation shared by serial transforms (libfft.py:221-261)."""
     def __init__(self, shape, axes=None, dtype=float, padding=False):
@@ -100,19 +112,39 @@ class FFT(FFTBase):
             U = fftw.aligned(self.shape, dtype=self.dtype)
             U.fill(0)
         assert tuple(U.shape) == tuple(self.shape) and U.dtype == self.dtype
-        self.fwd = plan_fwd(U, s=s, axes=self.axes, output_array=V)
-        V = self.fwd.output_array
-        self.bck = plan_bck(V, s=s, axes=self.axes, output_array=U)
-        self.M = self.fwd.get_normalization()
         self.padding_factor = 1.0
         if padding is not False:
             self.padding_factor = padding[self.axes[-1]] if np.ndim(padding) else padding
-        if abs(self.padding_factor - 1.0) > 1e-8:
+        self._fused_trunc = False
+        if self._padded:
             assert len(self.axes) == 1
-            trunc_array = self._get_truncarray(shape, V.dtype)
+            cdtype = np.dtype(self.dtype.char.upper())
+            trunc_array = self._get_truncarray(shape, cdtype)
+            n_keep = trunc_array.shape[self.axes[-1]]
+            # plan against the full-size spectrum's SHAPE only; if the engine fuses truncation and
+            # padding into the transform, that array never exists
+            full = list(self.shape)
+            if self.real_transform:
+                full[self.axes[-1]] = full[self.axes[-1]] // 2 + 1
+            ghost = _ShapeOnly(full, cdtype)
+            self.fwd = plan_fwd(U, s=s, axes=self.axes, output_array=ghost)
+            self.bck = plan_bck(ghost, s=s, axes=self.axes, output_array=U)
+            if self.fwd.set_truncation(n_keep) and self.bck.set_truncation(n_keep):
+                self._fused_trunc = True
+            else:
+                self.fwd.destroy()
+                self.bck.destroy()
+                self.fwd = plan_fwd(U, s=s, axes=self.axes, output_array=V)
+                V = self.fwd.output_array
+                self.bck = plan_bck(V, s=s, axes=self.axes, output_array=U)
+            self.M = self.fwd.get_normalization()
             self.forward = _Xfftn_wrap(self._forward, U, trunc_array)
             self.backward = _Xfftn_wrap(self._backward, trunc_array, U)
         else:
+            self.fwd = plan_fwd(U, s=s, axes=self.axes, output_array=V)
+            V = self.fwd.output_array
+            self.bck = plan_bck(V, s=s, axes=self.axes, output_array=U)
+            self.M = self.fwd.get_normalization()
             self.forward = _Xfftn_wrap(self._forward, U, V)
             self.backward = _Xfftn_wrap(self._backward, V, U)
 
@@ -127,7 +159,9 @@ class FFT(FFTBase):
         src = kw.pop('src', None)
         src = self.fwd.input_array if src is None else src
         scale = self.M if normalize else 1.0
-        if not self._padded:
+        if self._fused_trunc:
+            self.fwd.execute_scaled(src, self.forward.output_array, scale)
+        elif not self._padded:
             self.fwd.execute_scaled(src, self.fwd.output_array, scale)
         else:
             self.fwd.execute_scaled(src, self.fwd.output_array, 1.0)
@@ -137,6 +171,10 @@ class FFT(FFTBase):
     def _backward(self, **kw):
         normalize = kw.pop('normalize', False)
         src = kw.pop('src', None)
+        if self._fused_trunc:
+            self.bck.execute_scaled(self.backward.input_array if src is None else src,
+                                    self.bck.output_array, self.M if normalize else 1.0)
+            return self.backward.output_array
         if self._padded:
             self._padding_backward(self.backward.input_array if src is None else src, self.bck.input_array)
             src = None

@@ -286,3 +286,47 @@ def test_two_pass_235_lengths(n):
                                       ((320, 200, 400), 'D')])
 def test_mix5_3d(shape, dt):
     _check(shape, None, dt)
+
+
+@pytest.mark.parametrize('dt', ['D', 'd', 'F', 'f'])
+def test_fused_truncation_and_padding(dt):
+    """3/2-rule truncation / zero padding fused into the transform (gfft_plan_set_truncation) on
+    register-kernel lengths: values vs the oracle, even and odd truncated lengths, contiguous and
+    strided axes, and the fwd.bwd.fwd idempotence of tests/test_libfft.py:67-98."""
+    from mpi4py_fft_amd import FFT, asdevice
+    cases_ = [((48, 10), 0, 1.5), ((10, 48), 1, 1.5), ((6, 96, 5), 1, 1.5), ((64, 7), 0, 2.0),
+              ((5, 192), 1, 1.5), ((48, 6), 0, 48 / 31.), ((4, 80), 1, 80 / 63.), ((1536, 3), 0, 1.5),
+              ((3, 1536), 1, 1.5), ((100, 4), 0, 2.0), ((3, 768, 4), 1, 1.5), ((1024, 2), 0, 2.0)]
+    for shp, axis, padding in cases_:
+        fft = FFT(shp, axis, dtype=dt, padding=padding)
+        assert fft._fused_trunc, (shp, axis, padding)
+        ref = O.OFFT(shp, axis, dt, padding=padding)
+        A = O.rng_array(shp, dt, 21)
+        B = np.asarray(fft.forward(asdevice(A))).copy()
+        Bref = ref.forward(A)
+        tol = _tol(dt)
+        assert B.shape == Bref.shape and B.dtype == Bref.dtype
+        assert np.abs(B - Bref).max() <= tol * np.abs(Bref).max(), (shp, axis, padding, dt)
+        A1 = np.asarray(fft.backward(asdevice(Bref))).copy()
+        assert np.abs(A1 - ref.backward(Bref)).max() <= 10 * tol * np.abs(A).max(), (shp, axis, padding, dt)
+        B2 = np.asarray(fft.forward(asdevice(A1)))
+        assert np.abs(B2 - B).max() <= 10 * tol * np.abs(B).max()
+        fft.destroy()
+
+
+def test_padded_pfft_uses_fused_truncation():
+    from mpi4py_fft_amd import PFFT, newDistArray, comm
+    shape = (32, 64, 128)
+    for dt in 'dD':
+        fft = PFFT(comm.COMM_SELF, shape, dtype=dt, padding=[1.5, 1.5, 1.5])
+        assert all(x._fused_trunc for x in fft.xfftn)
+        ref = O.OPFFT(1, shape, dtype=dt, padding=[1.5, 1.5, 1.5])
+        G = O.rng_array(ref.input_shape, dt, 5)
+        u = newDistArray(fft, False)
+        u[...] = G
+        uh = np.asarray(fft.forward(u)).copy()
+        want = ref.forward([G])[0]
+        assert np.abs(uh - want).max() <= 2e-10 * np.abs(want).max()
+        back = np.asarray(fft.backward())
+        assert np.abs(back - ref.backward([want])[0]).max() <= 1e-10 * max(1, np.abs(G).max())
+        fft.destroy()

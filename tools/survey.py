@@ -69,6 +69,8 @@ pfft_case('    PFFT 384^3 c128', (384,) * 3, 'D')
 pfft_case('    PFFT 768^3 r2c f64', (768,) * 3, 'd')
 pfft_case('    PFFT 1536x768x768 c128', (1536, 768, 768), 'D')
 pfft_case('    PFFT 512^3 r2c f64 padded 1.5 (-> 768^3)', (512,) * 3, 'd', padding=[1.5, 1.5, 1.5])
+pfft_case('    PFFT 512^3 c128 padded 1.5 (-> 768^3)', (512,) * 3, 'D', padding=[1.5, 1.5, 1.5])
+pfft_case('    PFFT 1024x512x512 r2c f32 padded 1.5', (1024, 512, 512), 'f', padding=[1.5, 1.5, 1.5])
 pfft_case('    PFFT 1152^3 c64', (1152,) * 3, 'F')
 pfft_case('    PFFT 1000^3 c64 (R=20 kernels)', (1000,) * 3, 'F')
 pfft_case('    PFFT 1000^3 c128', (1000,) * 3, 'D')
