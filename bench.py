@@ -182,8 +182,8 @@ def main():
                                        'sample': 'failed: %r' % (e,)}
         print(json.dumps(out), flush=True)
     world.barrier()
-    if size > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

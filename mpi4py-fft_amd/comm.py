@@ -255,7 +255,8 @@ def init_distributed(backend=None):
     import torch.distributed as dist
     if not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            # GFFT_DIST_BACKEND=gloo lets several ranks share one GPU (development boxes)
+            backend = os.environ.get('GFFT_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

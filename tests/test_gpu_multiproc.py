@@ -1,0 +1,18 @@
+"""Real multi-process PFFT on one GPU (gloo carrying device tensors): see gpu_multiproc_worker.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('nranks,port', [(2, 29551), (4, 29552)])
+def test_pfft_across_processes_on_one_gpu(nranks, port):
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nranks),
+           '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(ROOT, 'tests', 'gpu_multiproc_worker.py')]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, text=True)
+    assert res.returncode == 0 and 'GPU_MULTIPROC_OK ranks=%d' % nranks in res.stdout, res.stdout[-4000:]
