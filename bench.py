@@ -69,7 +69,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--n', type=int, default=1024, help='cube edge (default: the BASELINE config)')
+    ap.add_argument('--size', dest='n', type=int, default=1024, help='cube edge (default: the BASELINE config)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     args = ap.parse_args()
 
