@@ -169,6 +169,10 @@ def main():
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'PFFT 3D c2c %d^3 complex128 forward+backward per step' % n,
                        'grid': [c.Get_size() for c in fft.subcomm],
+                       'exchange': [dict(ranks=t.comm.Get_size(), route=t.exchange,
+                                         **({'measured_s': [round(x, 5) for x in t.route_times]}
+                                            if hasattr(t, 'route_times') else {}))
+                                    for t in fft.transfer if t.comm.Get_size() > 1],
                        'round_trip_rel_err': rt_err},
             'whole_transform_hbm': whole,
             'roofline': roofline,

@@ -94,6 +94,17 @@ class Comm:
         block j of `recv` (recv_counts[j] elements) comes from rank j.  1-D real-typed tensors."""
         raise NotImplementedError
 
+    # the communicator a Cartesian sub-communicator was cut from (None for anything else): the
+    # relayed exchange of relay.py borrows its idle links
+    relay_parent = None
+    backend = None
+
+    def p2p(self, sends, recvs):
+        """One batch of point-to-point messages: sends / recvs = [(1-D tensor, peer rank)].
+        Messages between two ranks match in list order.  Returns when the batch is complete
+        (stream-ordered on the nccl backend)."""
+        raise NotImplementedError
+
 
 class SelfComm(Comm):
     _count = itertools.count()
@@ -115,6 +126,9 @@ class SelfComm(Comm):
 
     def alltoall(self, send, recv, send_counts, recv_counts):
         recv.copy_(send)
+
+    def p2p(self, sends, recvs):
+        assert not sends and not recvs
 
 
 COMM_SELF = SelfComm()
@@ -181,6 +195,27 @@ class TorchComm(Comm):
         self._dist.all_to_all_single(recv, send, [int(c) for c in recv_counts],
                                      [int(c) for c in send_counts], group=self._pg)
 
+    @property
+    def backend(self):
+        return str(self._dist.get_backend(self._pg))
+
+    def p2p(self, sends, recvs):
+        dist = self._dist
+        if self.backend != 'nccl' and any(t.is_cuda for t, _ in list(sends) + list(recvs)):
+            # gloo's send/recv take host pointers only (its collectives stage device tensors, its
+            # point-to-point calls do not): stage through host copies on this development route
+            hsends = [(t.cpu(), peer) for t, peer in sends]
+            hrecvs = [(t.new_empty(t.shape, device='cpu'), peer) for t, peer in recvs]
+            TorchComm.p2p(self, hsends, hrecvs)
+            for (t, _), (h, _) in zip(recvs, hrecvs):
+                t.copy_(h)
+            return
+        ops = [dist.P2POp(dist.irecv, t, self._ranks[peer], group=self._pg) for t, peer in recvs]
+        ops += [dist.P2POp(dist.isend, t, self._ranks[peer], group=self._pg) for t, peer in sends]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
     def alltoall_async(self, send, recv, send_counts, recv_counts):
         """Non-blocking variant: returns a handle with ``wait()``.  On the nccl backend the
         exchange runs on RCCL's own stream after the work already queued on the current stream;
@@ -232,7 +267,9 @@ class _CartView(Comm):
                 mine = tuple(members)
         if len(mine) == 1:
             return COMM_SELF
-        return TorchComm(mine, key=('sub', dims, remdims))
+        sub = TorchComm(mine, key=('sub', dims, remdims))
+        sub.relay_parent = self._parent
+        return sub
 
     def alltoall(self, *a):
         return self._parent.alltoall(*a)

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import comm as _comm
+from . import relay as _relay
 from . import _lib
 from .array import DeviceArray
 
@@ -88,6 +89,27 @@ class Transfer:
         assert self.subshapeA[self.axisA] == self.shape[self.axisA]
         assert self.subshapeB[self.axisB] == self.shape[self.axisB]
         self._stage = {}
+        self._relay = self._plan_relay()
+
+    def _plan_relay(self):
+        """Schedules of the multi-path exchange (relay.py) when the sub-communicator leaves most
+        of the parent's links idle; None = plain all-to-all.  Collective over the parent."""
+        parent = getattr(self.comm, 'relay_parent', None)
+        self.exchange = 'direct'          # route in use: 'direct' | 'relay' | None (to be measured)
+        if parent is None:
+            return None
+        mode = _relay.policy(self._p, parent.Get_size(), parent.backend)
+        if mode == 'off':
+            return None
+        self.exchange = 'relay' if mode == 'on' else None
+        mult = 2 if self.dtype.kind == 'c' else 1
+        members = tuple(parent._ranks.index(r) for r in self.comm._ranks)
+        meta = parent.allgather_obj((members, [c * mult for c in self._countsA],
+                                     [c * mult for c in self._countsB]))
+        me = parent.Get_rank()
+        fwd = _relay.Schedule([(m, a) for m, a, b in meta], me)
+        bwd = _relay.Schedule([(m, b) for m, a, b in meta], me)
+        return parent, fwd, bwd
 
     # -- staging buffers in the real scalar type (all-to-all backends want real dtypes)
     def _real_view(self, t):
@@ -152,7 +174,11 @@ class Transfer:
             return
         isz = self.dtype.itemsize
         mult = 2 if self.dtype.kind == 'c' else 1
-        K = self._nchunks(shape_src, axis_src, axis_dst, ts.numel() * isz)
+        if self._relay and self.exchange is None:
+            self.exchange = self._measure_routes(src, dst, shape_src, axis_src, counts_src,
+                                                 shape_dst, axis_dst, counts_dst)
+        use_relay = self._relay and self.exchange == 'relay'
+        K = 1 if use_relay else self._nchunks(shape_src, axis_src, axis_dst, ts.numel() * isz)
         if K > 1:
             self._move_chunked(src, dst, shape_src, axis_src, shape_dst, axis_dst, K)
             return
@@ -163,10 +189,45 @@ class Transfer:
             eng.pack(ts, send, shape_src, axis_src, p, isz)
         direct = _is_outermost(shape_dst, axis_dst)
         recv = td if direct else self._staging(td, 'recv')
-        self.comm.alltoall(self._real_view(send), self._real_view(recv),
-                           [c * mult for c in counts_src], [c * mult for c in counts_dst])
+        if use_relay:
+            parent, fwd, bwd = self._relay
+            sched = fwd if counts_src is self._countsA else bwd
+            rs = self._real_view(send)
+            key = ('relay', str(rs.dtype), str(rs.device))
+            size = max(fwd.relay_size, bwd.relay_size, 1)
+            relay = self._stage.get(key)
+            if relay is None:
+                relay = self._stage[key] = torch.empty(size, dtype=rs.dtype, device=rs.device)
+            sched.run(parent, rs, self._real_view(recv), relay)
+        else:
+            self.comm.alltoall(self._real_view(send), self._real_view(recv),
+                               [c * mult for c in counts_src], [c * mult for c in counts_dst])
         if not direct:
             eng.unpack(recv, td, shape_dst, axis_dst, p, isz)
+
+    def _measure_routes(self, *args):
+        """Time the direct and the relayed route on this transfer's own buffers (the exchange only
+        reads `src` and overwrites `dst`, so repeating it is harmless) and keep the faster; the
+        slowest rank of the parent decides, so every rank picks the same route."""
+        import time
+        parent = self._relay[0]
+        cuda = args[0].tensor.is_cuda
+        times = []
+        for route in ('direct', 'relay'):
+            self.exchange = route
+            self._move(*args)                  # connections, staging buffers
+            if cuda:
+                torch.cuda.synchronize()
+            parent.barrier()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                self._move(*args)
+            if cuda:
+                torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / 2)
+        worst = np.max(np.array(parent.allgather_obj(times)), axis=0)
+        self.route_times = tuple(float(t) for t in worst)
+        return 'relay' if worst[1] < 0.92 * worst[0] else 'direct'
 
     def forward(self, arrayA, arrayB):
         assert self.subshapeA == tuple(arrayA.shape)

@@ -25,7 +25,13 @@ def main():
     cases = [((16, 12, 10), "D", {}), ((13, 12, 10), "d", {}), ((7, 8, 9), "D", {}),
              ((12, 13), 'D', {}), ((16, 12, 10), 'd', dict(padding=[1.5, 1.5, 1.5])),
              ((12, 10, 8), 'D', dict(grid=(-1,))), ((12, 9, 8, 6), 'd', dict(axes=((0,), (1,), (2, 3))))]
-    for shape, dt, kw in cases:
+    from mpi4py_fft_amd import relay
+    relayed, run = [], relay.Schedule.run
+    relay.Schedule.run = lambda self, *a: (relayed.append(1), run(self, *a))[1]
+    # second sweep: the two-round multi-path exchange (relay.py) over point-to-point messages
+    sweeps = [(c, '0') for c in cases] + ([(c, '1') for c in cases] if P > 2 else [])
+    for (shape, dt, kw), mode in sweeps:
+        os.environ['GFFT_RELAY'] = mode if (mode == '0' or shape[0] != 7) else 'measure'
         ref = O.OPFFT(P, shape, dtype=dt, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
         G = O.rng_array(ref.input_shape, dt, 42)
         want = ref.forward(ref.scatter(G))[r]
@@ -41,6 +47,7 @@ def main():
             back = np.asarray(fft.backward())
             assert np.abs(back - G[fft.local_slice(False)]).max() < 1e-12
         fft.destroy()
+    assert bool(relayed) == (P > 2)
     # DistArray.redistribute over the real communicator (tests/test_darray.py:50-57)
     N = (8, 10, 12)
     sub = Subcomm(world, [0, 0, 1])

@@ -21,7 +21,10 @@ def main():
     pencil.Transfer.CHUNK_MIN_BYTES = 1 << 16
     cases = [((64, 48, 40), 'D', {}), ((48, 64, 66), 'd', {}), ((96, 64, 32), 'F', dict(grid=(-1,))),
              ((32, 48, 64), 'd', dict(padding=[1.5, 1.5, 1.5])), ((128, 128, 128), 'D', {})]
-    for shape, dt, kw in cases:
+    # second sweep: the two-round multi-path exchange (relay.py) over point-to-point messages
+    sweeps = [(c, '0') for c in cases] + ([(c, '1') for c in cases] if P > 2 else [])
+    for (shape, dt, kw), mode in sweeps:
+        os.environ['GFFT_RELAY'] = mode
         ref = O.OPFFT(P, shape, dtype=dt, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
         G = O.rng_array(ref.input_shape, dt, 42)
         want = ref.forward(ref.scatter(G))[r]

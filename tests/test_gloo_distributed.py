@@ -9,7 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('nranks,port', [(2, 29541), (4, 29542)])
+@pytest.mark.parametrize('nranks,port', [(2, 29541), (4, 29542), (8, 29543)])
 def test_pfft_over_gloo(nranks, port):
     env = dict(os.environ, OMP_NUM_THREADS='1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nranks),

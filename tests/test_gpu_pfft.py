@@ -202,3 +202,18 @@ def test_chunked_transfer_pipeline_on_device(monkeypatch):
         cases.check_pfft_golden(name)
     cases.check_pfft_vs_oracle(8, (32, 48, 40), 'D')
     cases.check_pfft_vs_oracle(4, (33, 20, 18), 'd')
+
+
+def test_relayed_exchange_on_device(monkeypatch):
+    """Two-round multi-path exchange (relay.py) around the real pack/unpack kernels."""
+    monkeypatch.setenv('GFFT_RELAY', '1')
+    from mpi4py_fft_amd import relay
+    calls, run = [], relay.Schedule.run
+    monkeypatch.setattr(relay.Schedule, 'run', lambda self, *a: (calls.append(1), run(self, *a))[1])
+    for name in ('c2c_16x16x16_p8', 'r2c_16x16x18_p8', 'r2c_13x12x10_p4', 'c2c_6x7x8x9_p4'):
+        cases.check_pfft_golden(name)
+    cases.check_pfft_vs_oracle(8, (32, 48, 40), 'D')
+    cases.check_pfft_vs_oracle(8, (64, 64, 64), 'F')
+    cases.check_pfft_vs_oracle(4, (33, 20, 18), 'd')
+    cases.check_pfft_vs_oracle(6, (24, 20, 18), 'd', padding=[1.5, 1.5, 1.5])
+    assert calls

@@ -94,3 +94,72 @@ def test_chunked_transfer_pipeline(monkeypatch):
     cases.check_pfft_golden('c2c_16x16x16_p8')
     cases.check_pfft_golden('r2c_16x16x18_p8')
     cases.check_pfft_golden('r2c_13x12x10_p4')
+
+
+def test_relay_schedule_is_consistent():
+    """relay.Schedule: for every pair of ranks the sends of one side match the receives of the
+    other in number, order and length, and every scalar of every block is delivered once."""
+    from mpi4py_fft_amd import relay
+    from mpi4py_fft_amd.pencil import _blockdist
+    for W, p, rest, n in [(8, 2, 5, 37), (8, 4, 3, 1000), (4, 2, 7, 129), (6, 3, 1, 5), (6, 2, 11, 64)]:
+        groups = [tuple(range(g * p, (g + 1) * p)) for g in range(W // p)]
+        meta = []
+        for a in range(W):
+            mem = groups[a // p]
+            ia = mem.index(a)
+            # rank a holds `rest + ia` rows of a length-n axis and sends each member its block of it
+            meta.append((mem, [(rest + ia) * _blockdist(n, p, i)[0] for i in range(p)]))
+        scheds = [relay.Schedule(meta, me) for me in range(W)]
+        for rnd in ('r1', 'r2'):
+            for x in range(W):
+                for y in range(W):
+                    s = [m[2] for m in getattr(scheds[x], rnd + '_send') if m[3] == y]
+                    r = [m[2] for m in getattr(scheds[y], rnd + '_recv') if m[3] == x]
+                    assert s == r, (W, p, rnd, x, y)
+                    assert x != y or not s
+        for j in range(W):
+            mem = groups[j // p]
+            total = sum(meta[a][1][mem.index(j)] for a in mem)
+            cover = np.zeros(total, int)
+            sc = scheds[j]
+            if sc.self_copy:
+                cover[sc.self_copy[1]:sc.self_copy[1] + sc.self_copy[2]] += 1
+            for b, o, ln, peer in sc.r1_recv + sc.r2_recv:
+                if b == 'recv':
+                    cover[o:o + ln] += 1
+            assert (cover == 1).all(), (W, p, j)
+
+
+@pytest.mark.parametrize('name', ['c2c_16x16x16_p8', 'r2c_16x16x18_p8', 'r2c_13x12x10_p4', 'c2c_12x13x14_p6'])
+def test_relayed_exchange(monkeypatch, name):
+    """The two-round multi-path exchange (relay.py) delivers what the direct all-to-all does."""
+    monkeypatch.setenv('GFFT_RELAY', '1')
+    if name not in cases.pfft_case_names():
+        pytest.skip('fixture absent')
+    from mpi4py_fft_amd import relay
+    calls, run = [], relay.Schedule.run
+    monkeypatch.setattr(relay.Schedule, 'run', lambda self, *a: (calls.append(1), run(self, *a))[1])
+    cases.check_pfft_golden(name)
+    assert calls
+
+
+def test_relayed_transfer_uneven(monkeypatch):
+    monkeypatch.setenv('GFFT_RELAY', '1')
+    from mpi4py_fft_amd import relay
+    monkeypatch.setattr(relay, 'PIECE_GRAIN', 4)
+    cases.check_pfft_vs_oracle(4, (12, 13, 12, 13), 'd', axes=((0,), (1,), (2, 3)))
+    cases.check_pfft_vs_oracle(6, (13, 11, 9), 'D')
+    cases.check_pfft_vs_oracle(8, (17, 16, 9), 'd')
+
+
+def test_measured_route_choice(monkeypatch):
+    """GFFT_RELAY=measure: the first exchange times both routes, all ranks agree on one, and the
+    data is right either way."""
+    monkeypatch.setenv('GFFT_RELAY', 'measure')
+    from mpi4py_fft_amd import pencil
+    seen, measure = [], pencil.Transfer._measure_routes
+    monkeypatch.setattr(pencil.Transfer, '_measure_routes',
+                        lambda self, *a: (lambda r: (seen.append((self.comm.Get_size(), r)), r)[1])(measure(self, *a)))
+    cases.check_pfft_golden('c2c_16x16x16_p8')
+    cases.check_pfft_vs_oracle(4, (20, 12, 16), 'd')
+    assert seen and all(r in ('direct', 'relay') for _, r in seen)

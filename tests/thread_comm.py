@@ -91,6 +91,28 @@ class ThreadComm(C.Comm):
         self._g['barrier'].wait()
 
 
+def _p2p(self, sends, recvs):
+    """Mailbox emulation of a batch of point-to-point messages (device copies between ranks)."""
+    posted = self._exchange([(t, self._members[peer]) for t, peer in sends])
+    cursor = {}
+    for t, peer in recvs:
+        src = self._members[peer]
+        lst = [m for m, dst in posted[peer] if dst == self._me]
+        k = cursor.get(src, 0)
+        cursor[src] = k + 1
+        assert lst[k].numel() == t.numel(), (lst[k].numel(), t.numel())
+        t.copy_(lst[k])
+    for peer in range(len(self._members)):
+        assert cursor.get(self._members[peer], 0) == sum(1 for _, dst in posted[peer] if dst == self._me)
+    import torch
+    if (recvs and recvs[0][0].device.type == 'cuda') or (sends and sends[0][0].device.type == 'cuda'):
+        torch.cuda.synchronize()
+    self._g['barrier'].wait()
+
+
+ThreadComm.p2p = _p2p
+
+
 class _Done:
     def wait(self):
         return True
@@ -116,7 +138,9 @@ class _ThreadCart(C._CartView):
                 members.append(wr)
         if len(members) == 1:
             return C.COMM_SELF
-        return ThreadComm(parent._world, members, parent._me)
+        sub = ThreadComm(parent._world, members, parent._me)
+        sub.relay_parent = parent
+        return sub
 
 
 def run(nranks, fn):
