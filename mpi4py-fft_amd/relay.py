@@ -9,14 +9,17 @@ the p=2 exchange moves half of the local array over ONE link while the others id
 This module schedules the same exchange over ALL links of the parent communicator (the W ranks the
 process grid was cut from) in two rounds of point-to-point messages:
 
-  round 1  every block a->j is cut into W pieces; piece r travels a->r   (r == j: already home,
-           r == a: stays put)
-  round 2  relay r forwards piece r to its destination j                 (r == a: a->j directly)
+  round 1  every block a->j is cut into pieces, one per relay r; piece r travels a->r
+           (r == j: already home, r == a: stays put)
+  round 2  relay r forwards piece r to its destination j     (r == a: a->j directly)
 
-Each directed link then carries (p-1)/W of a block per round instead of a whole block: the wire
-time drops by W / (2 (p-1))  (4x for p=2 on 8 GPUs, 2x for p=2 on 4 GPUs; nothing to gain once
-p-1 >= W/2, where the direct all-to-all is used).  Pieces land directly at their final offsets of
-the receive buffer, so pack / unpack are unchanged.
+The direct link a->j is used in both rounds (pieces r == j and r == a, a fraction f/2 of the block
+each); the rest is dealt evenly to the W-p ranks outside the sub-communicator.  A link to such a
+rank carries (p-1)(1-f)/(W-p) of a block per round (round 1: my pieces for p-1 destinations;
+round 2: what I relay from the p-1 sources of the destination), so all links are equally loaded
+for  f = 2(p-1) / (W-p + 2(p-1)),  and the wire time is f times that of the direct exchange:
+0.25 for p=2 on 8 GPUs, 0.5 for p=2 on 4, 0.6 for p=4 on 8.  Pieces land directly at their final
+offsets of the receive buffer, so pack / unpack are unchanged.
 
 Every rank of the parent takes part in every exchange of the family (the transfers of a PFFT are
 executed by all ranks in the same order), so the rounds are collective over the parent.
@@ -29,7 +32,7 @@ PIECE_GRAIN = 32        # pieces start on multiples of this many real scalars (1
 def policy(p, W, backend):
     """'off' | 'on' | 'measure'.  GFFT_RELAY = 0 | 1 | measure | auto (default): auto lets the
     planner time both routes on the first exchange (as FFTW_MEASURE does for the serial plans)
-    when the wire is RCCL and the predicted gain W / (2 (p-1)) is at least 4/3."""
+    when the wire is RCCL and the predicted wire-time ratio f (see above) is at most 0.75."""
     mode = os.environ.get('GFFT_RELAY', 'auto').lower()
     if p <= 1 or W <= p or mode in ('0', 'off', 'no'):
         return 'off'
@@ -37,20 +40,33 @@ def policy(p, W, backend):
         return 'on'
     if mode == 'measure':
         return 'measure'
-    return 'measure' if backend == 'nccl' and 8 * (p - 1) <= 3 * W else 'off'
+    return 'measure' if backend == 'nccl' and direct_fraction(p, W) <= 0.75 else 'off'
 
 
-def _pieces(cnt, W):
-    """[(offset, length)] * W: `cnt` scalars dealt to W relays in PIECE_GRAIN granules."""
+def direct_fraction(p, W):
+    """f: the share of each block that travels over the direct link (half of it per round)."""
+    return 2.0 * (p - 1) / ((W - p) + 2.0 * (p - 1))
+
+
+def _pieces(cnt, weights):
+    """[(offset, length)] per relay: `cnt` scalars dealt in PIECE_GRAIN granules, relay r getting
+    the share weights[r] (weights sum to 1; consecutive ranges, so the pieces tile the block)."""
     g = -(-cnt // PIECE_GRAIN)
-    q, rem = divmod(g, W)
-    out, start = [], 0
-    for r in range(W):
-        n = q + (1 if r < rem else 0)
-        lo, hi = min(cnt, start * PIECE_GRAIN), min(cnt, (start + n) * PIECE_GRAIN)
+    out, acc, start = [], 0.0, 0
+    for r, w in enumerate(weights):
+        acc += w
+        end = g if r == len(weights) - 1 else min(g, int(acc * g + 0.5))
+        end = max(end, start)
+        lo, hi = min(cnt, start * PIECE_GRAIN), min(cnt, end * PIECE_GRAIN)
         out.append((lo, hi - lo))
-        start += n
+        start = end
     return out
+
+
+def _weights(a, j, members, W):
+    f = direct_fraction(len(members), W)
+    outside = (1.0 - f) / (W - len(members))
+    return [f / 2 if r in (a, j) else (0.0 if r in members else outside) for r in range(W)]
 
 
 class Schedule:
@@ -80,7 +96,7 @@ class Schedule:
                         self.self_copy = (soff, roff, cnt)
                     soff += cnt
                     continue
-                for r, (poff, plen) in enumerate(_pieces(cnt, W)):
+                for r, (poff, plen) in enumerate(_pieces(cnt, _weights(a, j, members, W))):
                     if plen == 0:
                         continue
                     if r == j:

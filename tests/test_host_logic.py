@@ -163,3 +163,20 @@ def test_measured_route_choice(monkeypatch):
     cases.check_pfft_golden('c2c_16x16x16_p8')
     cases.check_pfft_vs_oracle(4, (20, 12, 16), 'd')
     assert seen and all(r in ('direct', 'relay') for _, r in seen)
+
+
+@pytest.mark.parametrize('W,p,ratio', [(8, 2, 0.25), (4, 2, 0.5), (8, 4, 0.6), (6, 3, 4 / 7)])
+def test_relay_balances_links(W, p, ratio):
+    """Per round no directed link carries more than f/2 of a block (relay.py docstring), i.e. the
+    two rounds together move f blocks' worth of wire time where the direct exchange moves 1."""
+    from mpi4py_fft_amd import relay
+    block = 1 << 20
+    groups = [tuple(range(g * p, (g + 1) * p)) for g in range(W // p)]
+    meta = [(groups[a // p], [block] * p) for a in range(W)]
+    assert abs(relay.direct_fraction(p, W) - ratio) < 1e-12
+    for rnd in ('r1_send', 'r2_send'):
+        load = np.zeros((W, W))
+        for me in range(W):
+            for b, o, ln, peer in getattr(relay.Schedule(meta, me), rnd):
+                load[me, peer] += ln
+        assert load.max() <= 1.02 * ratio / 2 * block, (rnd, load.max() / block)
