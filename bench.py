@@ -16,6 +16,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -70,6 +71,8 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', dest='n', type=int, default=1024, help='cube edge (default: the BASELINE config)')
+    ap.add_argument('--extras-deadline', type=float, default=240.0)
+    ap.add_argument('--no-slab', action='store_true', help='skip the slab-grid extra at N > 1')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     args = ap.parse_args()
 
@@ -153,10 +156,53 @@ def main():
                         algorithmic_bytes_per_launch=k['bytes'],
                         all_kernels={kk: round(v['ms'] / v['launches'], 4) for kk, v in kern.items()})
 
+    grid = [c.Get_size() for c in fft.subcomm]
+    exchange = [dict(ranks=t.comm.Get_size(), route=t.exchange,
+                     **({'measured_s': [round(x, 5) for x in t.route_times]} if hasattr(t, 'route_times') else {}))
+                for t in fft.transfer if t.comm.Get_size() > 1]
+    fl_f, bytes_f = fft.cost()
+    def multi_gpu_extras():
+        """Outside the timed region: where a step spends its time, stage by stage (synchronised,
+        max over ranks), and the same cube on the slab grid (N,1,1), whose single exchange spans
+        all ranks and therefore all xGMI links."""
+        nonlocal fft, u, ur
+        extras = {}
+
+        def stages(tr):
+            st = tr.stage_times()
+            allst = world.allgather_obj([b for _, b in st])
+            return [[st[i][0], round(max(r[i] for r in allst) * 1e3, 3)] for i in range(len(st))]
+        extras['stages_ms'] = {'forward': stages(fft.forward), 'backward': stages(fft.backward)}
+        if sum(1 for c in grid if c > 1) > 1 and n % size == 0 and not args.no_slab:
+            fft.destroy()
+            del fft, u, ur
+            torch.cuda.empty_cache()
+            slab = PFFT(world, shape, dtype='D', grid=(-1,))
+            torch.view_as_real(slab.forward.input_array.tensor).normal_()
+            ksteps = max(1, min(args.steps, 5))
+            for _ in range(2):
+                slab.forward()
+                slab.backward()
+            world.barrier()
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            for _ in range(ksteps):
+                slab.forward()
+                slab.backward()
+            torch.cuda.synchronize()
+            world.barrier()
+            sel = world.allreduce_max(time.perf_counter() - s0)
+            extras['slab_grid'] = {'grid': [c.Get_size() for c in slab.subcomm], 'steps': ksteps,
+                                   'ms_per_step': round(sel / ksteps * 1e3, 3),
+                                   'gflops': round(2 * flops_c2c(shape) / (sel / ksteps) / 1e9, 1),
+                                   'stages_ms': {'forward': stages(slab.forward)}}
+            slab.destroy()
+        return extras
+
+    out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         flops = 2 * flops_c2c(shape)
-        fl_f, bytes_f = fft.cost()
         whole = dict(gbs=round(2 * bytes_f * size / (elapsed / args.steps) / 1e9, 1))
         whole['frac_of_peak_per_gpu'] = round(whole['gbs'] / size / HBM_PEAK_GBS, 4)
         out = {
@@ -168,22 +214,38 @@ def main():
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'PFFT 3D c2c %d^3 complex128 forward+backward per step' % n,
-                       'grid': [c.Get_size() for c in fft.subcomm],
-                       'exchange': [dict(ranks=t.comm.Get_size(), route=t.exchange,
-                                         **({'measured_s': [round(x, 5) for x in t.route_times]}
-                                            if hasattr(t, 'route_times') else {}))
-                                    for t in fft.transfer if t.comm.Get_size() > 1],
+                       'grid': grid, 'exchange': exchange,
                        'round_trip_rel_err': rt_err},
             'whole_transform_hbm': whole,
             'roofline': roofline,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and size == 1:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
             try:
                 out['cpu_baseline'] = cpu_baseline(cores)
             except Exception as e:  # the baseline must never sink the GPU number
                 out['cpu_baseline'] = {'value': None, 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
+
+    extras = {}
+    if size > 1:
+        # the extras below must never cost the headline line: after the deadline every rank
+        # leaves, rank 0 printing what it has
+        def bail():
+            if rank == 0:
+                out['extras_error'] = 'deadline'
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        guard = threading.Timer(args.extras_deadline, bail)
+        guard.daemon = True
+        guard.start()
+        try:
+            extras = multi_gpu_extras()
+        except Exception as e:
+            extras = {'extras_error': repr(e)[:300]}
+        guard.cancel()
+    if rank == 0:
+        out.update(extras)
         print(json.dumps(out), flush=True)
     world.barrier()
     import torch.distributed as dist

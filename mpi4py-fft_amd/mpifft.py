@@ -82,6 +82,42 @@ class Transform:
         return self.output_array
 
 
+    def stage_times(self):
+        """One synchronised execution on the planned arrays, timed stage by stage:
+        [(label, seconds)] with the serial transforms ("fft axes=...") and the phases of every
+        global redistribution (pack / exchange / unpack; the slab-chunked overlap is switched off
+        for this run).  A measuring aid for bench.py -- the numbers add up to more than the
+        pipelined transform takes."""
+        import time
+        import torch
+        out = []
+
+        def sync():
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            return time.perf_counter()
+        if self._fused is not None:
+            t0 = sync()
+            self._fused()
+            return [('fft fused', sync() - t0)]
+        for i, x in enumerate(self._xfftn):
+            t0 = sync()
+            x()
+            owner = getattr(getattr(x, 'xfftn', None), '__self__', None)
+            out.append(('fft axes=%s' % (tuple(getattr(owner, 'axes', ())),), sync() - t0))
+            if i < len(self._transfer):
+                arrayA, arrayB = x.output_array, self._xfftn[i + 1].input_array
+                if arrayA is not arrayB:
+                    tr = self._transfer[i].__self__
+                    tr.trace = []
+                    try:
+                        self._transfer[i](arrayA, arrayB)
+                    finally:
+                        out.extend(tr.trace)
+                        tr.trace = None
+        return out
+
+
 class PFFT:
     """Parallel (pencil/slab decomposed) FFT of a distributed array on MI355X GPUs.
 

@@ -89,6 +89,7 @@ class Transfer:
         assert self.subshapeA[self.axisA] == self.shape[self.axisA]
         assert self.subshapeB[self.axisB] == self.shape[self.axisB]
         self._stage = {}
+        self.trace = None                 # list -> _move appends (phase, seconds), synchronising
         self._relay = self._plan_relay()
 
     def _plan_relay(self):
@@ -179,7 +180,9 @@ class Transfer:
                                                  shape_dst, axis_dst, counts_dst)
         use_relay = self._relay and self.exchange == 'relay'
         K = 1 if use_relay else self._nchunks(shape_src, axis_src, axis_dst, ts.numel() * isz)
-        if K > 1:
+        tick = self._tick
+        tick(None)
+        if K > 1 and self.trace is None:
             self._move_chunked(src, dst, shape_src, axis_src, shape_dst, axis_dst, K)
             return
         if _is_outermost(shape_src, axis_src):
@@ -187,6 +190,7 @@ class Transfer:
         else:
             send = self._staging(ts, 'send')
             eng.pack(ts, send, shape_src, axis_src, p, isz)
+            tick('pack')
         direct = _is_outermost(shape_dst, axis_dst)
         recv = td if direct else self._staging(td, 'recv')
         if use_relay:
@@ -202,8 +206,22 @@ class Transfer:
         else:
             self.comm.alltoall(self._real_view(send), self._real_view(recv),
                                [c * mult for c in counts_src], [c * mult for c in counts_dst])
+        tick('exchange[%s p=%d]' % ('relay' if use_relay else 'direct', p))
         if not direct:
             eng.unpack(recv, td, shape_dst, axis_dst, p, isz)
+            tick('unpack')
+
+    def _tick(self, name):
+        """Stage timing for bench.py's breakdown (only when `trace` is a list; synchronises)."""
+        if self.trace is None:
+            return
+        import time
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        now = time.perf_counter()
+        if name is not None:
+            self.trace.append((name, now - self._t0))
+        self._t0 = now
 
     def _measure_routes(self, *args):
         """Time the direct and the relayed route on this transfer's own buffers (the exchange only
