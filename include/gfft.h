@@ -74,6 +74,14 @@ int gfft_plan_destroy(gfft_plan plan);
  * reference's Nyquist rules.  GFFT_ERR_UNSUPPORTED = not fusable for this plan (use
  * gfft_truncate / gfft_pad); the plan is left unchanged. */
 int gfft_plan_set_truncation(gfft_plan plan, int64_t n_keep);
+/* Fuse the pack / unpack side of Transfer (pencil.py:12-29,182,200: the subarray datatypes of
+ * Alltoallw) into a single-axis complex plan.  side 1: gfft_execute writes its output directly
+ * in the layout of the all-to-all SEND buffer for `nblocks` equal blocks of the transformed axis
+ * -- what gfft_pack would produce from the natural output; side 0: it reads its input directly
+ * from the RECEIVE buffer -- what gfft_unpack would consume.  nblocks = 1 restores the natural
+ * layout.  GFFT_ERR_UNSUPPORTED (plan unchanged) when the plan is not one register-kernel pass,
+ * nblocks is not a power of two <= 8 dividing the length, or the transform is real. */
+int gfft_plan_set_split(gfft_plan plan, int side, int nblocks);
 int gfft_plan_describe(gfft_plan plan, char *buf, size_t len);
 /* flops (5 n log2 n per line, half for real) and algorithmic bytes (one read + one write of
  * the array per 1-D pass) of one execute, and the number of kernel launches it issues */

@@ -39,6 +39,7 @@ def _declare(lib):
         'gfft_execute': (c.c_int, [vp, vp, vp, c.c_double, vp]),
         'gfft_plan_destroy': (c.c_int, [vp]),
         'gfft_plan_set_truncation': (c.c_int, [vp, c.c_int64]),
+        'gfft_plan_set_split': (c.c_int, [vp, c.c_int, c.c_int]),
         'gfft_plan_describe': (c.c_int, [vp, c.c_char_p, c.c_size_t]),
         'gfft_plan_cost': (c.c_int, [vp, c.POINTER(c.c_double), c.POINTER(c.c_double), ip]),
         'gfft_pack': (c.c_int, [vp, vp, c.c_int, i64p, c.c_int, c.c_int, c.c_int, vp]),
@@ -130,6 +131,15 @@ class HipEngine:
     def plan_set_truncation(self, h, n_keep):
         """True if the truncation/padding was fused into the plan, False if it cannot be."""
         rc = lib().gfft_plan_set_truncation(h, int(n_keep))
+        if rc == -2:
+            return False
+        check(rc)
+        return True
+
+    def plan_set_split(self, h, side, nblocks):
+        """Packed (all-to-all buffer) layout on the plan's input (side 0) / output (side 1);
+        True if fused, False if this plan cannot (caller keeps the pack / unpack kernel)."""
+        rc = lib().gfft_plan_set_split(h, int(side), int(nblocks))
         if rc == -2:
             return False
         check(rc)

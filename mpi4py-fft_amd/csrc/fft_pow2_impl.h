@@ -576,8 +576,13 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     const int64_t in0 = (int64_t)o * d.in_os + (int64_t)m * d.in_ms + (int64_t)i * d.in_is;
     const int64_t out0 = (int64_t)o * d.out_os + (int64_t)m * d.out_ms + (int64_t)i * d.out_is;
     cx<real> v[R];
+    // Split layouts: thread slots e = t + q*NT advance by NT, and a block of the cut axis holds
+    // (R >> lgp) * NT entries, so block boundaries fall between the same q for every thread: a
+    // workgroup-uniform counter adds the block jump to the (uniform) step -- scalar work only.
+    const int seg_in = R >> d.in_lgp, seg_out = R >> d.out_lgp;
     if (valid) {
       int64_t idx = in0 + t_in;
+      int cnt = 0;
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         if constexpr ((FLAGS & 16) != 0) {
@@ -586,7 +591,12 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
         } else {
           v[q] = tile_load<real, MODE, (FLAGS & 1) != 0>(d, in, in0, idx, t + q * NT, sy_in);
         }
-        idx += q_in;
+        int64_t step = q_in;
+        if (++cnt == seg_in) {
+          cnt = 0;
+          step += d.in_jump;
+        }
+        idx += step;
       }
     } else {
 #pragma unroll
@@ -617,6 +627,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     }
     if (valid) {
       int64_t idx = out0 + t_out;
+      int cnt = 0;
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         if constexpr ((FLAGS & 16) != 0) {
@@ -625,7 +636,12 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
         } else {
           tile_store<real, MODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, t + q * NT, m, v[q], sx_out, sy_out);
         }
-        idx += q_out;
+        int64_t step = q_out;
+        if (++cnt == seg_out) {
+          cnt = 0;
+          step += d.out_jump;
+        }
+        idx += step;
       }
     }
   }
@@ -642,6 +658,11 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   constexpr size_t lds_f = (FLAGS & 16) ? (size_t)T * 2 * sizeof(real) : 0;
   constexpr size_t lds = lds_x > lds_f ? lds_x : lds_f;
   static_assert(lds <= 160 * 1024, "LDS budget");
+  // split layouts: whole thread slots per block, plain complex passes only
+  if (d.in_lgp || d.out_lgp) {
+    const int lg = d.in_lgp > d.out_lgp ? d.in_lgp : d.out_lgp;
+    if (((R >> lg) << lg) != R || MODE != MODE_C2C || BIGTW || (FLAGS & 16)) return hipErrorInvalidValue;
+  }
   auto kern = fft_pow2_kernel<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE, BIGTW, RADS...>;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
@@ -682,11 +703,11 @@ hipError_t launch_pow2_inst(const PassDesc &d, const void *in, void *out, hipStr
     if (d.tr_dir == 2 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2C, false, RADS...>(d, in, out, s);
     if (d.tr_dir == 2 && d.mode == MODE_C2R) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2R, false, RADS...>(d, in, out, s);
     if (d.tr_dir) return hipErrorInvalidValue;
-  }
-  switch (d.mode) {
-    case MODE_C2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, false, RADS...>(d, in, out, s);
-    case MODE_R2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_R2C, false, RADS...>(d, in, out, s);
-    case MODE_C2R: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2R, false, RADS...>(d, in, out, s);
+    switch (d.mode) {
+      case MODE_C2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, false, RADS...>(d, in, out, s);
+      case MODE_R2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_R2C, false, RADS...>(d, in, out, s);
+      case MODE_C2R: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2R, false, RADS...>(d, in, out, s);
+    }
   }
   return hipErrorInvalidValue;
 }

@@ -35,6 +35,11 @@ struct PassDesc {
   int64_t mid, inner;
   int64_t in_os, in_ms, in_is, in_es;
   int64_t out_os, out_ms, out_is, out_es;
+  // packed-layout adapters (gfft_plan_set_split): the transform axis is cut into 2^lgp equal
+  // blocks that lie `jump` elements further apart than consecutive entries would (the layout of
+  // an all-to-all send / receive buffer); 0 / 0 = natural layout
+  int in_lgp, out_lgp;
+  int64_t in_jump, out_jump;
   double scale;           // applied on store
   const void *tw;         // cx<real>[n]: exp(-2 pi i k / n)
   // optional four-step twiddle: output element k of a column with mid index m is multiplied

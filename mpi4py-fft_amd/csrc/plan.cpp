@@ -968,6 +968,39 @@ int gfft_plan_set_truncation(gfft_plan pl, int64_t n_keep) {
   return GFFT_OK;
 }
 
+/* Packed-layout adapters (see include/gfft.h).  side 0: the plan reads its input from an
+ * all-to-all receive buffer; side 1: it writes its output as an all-to-all send buffer.  Both are
+ * the layout gfft_pack produces for `nblocks` equal blocks of the transformed axis:
+ * [block][outer][n/nblocks][inner].  nblocks = 1 restores the natural layout. */
+int gfft_plan_set_split(gfft_plan pl, int side, int nblocks) {
+  if (!pl) return fail(GFFT_ERR_INVALID, "null plan");
+  if (side != 0 && side != 1) return fail(GFFT_ERR_INVALID, "side must be 0 (input) or 1 (output)");
+  if (pl->passes.size() != 1 || pl->axes.size() != 1 || pl->fused3)
+    return fail(GFFT_ERR_UNSUPPORTED, "split layouts fuse into single-pass plans only");
+  Pass &p = pl->passes[0];
+  if (p.kind != PK_FFT || !p.regk || p.d.mid != 1 || p.d.tw_hi || p.d.tr_dir || p.d.mode != MODE_C2C)
+    return fail(GFFT_ERR_UNSUPPORTED, "split layouts fuse into complex register-kernel passes only");
+  const int64_t n = p.d.n, inner = p.d.inner, outer = p.d.batch / p.d.inner;
+  int lg = 0;
+  while ((1 << lg) < nblocks) ++lg;
+  if (nblocks < 1 || (1 << lg) != nblocks) return fail(GFFT_ERR_UNSUPPORTED, "block count must be a power of two");
+  // whole thread slots per block: R = 4 (n = 16), 8 or 16 (other powers of two), 12 / 20 (3^b 2^k / 5^c 2^k)
+  const int max_blocks = is_pow2(n) ? (n >= 32 ? 8 : 4) : 4;
+  if (nblocks > max_blocks || n % nblocks) return fail(GFFT_ERR_UNSUPPORTED, "block count not supported for this length");
+  const int64_t nb = n / nblocks;
+  const int64_t os = nb * inner, jump = nblocks > 1 ? (outer - 1) * nb * inner : 0;
+  if (side == 0) {
+    p.d.in_os = os;
+    p.d.in_jump = jump;
+    p.d.in_lgp = lg;
+  } else {
+    p.d.out_os = os;
+    p.d.out_jump = jump;
+    p.d.out_lgp = lg;
+  }
+  return GFFT_OK;
+}
+
 int gfft_plan_destroy(gfft_plan pl) {
   if (!pl) return GFFT_OK;
   if (pl->scratch) (void)hipFree(pl->scratch);

@@ -103,6 +103,12 @@ class FFT:
         single-axis plan; returns False when the engine cannot (see gfft_plan_set_truncation)."""
         return self._eng.plan_set_truncation(self._plan, n_keep)
 
+    def set_split(self, side, nblocks):
+        """Read the input from (side 0) / write the output as (side 1) an all-to-all buffer of
+        `nblocks` equal blocks of the transformed axis (see gfft_plan_set_split); False when the
+        engine cannot fuse it into this plan."""
+        return self._eng.plan_set_split(self._plan, side, nblocks)
+
     def update_arrays(self, input_array, output_array):
         assert self.input_shape == tuple(input_array.shape)
         assert self.input_strides == input_array.strides

@@ -12,6 +12,8 @@ Two things are done differently because they only cost time in the reference:
     stage's input array *is* the previous stage's output array, so nothing is copied;
   * forward normalisation is fused into the FFT kernels (see libfft.py).
 """
+import os
+
 import numpy as np
 
 from .array import DeviceArray
@@ -278,6 +280,9 @@ class PFFT:
                 and kw.get('fuse', True)):
             fused_fwd, fused_bck = self._plan_fused()
 
+        if not local and kw.get('fuse_pack', os.environ.get('GFFT_FUSE_PACK', '1') != '0'):
+            self._fuse_packs()
+
         self.forward = Transform(
             [o.forward for o in self.xfftn],
             [o.forward for o in self.transfer],
@@ -286,6 +291,38 @@ class PFFT:
             [o.backward for o in self.xfftn[::-1]],
             [o.backward for o in self.transfer[::-1]],
             self.pencil[::-1], fused_bck)
+
+    def _fuse_packs(self):
+        """Let the serial transforms next to a redistribution write / read the exchange buffers
+        themselves.  The reference gives ``Alltoallw`` subarray datatypes and MPI gathers/scatters
+        the blocks (pencil.py:12-29); the staged equivalent is pack kernel -> all-to-all -> unpack
+        kernel, two extra HBM round trips of the local array per redistribution.  Both sides of a
+        redistribution cut the axis that the neighbouring stage transforms, so the stage's
+        kernel can address the packed buffer directly (``gfft_plan_set_split``): its output array
+        then IS the send buffer (and the next stage's input array the receive buffer).  Applied
+        per side when the stage is one complex single-axis register-kernel pass and the axis
+        divides evenly; otherwise that side keeps its pack / unpack kernel.  The intermediate
+        arrays ``xfftn[i].forward.output_array`` then hold packed layouts."""
+        for i, tr in enumerate(self.transfer):
+            p = tr.comm.Get_size()
+            if p == 1:
+                continue
+            for stage, axis, attr, io in ((self.xfftn[i], tr.axisA, 'packedA', (1, 0)),
+                                          (self.xfftn[i + 1], tr.axisB, 'packedB', (0, 1))):
+                if (tuple(stage.axes) != (axis,) or stage._padded or not hasattr(stage.fwd, 'set_split')
+                        or not hasattr(stage.bck, 'set_split')):
+                    continue
+                # an in-place stage (single-rank chain: input array == output array) reads and
+                # writes each tile at the same addresses; a packed side would break that
+                if stage.forward.input_array.data_ptr == stage.forward.output_array.data_ptr:
+                    continue
+                # forward plan: A side = its output (1), B side = its input (0); backward mirrored
+                if not stage.fwd.set_split(io[0], p):
+                    continue
+                if not stage.bck.set_split(io[1], p):
+                    stage.fwd.set_split(io[0], 1)
+                    continue
+                setattr(tr, attr, True)
 
     def _plan_fused(self):
         """All ranks-local case (one GPU): every stage's redistribution is the identity, so the

@@ -90,6 +90,9 @@ class Transfer:
         assert self.subshapeB[self.axisB] == self.shape[self.axisB]
         self._stage = {}
         self.trace = None                 # list -> _move appends (phase, seconds), synchronising
+        # set by PFFT when the neighbouring serial transforms write / read the exchange buffers
+        # themselves (gfft_plan_set_split): that side's array IS the packed buffer
+        self.packedA = self.packedB = False
         self._relay = self._plan_relay()
 
     def _plan_relay(self):
@@ -165,7 +168,8 @@ class Transfer:
             work.wait()
             eng.unpack(rcv, d_sub, dshape, axis_dst, p, isz)
 
-    def _move(self, src, dst, shape_src, axis_src, counts_src, shape_dst, axis_dst, counts_dst):
+    def _move(self, src, dst, shape_src, axis_src, counts_src, shape_dst, axis_dst, counts_dst,
+              packed_src=False, packed_dst=False):
         p = self._p
         eng = _lib.engine()
         ts, td = src.tensor, dst.tensor
@@ -177,21 +181,22 @@ class Transfer:
         mult = 2 if self.dtype.kind == 'c' else 1
         if self._relay and self.exchange is None:
             self.exchange = self._measure_routes(src, dst, shape_src, axis_src, counts_src,
-                                                 shape_dst, axis_dst, counts_dst)
+                                                 shape_dst, axis_dst, counts_dst, packed_src, packed_dst)
         use_relay = self._relay and self.exchange == 'relay'
-        K = 1 if use_relay else self._nchunks(shape_src, axis_src, axis_dst, ts.numel() * isz)
+        K = 1 if (use_relay or packed_src or packed_dst) else \
+            self._nchunks(shape_src, axis_src, axis_dst, ts.numel() * isz)
         tick = self._tick
         tick(None)
         if K > 1 and self.trace is None:
             self._move_chunked(src, dst, shape_src, axis_src, shape_dst, axis_dst, K)
             return
-        if _is_outermost(shape_src, axis_src):
+        if packed_src or _is_outermost(shape_src, axis_src):
             send = ts
         else:
             send = self._staging(ts, 'send')
             eng.pack(ts, send, shape_src, axis_src, p, isz)
             tick('pack')
-        direct = _is_outermost(shape_dst, axis_dst)
+        direct = packed_dst or _is_outermost(shape_dst, axis_dst)
         recv = td if direct else self._staging(td, 'recv')
         if use_relay:
             parent, fwd, bwd = self._relay
@@ -253,7 +258,7 @@ class Transfer:
         assert self.dtype == arrayA.dtype
         assert self.dtype == arrayB.dtype
         self._move(arrayA, arrayB, self.subshapeA, self.axisA, self._countsA,
-                   self.subshapeB, self.axisB, self._countsB)
+                   self.subshapeB, self.axisB, self._countsB, self.packedA, self.packedB)
 
     def backward(self, arrayB, arrayA):
         assert self.subshapeA == tuple(arrayA.shape)
@@ -261,7 +266,7 @@ class Transfer:
         assert self.dtype == arrayA.dtype
         assert self.dtype == arrayB.dtype
         self._move(arrayB, arrayA, self.subshapeB, self.axisB, self._countsB,
-                   self.subshapeA, self.axisA, self._countsA)
+                   self.subshapeA, self.axisA, self._countsA, self.packedB, self.packedA)
 
     def destroy(self):
         self._stage = {}

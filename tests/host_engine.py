@@ -26,7 +26,28 @@ class HostEngine:
         return dict(sizes_in=tuple(sizes_in), sizes_out=tuple(sizes_out), axes=tuple(axes),
                     kind=kind, precision=precision)
 
+    def plan_set_split(self, h, side, nblocks):
+        # same acceptance rule as gfft_plan_set_split for what this checker can see
+        n = h['sizes_in'][h['axes'][0]]
+        if len(h['axes']) != 1 or h['kind'] not in (-1, 1) or nblocks & (nblocks - 1) or nblocks > 8 or n % nblocks:
+            return False
+        h['split_in' if side == 0 else 'split_out'] = nblocks
+        return True
+
     def plan_execute(self, h, tin, tout, scale):
+        if h.get('split_in', 1) > 1 or h.get('split_out', 1) > 1:
+            # packed layouts: unpack the input / pack the output around the natural transform
+            nat = dict(h, split_in=1, split_out=1)
+            tin2, tout2 = tin, tout
+            if h.get('split_in', 1) > 1:
+                tin2 = torch.empty_like(tin)
+                self.unpack(tin, tin2, h['sizes_in'], h['axes'][0], h['split_in'], 0)
+            if h.get('split_out', 1) > 1:
+                tout2 = torch.empty_like(tout)
+            self.plan_execute(nat, tin2, tout2, scale)
+            if h.get('split_out', 1) > 1:
+                self.pack(tout2, tout, h['sizes_out'], h['axes'][0], h['split_out'], 0)
+            return
         a = _np(tin).reshape(h['sizes_in'])
         axes, kind = h['axes'], h['kind']
         if kind == -1:

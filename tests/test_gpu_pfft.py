@@ -217,3 +217,26 @@ def test_relayed_exchange_on_device(monkeypatch):
     cases.check_pfft_vs_oracle(4, (33, 20, 18), 'd')
     cases.check_pfft_vs_oracle(6, (24, 20, 18), 'd', padding=[1.5, 1.5, 1.5])
     assert calls
+
+
+def test_pack_fusion_on_device(monkeypatch):
+    """Exchange buffers written / read by the FFT kernels themselves (PFFT._fuse_packs): same
+    results as the staged pack -> exchange -> unpack path, with and without the relayed route."""
+    from tests import thread_comm
+    from mpi4py_fft_amd import PFFT
+
+    def flags(comm):
+        return [(t.packedA, t.packedB) for t in PFFT(comm, (64, 64, 64), dtype='D').transfer]
+    assert thread_comm.run(8, flags)[0] == [(True, True), (True, True)]
+    for mode in ('0', '1'):
+        monkeypatch.setenv('GFFT_RELAY', mode)
+        cases.check_pfft_golden('c2c_16x16x16_p8')
+        cases.check_pfft_vs_oracle(8, (64, 64, 64), 'D')
+        cases.check_pfft_vs_oracle(8, (64, 128, 32), 'F')
+        cases.check_pfft_vs_oracle(4, (128, 96, 64), 'D')
+        cases.check_pfft_vs_oracle(4, (64, 64, 64), 'd')
+        cases.check_pfft_vs_oracle(2, (64, 64, 64), 'D')
+        cases.check_pfft_vs_oracle(4, (32, 64, 48), 'D', grid=(-1,))
+        cases.check_pfft_vs_oracle(4, (40, 64, 64), 'd', padding=[1.5, 1.5, 1.5])
+    monkeypatch.setenv('GFFT_FUSE_PACK', '0')
+    cases.check_pfft_vs_oracle(8, (64, 64, 64), 'D')

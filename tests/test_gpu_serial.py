@@ -330,3 +330,61 @@ def test_padded_pfft_uses_fused_truncation():
         back = np.asarray(fft.backward())
         assert np.abs(back - ref.backward([want])[0]).max() <= 1e-10 * max(1, np.abs(G).max())
         fft.destroy()
+
+
+def _packed(a, axis, p):
+    n = a.shape[axis]
+    return np.concatenate([np.ascontiguousarray(np.take(a, range(s, s + m), axis=axis)).reshape(-1)
+                           for m, s in (O.blockdist(n, p, i) for i in range(p))])
+
+
+@pytest.mark.parametrize('dt', ['D', 'F'])
+@pytest.mark.parametrize('shape,axis', [((6, 16, 5), 1), ((3, 5, 32), 2), ((64, 7, 3), 0), ((5, 256, 18), 1),
+                                        ((4, 3, 1024), 2), ((1024, 3, 17), 0), ((2, 2048, 16), 1),
+                                        ((3, 2, 4096), 2), ((3, 768, 8), 1), ((2, 5, 1000), 2),
+                                        ((96, 4, 33), 0), ((2, 640, 9), 1), ((2, 512, 513), 1)])
+def test_split_layout_plans(shape, axis, dt):
+    """gfft_plan_set_split: a plan writes what gfft_pack would make of its natural output, and
+    reads what gfft_unpack would consume (bit-identical: only the addressing differs)."""
+    from mpi4py_fft_amd import fftw, asdevice, zeros
+    n = shape[axis]
+    A = O.rng_array(shape, dt, 5)
+    a = asdevice(A)
+    for planner, kind in ((fftw.fftn, -1), (fftw.ifftn, 1)):
+        nat = planner(a, axes=(axis,), output_array=zeros(shape, dt))
+        want = np.asarray(nat.execute_scaled(a, nat.output_array, 0.5)).copy()
+        for p in (2, 4, 8):
+            ok_len = n % p == 0 and p <= (8 if (n & (n - 1)) == 0 and n >= 32 else 4)
+            plan = planner(a, axes=(axis,), output_array=zeros(shape, dt))
+            assert plan.set_split(1, p) == ok_len, (shape, axis, p)
+            if ok_len:
+                got = np.asarray(plan.execute_scaled(a, plan.output_array, 0.5)).reshape(-1)
+                assert np.array_equal(got, _packed(want, axis, p)), (shape, axis, kind, p, 'store')
+                assert plan.set_split(1, 1)
+                assert plan.set_split(0, p)
+                src = asdevice(_packed(A, axis, p).reshape(shape))
+                got = np.asarray(plan.execute_scaled(src, plan.output_array, 0.5))
+                assert np.array_equal(got, want), (shape, axis, kind, p, 'load')
+                # both sides at once
+                assert plan.set_split(1, p)
+                got = np.asarray(plan.execute_scaled(src, plan.output_array, 0.5)).reshape(-1)
+                assert np.array_equal(got, _packed(want, axis, p)), (shape, axis, kind, p, 'both')
+            plan.destroy()
+        nat.destroy()
+
+
+def test_split_layout_refusals():
+    from mpi4py_fft_amd import fftw, asdevice, zeros
+    a = asdevice(O.rng_array((8, 16, 32), 'd', 1))
+    r = fftw.rfftn(a, axes=(2,))
+    assert r.set_split(1, 2) is False                    # real transform
+    c = asdevice(O.rng_array((8, 16, 32), 'D', 1))
+    p2 = fftw.fftn(c, axes=(1, 2))
+    assert p2.set_split(1, 2) is False                   # two passes
+    p3 = fftw.fftn(c, axes=(1,))
+    assert p3.set_split(1, 3) is False and p3.set_split(1, 16) is False
+    big = asdevice(O.rng_array((2, 8192), 'D', 1))
+    p4 = fftw.fftn(big, axes=(1,))
+    assert p4.set_split(1, 2) is False                   # four-step
+    for q in (r, p2, p3, p4):
+        q.destroy()

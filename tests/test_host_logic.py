@@ -180,3 +180,30 @@ def test_relay_balances_links(W, p, ratio):
             for b, o, ln, peer in getattr(relay.Schedule(meta, me), rnd):
                 load[me, peer] += ln
         assert load.max() <= 1.02 * ratio / 2 * block, (rnd, load.max() / block)
+
+
+def test_pack_fusion_bookkeeping(monkeypatch):
+    """PFFT._fuse_packs: sides whose neighbouring stage can address the exchange buffer are marked
+    packed and the transform still matches the oracle; GFFT_FUSE_PACK=0 switches it off."""
+    from tests import thread_comm
+    from mpi4py_fft_amd import PFFT
+    from oracle import pfft_oracle as O
+
+    def body(comm):
+        fft = PFFT(comm, (16, 16, 16), dtype='D')
+        flags = [(t.packedA, t.packedB) for t in fft.transfer]
+        fft2 = PFFT(comm, (16, 12, 16), dtype='d')          # r2c stage 0, axis 1 = 12 over 2 ranks
+        flags2 = [(t.packedA, t.packedB) for t in fft2.transfer]
+        return flags, flags2
+    flags, flags2 = thread_comm.run(4, body)[0]
+    assert flags == [(True, True), (True, True)]
+    # r2c output (9 wide) cannot be cut evenly, 12 is no power-of-two block count problem (12 / 2 = 6 fits)
+    assert flags2[0][0] is False
+    cases.check_pfft_vs_oracle(4, (16, 16, 16), 'D')
+    cases.check_pfft_vs_oracle(8, (32, 16, 16), 'F')
+    cases.check_pfft_vs_oracle(4, (16, 12, 16), 'd')
+    monkeypatch.setenv('GFFT_FUSE_PACK', '0')
+
+    def body0(comm):
+        return [(t.packedA, t.packedB) for t in PFFT(comm, (16, 16, 16), dtype='D').transfer]
+    assert thread_comm.run(4, body0)[0] == [(False, False), (False, False)]
