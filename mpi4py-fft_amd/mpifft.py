@@ -280,6 +280,7 @@ class PFFT:
                 and kw.get('fuse', True)):
             fused_fwd, fused_bck = self._plan_fused()
 
+        self._transforms = transforms
         if not local and kw.get('fuse_pack', os.environ.get('GFFT_FUSE_PACK', '1') != '0'):
             self._fuse_packs()
 
@@ -313,9 +314,15 @@ class PFFT:
                         or not hasattr(stage.bck, 'set_split')):
                     continue
                 # an in-place stage (single-rank chain: input array == output array) reads and
-                # writes each tile at the same addresses; a packed side would break that
+                # writes each tile at the same addresses; a packed side would break that.  Give
+                # such a stage its own output array (one more local array, one pack pass less).
                 if stage.forward.input_array.data_ptr == stage.forward.output_array.data_ptr:
-                    continue
+                    if self._transforms is not None or attr != 'packedA':
+                        continue
+                    k = self.xfftn.index(stage)
+                    new = FFT(stage.shape, stage.axes, stage.dtype, U=stage.forward.input_array)
+                    stage.destroy()
+                    self.xfftn[k] = stage = new
                 # forward plan: A side = its output (1), B side = its input (0); backward mirrored
                 if not stage.fwd.set_split(io[0], p):
                     continue

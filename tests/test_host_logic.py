@@ -197,6 +197,15 @@ def test_pack_fusion_bookkeeping(monkeypatch):
         return flags, flags2
     flags, flags2 = thread_comm.run(4, body)[0]
     assert flags == [(True, True), (True, True)]
+
+    def slab(comm):
+        fft = PFFT(comm, (16, 16, 16), dtype='D', grid=(-1,))
+        # the in-place axis-1 stage got its own output array so that it can write the send buffer
+        return [(t.comm.Get_size(), t.packedA, t.packedB) for t in fft.transfer], \
+            fft.xfftn[1].forward.input_array.data_ptr != fft.xfftn[1].forward.output_array.data_ptr
+    fl, unshared = thread_comm.run(2, slab)[0]
+    assert fl == [(1, False, False), (2, True, True)] and unshared
+    cases.check_pfft_vs_oracle(2, (16, 16, 16), 'D', grid=(-1,))
     # r2c output (9 wide) cannot be cut evenly, 12 is no power-of-two block count problem (12 / 2 = 6 fits)
     assert flags2[0][0] is False
     cases.check_pfft_vs_oracle(4, (16, 16, 16), 'D')
