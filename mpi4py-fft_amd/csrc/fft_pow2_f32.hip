@@ -7,12 +7,13 @@ namespace gfft {
 
 #define P32(N, R, T, COLS, SPLIT, MINW, ...) \
   launch_pow2_inst<float, N, R, T, COLS, SPLIT, MINW, 0, __VA_ARGS__>(d, in, out, s)
+#define P32F(N, R, T, COLS, SPLIT, MINW, FLAGS, ...) \
+  launch_pow2_inst<float, N, R, T, COLS, SPLIT, MINW, FLAGS, __VA_ARGS__>(d, in, out, s)
 
 bool pow2_supported_f32(int n) { return n >= 16 && n <= 4096 && (n & (n - 1)) == 0; }
 
 hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void *in, void *out,
                            hipStream_t s) {
-  (void)variant;
   if (!cols) {
     switch (d.n) {
       case 16: return P32(16, 4, 16, false, false, 1, 4, 4);
@@ -39,14 +40,29 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 4096: return P32(4096, 8, 2, true, false, 1, 8, 8, 8, 8);
     }
   } else {
+    // plain c2c along a strided axis: 32 adjacent columns = 256-byte segments up to n = 512
+    // (measured on (2048,512,1024) c64: 3.88 -> 3.35 ms; n = 256: 3.53 -> 3.37 ms).  n = 1024 would
+    // need R = 32 to stay within 1024 threads, which spills (variant 1: 4.01 -> 4.40 ms).
     switch (d.n) {
-      case 16: return P32(16, 4, 16, true, false, 1, 4, 4);
-      case 32: return P32(32, 8, 16, true, false, 1, 8, 4);
-      case 64: return P32(64, 8, 16, true, false, 1, 8, 8);
-      case 128: return P32(128, 8, 16, true, false, 1, 8, 8, 2);
-      case 256: return P32(256, 16, 16, true, false, 1, 16, 16);
-      case 512: return P32(512, 8, 16, true, true, 1, 8, 8, 8);
-      case 1024: return P32(1024, 16, 16, true, true, 1, 16, 16, 4);
+      case 16: return P32F(16, 4, 32, true, false, 1, 8, 4, 4);
+      case 32: return P32F(32, 8, 32, true, false, 1, 8, 8, 4);
+      case 64: return P32F(64, 8, 32, true, false, 1, 8, 8, 8);
+      case 128: return P32F(128, 8, 32, true, false, 1, 8, 8, 8, 2);
+      case 256:
+        switch (variant) {
+          default: return P32F(256, 8, 32, true, false, 1, 8, 8, 8, 4);
+          case 1: return P32(256, 16, 16, true, false, 1, 16, 16);
+        }
+      case 512:
+        switch (variant) {
+          default: return P32F(512, 16, 32, true, true, 1, 8, 16, 8, 4);
+          case 1: return P32(512, 8, 16, true, true, 1, 8, 8, 8);
+        }
+      case 1024:
+        switch (variant) {
+          default: return P32(1024, 16, 16, true, true, 1, 16, 16, 4);
+          case 1: return P32F(1024, 32, 32, true, true, 1, 8, 16, 16, 4);    // 256-B segments, R = 32: spills
+        }
       case 2048: return P32(2048, 16, 8, true, true, 4, 16, 16, 8);
       case 4096: return P32(4096, 16, 4, true, true, 4, 16, 16, 16);
     }

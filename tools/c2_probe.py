@@ -41,6 +41,17 @@ if 'c2' in which:
     case('2^20 c64 B=128', (128, 1 << 20), 'F', (1,))
     case('2^16 c128 B=1024', (1024, 1 << 16), 'D', (1,))
     case('2^22 c128 B=16', (16, 1 << 22), 'D', (1,))
+if 'f32v' in which:
+    for v in (0, 1, 2):
+        _lib.set_option('variant_cols', v)
+        print('--- cols variant', v)
+        case('(1024,1024,1024) axis1 c64', (1024, 1024, 1024), 'F', (1,))
+        case('(1024,1024,1024) axis0 c64', (1024, 1024, 1024), 'F', (0,))
+        case('(1024,1024,513) axis1 c64', (1024, 1024, 513), 'F', (1,))
+        case('(2048,512,1024) axis1 c64', (2048, 512, 1024), 'F', (1,))
+        case('(2048,512,513) axis1 c64', (2048, 512, 513), 'F', (1,))
+        case('(4096,256,1024) axis1 c64', (4096, 256, 1024), 'F', (1,))
+    _lib.set_option('variant_cols', 0)
 if 'f32' in which:
     case('(512,2048,513) axis1 c64', (512, 2048, 513), 'F', (1,))
     case('(2048,512,513) axis0 c64', (2048, 512, 513), 'F', (0,))
