@@ -3,9 +3,11 @@ PFFT hot path -- the device counterpart of the reference's examples/spectral_dns
 algorithm, same parameters, same known answer (kinetic energy 0.124953117517 after 10 steps at
 64^3, examples/spectral_dns_solver.py:129).
 
-Everything between the transforms is elementwise work on device arrays (torch is the array
-library of the caller here, as numpy is in the reference); the transforms are
-`PFFT.forward/backward` of this package.
+The transforms are `PFFT.forward/backward` of this package, reading and writing the solver's own
+device arrays in place.  The elementwise work between them runs either as the package's one-pass
+kernels (`mpi4py_fft_amd.spectral`: curl, cross product, projection + viscous term, RK stage;
+`fused=True`, default) or as torch expressions that transcribe the reference line by line
+(`fused=False`, the A/B baseline: same answer, one temporary per operator).
 
   python examples/dns_taylor_green.py                         # 1 GPU
   torchrun --nproc-per-node 2 examples/dns_taylor_green.py    # one rank per GPU
@@ -20,8 +22,8 @@ import numpy as np
 import torch
 
 
-def solve(world, M=6, nsteps=10, dt=0.01, nu=0.000625, verbose=False):
-    from mpi4py_fft_amd import PFFT, newDistArray
+def solve(world, M=6, nsteps=10, dt=0.01, nu=0.000625, verbose=False, fused=True):
+    from mpi4py_fft_amd import PFFT, newDistArray, spectral
     N = [2 ** M] * 3
     L = np.array([2 * np.pi, 4 * np.pi, 4 * np.pi])
     FFT = PFFT(world, N, collapse=False)                      # real input: r2c along axis 2
@@ -47,6 +49,21 @@ def solve(world, M=6, nsteps=10, dt=0.01, nu=0.000625, verbose=False):
     K_over_K2 = K / torch.where(K2 == 0, torch.ones_like(K2), K2)
 
     u, uh, uh0, uh1, du, cu = (a.tensor for a in (U, U_hat, U_hat0, U_hat1, dU, curl))
+    if fused:
+        ops = spectral.SpectralOps(FFT, L)
+        W_hat = newDistArray(FFT, rank=1)                     # i K x u_hat
+        UxW = newDistArray(FFT, False, rank=1)                # u x curl u
+
+        def compute_rhs_fused():
+            for j in range(3):
+                FFT.backward(U_hat[j], U[j])                  # kernels read U_hat[j], write U[j]
+            ops.curl(U_hat, W_hat)
+            for j in range(3):
+                FFT.backward(W_hat[j], curl[j])
+            spectral.cross(U, curl, UxW)
+            for j in range(3):
+                FFT.forward(UxW[j], dU[j])
+            ops.project(dU, U_hat, nu)
 
     def fwd(x, out):      # physical (torch expression) -> spectral slice `out`
         out.copy_(FFT.forward(x).tensor)
@@ -75,21 +92,34 @@ def solve(world, M=6, nsteps=10, dt=0.01, nu=0.000625, verbose=False):
 
     a = [1. / 6., 1. / 3., 1. / 3., 1. / 6.]
     b = [0.5, 0.5, 1.]
+    if dev.type == 'cuda':
+        torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(nsteps):
         uh0.copy_(uh)
         uh1.copy_(uh)
         for rk in range(4):
-            compute_rhs()
-            if rk < 3:
-                torch.add(uh0, du, alpha=b[rk] * dt, out=uh)
-            uh1.add_(du, alpha=a[rk] * dt)
+            if fused:
+                compute_rhs_fused()
+                spectral.rk_stage(U_hat if rk < 3 else None, U_hat0, U_hat1, dU,
+                                  b[rk] * dt if rk < 3 else 0.0, a[rk] * dt)
+            else:
+                compute_rhs()
+                if rk < 3:
+                    torch.add(uh0, du, alpha=b[rk] * dt, out=uh)
+                uh1.add_(du, alpha=a[rk] * dt)
         uh.copy_(uh1)
         for i in range(3):
-            bwd(uh[i], u[i])
+            if fused:
+                FFT.backward(U_hat[i], U[i])
+            else:
+                bwd(uh[i], u[i])
     energy = sum(world.allgather_obj(float((u * u).sum().item()))) / N[0] / N[1] / N[2] / 2
+    elapsed = time.time() - t0
     if verbose and world.Get_rank() == 0:
-        print('Time = %.3f s, energy = %.12f' % (time.time() - t0, energy))
+        print('%d^3, %d steps, %s pointwise path: %.3f s (%.2f ms per RK4 step), energy = %.12f'
+              % (N[0], nsteps, 'fused-kernel' if fused else 'torch-expression', elapsed,
+                 elapsed / nsteps * 1e3, energy))
     FFT.destroy()
     return energy
 
@@ -99,3 +129,8 @@ if __name__ == '__main__':
     w = comm.init_distributed()
     e = solve(w, verbose=True)
     assert round(e - 0.124953117517, 7) == 0, e
+    e = solve(w, verbose=True, fused=False)
+    assert round(e - 0.124953117517, 7) == 0, e
+    if len(sys.argv) > 1:                       # e.g. `dns_taylor_green.py 8` for 256^3 timings
+        for f in (True, False):
+            solve(w, M=int(sys.argv[1]), nsteps=5, verbose=True, fused=f)

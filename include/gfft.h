@@ -109,6 +109,23 @@ int gfft_pad(const void *d_trunc, void *d_padded, int ndims, const int64_t *shap
 /* d_data[i] *= scale for `count` real scalars of the given precision */
 int gfft_scale(void *d_data, int64_t count, int precision, double scale, void *stream);
 
+/* ---- the pseudo-spectral caller either side of the path ----
+ * One-pass device versions of the pointwise steps examples/spectral_dns_solver.py:65-91 writes as
+ * numpy expressions.  Vector fields are [3][n0][n1][n2] (the layout of newDistArray(fft, rank=1));
+ * d_k0/1/2 are the local wavenumbers along each axis (n0, n1, n2 real scalars: the sparse form of
+ * get_local_wavenumbermesh, :52-63), not array-sized meshes.
+ *   gfft_ps_curl     out = 1j * (K x u_hat)                                   compute_curl, :76-80
+ *   gfft_ps_cross    out = a x b, real fields, count = n0*n1*n2 per component   cross, :69-74
+ *   gfft_ps_project  P = sum(du*K/|K|^2); du -= P*K; du -= nu*|K|^2*u_hat      compute_rhs, :88-90
+ *   gfft_ps_rk_stage u = u0 + cb*du (skipped when d_u is NULL); u1 += ca*du; `count` real scalars   :112-116 */
+int gfft_ps_curl(const void *d_u_hat, void *d_out, const void *d_k0, const void *d_k1, const void *d_k2,
+                 int64_t n0, int64_t n1, int64_t n2, int precision, void *stream);
+int gfft_ps_cross(const void *d_a, const void *d_b, void *d_out, int64_t count, int precision, void *stream);
+int gfft_ps_project(void *d_du_hat, const void *d_u_hat, const void *d_k0, const void *d_k1, const void *d_k2,
+                    int64_t n0, int64_t n1, int64_t n2, double nu, int precision, void *stream);
+int gfft_ps_rk_stage(void *d_u, const void *d_u0, void *d_u1, const void *d_du, int64_t count, double cb,
+                     double ca, int precision, void *stream);
+
 /* ---- raw device helpers for non-torch hosts (the Python host uses torch for these) ---- */
 int gfft_malloc(void **d_ptr, size_t bytes);
 int gfft_free(void *d_ptr);

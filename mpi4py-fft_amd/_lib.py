@@ -47,6 +47,10 @@ def _declare(lib):
         'gfft_truncate': (c.c_int, [vp, vp, c.c_int, i64p, c.c_int, c.c_int64, c.c_int, c.c_int, c.c_double, vp]),
         'gfft_pad': (c.c_int, [vp, vp, c.c_int, i64p, c.c_int, c.c_int64, c.c_int, c.c_int, vp]),
         'gfft_scale': (c.c_int, [vp, c.c_int64, c.c_int, c.c_double, vp]),
+        'gfft_ps_curl': (c.c_int, [vp, vp, vp, vp, vp, c.c_int64, c.c_int64, c.c_int64, c.c_int, vp]),
+        'gfft_ps_cross': (c.c_int, [vp, vp, vp, c.c_int64, c.c_int, vp]),
+        'gfft_ps_project': (c.c_int, [vp, vp, vp, vp, vp, c.c_int64, c.c_int64, c.c_int64, c.c_double, c.c_int, vp]),
+        'gfft_ps_rk_stage': (c.c_int, [vp, vp, vp, vp, c.c_int64, c.c_double, c.c_double, c.c_int, vp]),
         'gfft_malloc': (c.c_int, [c.POINTER(vp), c.c_size_t]),
         'gfft_free': (c.c_int, [vp]),
         'gfft_memcpy_h2d': (c.c_int, [vp, vp, c.c_size_t, vp]),
@@ -198,6 +202,27 @@ class HipEngine:
     def scale(self, t, count, precision, scale):
         self.require_device(t)
         check(lib().gfft_scale(t.data_ptr(), count, precision, float(scale), current_stream()))
+
+    # pseudo-spectral caller kernels (spectral.py)
+    def ps_curl(self, tu, tout, k, shape, precision):
+        self.require_device(tu)
+        check(lib().gfft_ps_curl(tu.data_ptr(), tout.data_ptr(), k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr(),
+                                 shape[0], shape[1], shape[2], precision, current_stream()))
+
+    def ps_cross(self, ta, tb, tout, count, precision):
+        self.require_device(ta)
+        check(lib().gfft_ps_cross(ta.data_ptr(), tb.data_ptr(), tout.data_ptr(), count, precision, current_stream()))
+
+    def ps_project(self, tdu, tu, k, shape, nu, precision):
+        self.require_device(tdu)
+        check(lib().gfft_ps_project(tdu.data_ptr(), tu.data_ptr(), k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr(),
+                                    shape[0], shape[1], shape[2], float(nu), precision, current_stream()))
+
+    def ps_rk_stage(self, tu, tu0, tu1, tdu, count, cb, ca, precision):
+        self.require_device(tu1)
+        check(lib().gfft_ps_rk_stage(None if tu is None else tu.data_ptr(), None if tu0 is None else tu0.data_ptr(),
+                                     tu1.data_ptr(), tdu.data_ptr(), count, float(cb), float(ca), precision,
+                                     current_stream()))
 
     def copy(self, tsrc, tdst):
         self.require_device(tsrc)

@@ -98,6 +98,13 @@ hipError_t launch_embed(const PointDesc &p, int precision, const void *in, void 
 hipError_t launch_mulb(const PointDesc &p, int precision, void *scratch, hipStream_t s);
 hipError_t launch_extract(const PointDesc &p, int precision, const void *scratch, void *out, double scale, hipStream_t s);
 hipError_t launch_scale(void *data, int64_t count, int precision, double scale, hipStream_t s);
+hipError_t launch_ps_curl(const void *u, void *out, const void *k0, const void *k1, const void *k2, int64_t n0,
+                          int64_t n1, int64_t n2, int precision, hipStream_t s);
+hipError_t launch_ps_cross(const void *a, const void *b, void *out, int64_t count, int precision, hipStream_t s);
+hipError_t launch_ps_project(void *du, const void *u, const void *k0, const void *k1, const void *k2, int64_t n0,
+                             int64_t n1, int64_t n2, double nu, int precision, hipStream_t s);
+hipError_t launch_ps_rk(void *u, const void *u0, void *u1, const void *du, int64_t count, double cb, double ca,
+                        int precision, hipStream_t s);
 extern int g_copy_nt;
 hipError_t launch_copy(const void *src, void *dst, size_t bytes, hipStream_t s);
 hipError_t launch_tile_copy(const void *src, void *dst, int64_t outer, int64_t n, int64_t inner,

@@ -1105,6 +1105,45 @@ int gfft_scale(void *d_data, int64_t count, int precision, double scale, void *s
   return GFFT_OK;
 }
 
+int gfft_ps_curl(const void *d_u_hat, void *d_out, const void *d_k0, const void *d_k1, const void *d_k2,
+                 int64_t n0, int64_t n1, int64_t n2, int precision, void *stream) {
+  int rc = check_device();
+  if (rc) return rc;
+  if (!d_u_hat || !d_out || !d_k0 || !d_k1 || !d_k2 || n0 < 0 || n1 < 0 || n2 < 0 || (precision != 4 && precision != 8))
+    return fail(GFFT_ERR_INVALID, "gfft_ps_curl: bad argument");
+  HIP_TRY(launch_ps_curl(d_u_hat, d_out, d_k0, d_k1, d_k2, n0, n1, n2, precision, (hipStream_t)stream));
+  return GFFT_OK;
+}
+
+int gfft_ps_cross(const void *d_a, const void *d_b, void *d_out, int64_t count, int precision, void *stream) {
+  int rc = check_device();
+  if (rc) return rc;
+  if (!d_a || !d_b || !d_out || count < 0 || (precision != 4 && precision != 8))
+    return fail(GFFT_ERR_INVALID, "gfft_ps_cross: bad argument");
+  HIP_TRY(launch_ps_cross(d_a, d_b, d_out, count, precision, (hipStream_t)stream));
+  return GFFT_OK;
+}
+
+int gfft_ps_project(void *d_du_hat, const void *d_u_hat, const void *d_k0, const void *d_k1, const void *d_k2,
+                    int64_t n0, int64_t n1, int64_t n2, double nu, int precision, void *stream) {
+  int rc = check_device();
+  if (rc) return rc;
+  if (!d_du_hat || !d_u_hat || !d_k0 || !d_k1 || !d_k2 || n0 < 0 || n1 < 0 || n2 < 0 || (precision != 4 && precision != 8))
+    return fail(GFFT_ERR_INVALID, "gfft_ps_project: bad argument");
+  HIP_TRY(launch_ps_project(d_du_hat, d_u_hat, d_k0, d_k1, d_k2, n0, n1, n2, nu, precision, (hipStream_t)stream));
+  return GFFT_OK;
+}
+
+int gfft_ps_rk_stage(void *d_u, const void *d_u0, void *d_u1, const void *d_du, int64_t count, double cb,
+                     double ca, int precision, void *stream) {
+  int rc = check_device();
+  if (rc) return rc;
+  if ((d_u && !d_u0) || !d_u1 || !d_du || count < 0 || (precision != 4 && precision != 8))
+    return fail(GFFT_ERR_INVALID, "gfft_ps_rk_stage: bad argument");
+  HIP_TRY(launch_ps_rk(d_u, d_u0, d_u1, d_du, count, cb, ca, precision, (hipStream_t)stream));
+  return GFFT_OK;
+}
+
 int gfft_malloc(void **d_ptr, size_t bytes) {
   int rc = check_device();
   if (rc) return rc;

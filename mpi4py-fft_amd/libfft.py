@@ -155,32 +155,36 @@ class FFT(FFTBase):
     def _forward(self, **kw):
         # `src`: read the input directly from a caller's device array of the planned layout
         # (no plan of this package writes to its input when run out of place)
+        # `dst`: write the result directly into a caller's device array of the planned layout
         normalize = kw.pop('normalize', True)
         src = kw.pop('src', None)
+        dst = kw.pop('dst', None)
         src = self.fwd.input_array if src is None else src
         scale = self.M if normalize else 1.0
         if self._fused_trunc:
-            self.fwd.execute_scaled(src, self.forward.output_array, scale)
+            self.fwd.execute_scaled(src, self.forward.output_array if dst is None else dst, scale)
         elif not self._padded:
-            self.fwd.execute_scaled(src, self.fwd.output_array, scale)
+            self.fwd.execute_scaled(src, self.fwd.output_array if dst is None else dst, scale)
         else:
             self.fwd.execute_scaled(src, self.fwd.output_array, 1.0)
-            self._truncation_forward(self.fwd.output_array, self.forward.output_array, scale)
-        return self.forward.output_array
+            self._truncation_forward(self.fwd.output_array, self.forward.output_array if dst is None else dst, scale)
+        return self.forward.output_array if dst is None else dst
 
     def _backward(self, **kw):
         normalize = kw.pop('normalize', False)
         src = kw.pop('src', None)
+        dst = kw.pop('dst', None)
+        out = self.bck.output_array if dst is None else dst
         if self._fused_trunc:
             self.bck.execute_scaled(self.backward.input_array if src is None else src,
-                                    self.bck.output_array, self.M if normalize else 1.0)
-            return self.backward.output_array
+                                    out, self.M if normalize else 1.0)
+            return out
         if self._padded:
             self._padding_backward(self.backward.input_array if src is None else src, self.bck.input_array)
             src = None
-        self.bck.execute_scaled(self.bck.input_array if src is None else src, self.bck.output_array,
+        self.bck.execute_scaled(self.bck.input_array if src is None else src, out,
                                 self.M if normalize else 1.0)
-        return self.backward.output_array
+        return out
 
     # 3/2-rule helpers: libfft.py:263-311 as one kernel each
     def _truncation_forward(self, padded_array, trunc_array, scale=1.0):

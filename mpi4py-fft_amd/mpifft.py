@@ -53,36 +53,52 @@ class Transform:
         """Compute the transform.  Without arguments it works on the planned arrays and returns
         the planned output array (aliasing is part of the contract, mpifft.py:75-79).
         ``normalize=True/False`` overrides the default (forward normalised, backward not)."""
-        src = None
+        src = dst = None
         if input_array is not None:
             # The reference copies the caller's array into the planned input array
             # (mpifft.py:65-66).  A device array of the planned shape/dtype is read in place
             # instead -- one full HBM round trip less; the first kernel only reads it.
             ref = self.input_array
-            if (isinstance(input_array, DeviceArray) and input_array is not ref
-                    and tuple(input_array.shape) == tuple(ref.shape) and input_array.dtype == ref.dtype
-                    and input_array.is_contiguous() and input_array.device == ref.device):
+            if self._direct(input_array, ref):
                 src = input_array
             elif input_array is not ref:
                 ref[...] = input_array
+        # ... and copies the planned output array into the caller's (mpifft.py:75-77): the last
+        # kernel writes a device array of the planned shape/dtype directly.
+        if output_array is not None and self._direct(output_array, self.output_array):
+            dst = output_array
+        io = {}
+        if src is not None:
+            io['src'] = src
         if self._fused is not None:
-            self._fused(src=src, **kw)
-            if output_array is not None:
+            if dst is not None:
+                io['dst'] = dst
+            self._fused(**io, **kw)
+            if output_array is not None and dst is None:
                 output_array[...] = self.output_array
-                return output_array
-            return self.output_array
-        for i in range(len(self._transfer)):
-            self._xfftn[i](**(dict(kw, src=src) if (i == 0 and src is not None) else kw))
+            return self.output_array if output_array is None else output_array
+        last = len(self._transfer)
+        for i in range(last):
+            self._xfftn[i](**(dict(kw, **io) if i == 0 else kw))
             arrayA = self._xfftn[i].output_array
             arrayB = self._xfftn[i + 1].input_array
             if arrayA is not arrayB:          # single-rank transfers share the buffer
                 self._transfer[i](arrayA, arrayB)
-        self._xfftn[-1](**(dict(kw, src=src) if (not self._transfer and src is not None) else kw))
-        if output_array is not None:
+        if dst is not None and not (last and self._xfftn[last].input_array.data_ptr == dst.data_ptr):
+            kw = dict(kw, dst=dst)
+        else:
+            dst = None
+        self._xfftn[last](**(dict(kw, **io) if last == 0 else kw))
+        if output_array is not None and dst is None:
             output_array[...] = self.output_array
-            return output_array
-        return self.output_array
+        return self.output_array if output_array is None else output_array
 
+    @staticmethod
+    def _direct(arr, ref):
+        """A caller's device array that a kernel can read / write in place of the planned one."""
+        return (isinstance(arr, DeviceArray) and arr is not ref and arr.data_ptr != ref.data_ptr
+                and tuple(arr.shape) == tuple(ref.shape) and arr.dtype == ref.dtype
+                and arr.is_contiguous() and arr.device == ref.device)
 
     def stage_times(self):
         """One synchronised execution on the planned arrays, timed stage by stage:
@@ -348,13 +364,13 @@ class PFFT:
         self._fused_plans = (fwd, bck)
         M = fwd.get_normalization()
 
-        def forward(src=None, **kw):
+        def forward(src=None, dst=None, **kw):
             normalize = kw.pop('normalize', True)
-            fwd.execute_scaled(U if src is None else src, V, M if normalize else 1.0)
+            fwd.execute_scaled(U if src is None else src, V if dst is None else dst, M if normalize else 1.0)
 
-        def backward(src=None, **kw):
+        def backward(src=None, dst=None, **kw):
             normalize = kw.pop('normalize', False)
-            bck.execute_scaled(V if src is None else src, U, M if normalize else 1.0)
+            bck.execute_scaled(V if src is None else src, U if dst is None else dst, M if normalize else 1.0)
 
         return forward, backward
 

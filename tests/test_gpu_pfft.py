@@ -9,6 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from tests import cases
+from oracle import pfft_oracle as O
 
 
 @pytest.mark.parametrize('name', cases.pfft_case_names())
@@ -240,3 +241,34 @@ def test_pack_fusion_on_device(monkeypatch):
         cases.check_pfft_vs_oracle(4, (40, 64, 64), 'd', padding=[1.5, 1.5, 1.5])
     monkeypatch.setenv('GFFT_FUSE_PACK', '0')
     cases.check_pfft_vs_oracle(8, (64, 64, 64), 'D')
+
+
+@pytest.mark.parametrize('P', [1, 2, 4])
+def test_callers_output_array_is_written_directly(P):
+    """forward(u, out) / backward(uh, out): the last kernel writes the caller's device array; the
+    planned output array is not staged through (mpifft.py:75-77 copies instead)."""
+    from mpi4py_fft_amd import PFFT, newDistArray
+    shape = (48, 32, 40)
+    ref = O.OPFFT(P, shape, dtype='d')
+    G = O.rng_array(shape, 'd', 3)
+    want = ref.forward(ref.scatter(G))
+
+    def body(comm):
+        fft = PFFT(comm, shape, dtype='d')
+        u = newDistArray(fft, False)
+        u[...] = G[fft.local_slice(False)]
+        out = newDistArray(fft, True)
+        planned = fft.forward.output_array
+        planned.fill(7)
+        assert fft.forward(u, out) is out
+        untouched = bool(np.all(np.asarray(planned) == 7))
+        back = newDistArray(fft, False)
+        assert fft.backward(out, back) is back
+        keep = np.asarray(out).copy()
+        host = np.zeros(fft.shape(True), dtype='D')
+        fft.forward(u, host)
+        return keep, np.asarray(back).copy(), host, fft.local_slice(False), untouched
+    for r, (uh, back, host, sl, untouched) in enumerate(cases.run_ranks(P, body)):
+        assert untouched
+        assert np.abs(uh - want[r]).max() < 1e-13 and np.abs(host - want[r]).max() < 1e-13
+        assert np.abs(back - G[sl]).max() < 1e-13

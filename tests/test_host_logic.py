@@ -216,3 +216,37 @@ def test_pack_fusion_bookkeeping(monkeypatch):
     def body0(comm):
         return [(t.packedA, t.packedB) for t in PFFT(comm, (16, 16, 16), dtype='D').transfer]
     assert thread_comm.run(4, body0)[0] == [(False, False), (False, False)]
+
+
+def test_callers_output_array_is_written_directly():
+    """forward(u, out) / backward(uh, out) with device arrays of the planned layout: the last kernel
+    writes `out` itself (no copy out of the planned array); other kinds of `out` are copied into."""
+    from tests import thread_comm
+    from mpi4py_fft_amd import PFFT, newDistArray
+    from oracle import pfft_oracle as O
+
+    for P in (1, 2, 4):
+        ref = O.OPFFT(P, (12, 8, 10), dtype='d')
+        G = O.rng_array((12, 8, 10), 'd', 3)
+        want = ref.forward(ref.scatter(G))
+
+        def body(comm):
+            fft = PFFT(comm, (12, 8, 10), dtype='d')
+            u = newDistArray(fft, False)
+            u[...] = G[fft.local_slice(False)]
+            out = newDistArray(fft, True)
+            planned = fft.forward.output_array
+            planned.fill(7)
+            r = fft.forward(u, out)
+            assert r is out
+            assert np.all(np.asarray(planned) == 7)          # untouched: nothing was staged through it
+            back = newDistArray(fft, False)
+            r2 = fft.backward(out, back)
+            assert r2 is back
+            host = np.zeros(fft.shape(True), dtype='D')
+            fft.forward(u, host)                             # numpy output: copied into
+            return np.asarray(out).copy(), np.asarray(back).copy(), host, fft.local_slice(False)
+        for r, (uh, back, host, sl) in enumerate(thread_comm.run(P, body)):
+            assert np.abs(uh - want[r]).max() < 1e-13
+            assert np.abs(host - want[r]).max() < 1e-13
+            assert np.abs(back - G[sl]).max() < 1e-13
