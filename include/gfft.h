@@ -44,6 +44,9 @@ typedef enum {
 
 /* transform kinds: same integers as the reference (fftw_planxfftn.c:3-8, utilities.pyx:7-26) */
 enum { GFFT_C2C_FORWARD = -1, GFFT_C2C_BACKWARD = +1, GFFT_R2C = -2, GFFT_C2R = +2 };
+/* real-to-real kinds: the integers of FFTW's fftw_r2r_kind as utilities.pyx:7-20 exposes them */
+enum { GFFT_REDFT00 = 3, GFFT_REDFT01 = 4, GFFT_REDFT10 = 5, GFFT_REDFT11 = 6,
+       GFFT_RODFT00 = 7, GFFT_RODFT01 = 8, GFFT_RODFT10 = 9, GFFT_RODFT11 = 10, GFFT_R2R = 100 };
 /* precision of the real type: float (fftwf_* clone, setup.py:93-111) or double */
 enum { GFFT_F32 = 4, GFFT_F64 = 8 };
 
@@ -64,6 +67,12 @@ int gfft_set_option(const char *key, int value);
  * side, as fftw_planxfftn.c:23 does.  */
 int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const int64_t *sizes_out,
                      int naxes, const int *axes, int kind, int precision);
+/* Real-to-real plan: the `default:` branch of fftw_planxfftn (fftw_planxfftn.c:68-75,
+ * fftw_plan_guru_r2r).  One kind per transformed axis (GFFT_REDFT00 .. GFFT_RODFT11 = DCT-I,
+ * DCT-III, DCT-II, DCT-IV, DST-I, DST-III, DST-II, DST-IV in FFTW's unnormalised definitions);
+ * input and output are real arrays of shape `sizes`; in-place execution is allowed. */
+int gfft_plan_create_r2r(gfft_plan *plan, int ndims, const int64_t *sizes, int naxes, const int *axes,
+                         const int *kinds, int precision);
 /* out = scale * DFT(in).  d_in == d_out is allowed for C2C.  C2C out-of-place preserves the
  * input; C2R with naxes > 1 overwrites it (as FFTW does).  */
 int gfft_execute(gfft_plan plan, const void *d_in, void *d_out, double scale, void *stream);

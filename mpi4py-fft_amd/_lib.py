@@ -36,6 +36,7 @@ def _declare(lib):
         'gfft_device_name': (c.c_int, [c.c_int, c.c_char_p, c.c_size_t]),
         'gfft_set_option': (c.c_int, [c.c_char_p, c.c_int]),
         'gfft_plan_create': (c.c_int, [c.POINTER(vp), c.c_int, i64p, i64p, c.c_int, ip, c.c_int, c.c_int]),
+        'gfft_plan_create_r2r': (c.c_int, [c.POINTER(vp), c.c_int, i64p, c.c_int, ip, ip, c.c_int]),
         'gfft_execute': (c.c_int, [vp, vp, vp, c.c_double, vp]),
         'gfft_plan_destroy': (c.c_int, [vp]),
         'gfft_plan_set_truncation': (c.c_int, [vp, c.c_int64]),
@@ -125,6 +126,14 @@ class HipEngine:
         ax = (ctypes.c_int * len(axes))(*[int(a) for a in axes])
         check(lib().gfft_plan_create(ctypes.byref(h), len(sizes_in), _i64(sizes_in), _i64(sizes_out),
                                      len(axes), ax, int(kind), int(precision)))
+        return h
+
+    def plan_create_r2r(self, sizes, axes, kinds, precision):
+        h = ctypes.c_void_p()
+        ax = (ctypes.c_int * len(axes))(*[int(a) for a in axes])
+        kd = (ctypes.c_int * len(kinds))(*[int(k) for k in kinds])
+        check(lib().gfft_plan_create_r2r(ctypes.byref(h), len(sizes), _i64(sizes), len(axes), ax, kd,
+                                         int(precision)))
         return h
 
     def plan_execute(self, h, tin, tout, scale):

@@ -21,7 +21,7 @@ template <typename T> __device__ __forceinline__ cx<T> cswap(cx<T> a) { return {
 // Column b of the batch decomposes as b = (o * mid + m) * inner + i; element e of that column
 // sits at  base + o*os + m*ms + i*is + e*es  (strides in units of the buffer's element type:
 // real scalars on the real side of r2c/c2r, complex otherwise).
-enum PassMode { MODE_C2C = 0, MODE_R2C = 1, MODE_C2R = 2 };
+enum PassMode { MODE_C2C = 0, MODE_R2C = 1, MODE_C2R = 2, MODE_R2R = 3 };
 
 struct PassDesc {
   int n;          // logical transform length
@@ -61,6 +61,11 @@ struct PointDesc {
   int conj;           // conjugate (embed: on load; extract: on store)
   const void *chirp;  // cx<real>[n]: exp(-i pi j^2 / n), or null
   const void *B;      // cx<real>[Lw]: FFT of the wrapped conjugate chirp (PK_MULB)
+  // MODE_R2R (DCT / DST kinds as one complex transform of the logical length Lw, plan.cpp
+  // plan_r2r_line): embed writes z[pos0 + j] = pre[j] * x[j], zeros elsewhere; extract writes
+  // y[k] = Re(post[k] * Z[idx0 + k]).  pre / post: cx<real>[n]
+  const void *pre, *post;
+  int pos0, idx0;
 };
 
 struct Factors {

@@ -165,7 +165,14 @@ embed_kernel(PointDesc p, const void *__restrict__ in, cx<real> *__restrict__ W)
     const int64_t rem = idx - o * p.Lw * p.inner;
     const int64_t j = rem / p.inner, i = rem - j * p.inner;
     cx<real> v = {0, 0};
-    if (j < p.n) {
+    if (p.mode == MODE_R2R) {
+      const int64_t jj = j - p.pos0;
+      if (jj >= 0 && jj < p.n) {
+        const real x = reinterpret_cast<const real *>(in)[(o * p.nin + jj) * p.inner + i];
+        const cx<real> a = reinterpret_cast<const cx<real> *>(p.pre)[jj];
+        v = {a.x * x, a.y * x};
+      }
+    } else if (j < p.n) {
       if (p.mode == MODE_R2C) {
         v.x = reinterpret_cast<const real *>(in)[(o * p.nin + j) * p.inner + i];
       } else if (p.mode == MODE_C2R) {
@@ -204,6 +211,12 @@ extract_kernel(PointDesc p, const cx<real> *__restrict__ W, void *__restrict__ o
     const int64_t o = idx / (p.nout * p.inner);
     const int64_t rem = idx - o * p.nout * p.inner;
     const int64_t k = rem / p.inner, i = rem - k * p.inner;
+    if (p.mode == MODE_R2R) {
+      const cx<real> z = W[(o * p.Lw + k + p.idx0) * p.inner + i];
+      const cx<real> b = reinterpret_cast<const cx<real> *>(p.post)[k];
+      reinterpret_cast<real *>(out)[idx] = (b.x * z.x - b.y * z.y) * scale;
+      continue;
+    }
     cx<real> v = W[(o * p.Lw + k) * p.inner + i];
     if (chirp) v = cmul(v, chirp[k]);
     if (p.conj) v.y = -v.y;

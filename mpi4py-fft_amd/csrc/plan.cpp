@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -476,6 +477,122 @@ int plan_embedded(gfft_plan_s *pl, const Line &L, bool bluestein) {
   return GFFT_OK;
 }
 
+// ---- real-to-real kinds (DCT / DST I-IV; FFTW's REDFTxx / RODFTxx, fftw_planxfftn.c:68-75) ------
+// Every kind is one complex DFT of its logical length N (2(n-1), 2n or 2(n+1): the figure
+// get_normalization uses, xfftn.py:763-806) between two pointwise passes:
+//   z[pos0 + j] = pre[j] x[j]  (zeros elsewhere)  ->  Z = DFT_N z  ->  y[k] = Re(post[k] Z[idx0 + k])
+// with (theta = pi/(2n))
+//   REDFT00  N=2(n-1)  pre = 1,2,...,2,1                         post = 1
+//   REDFT10  N=2n      pre = 1                                   post = 2 e^{-i k theta}
+//   REDFT01  N=2n      pre = (1,2,2,...) e^{-i j theta}          post = 1
+//   REDFT11  N=2n      pre = e^{-i j theta}                      post = 2 e^{-i (2k+1) theta/2}
+//   RODFT00  N=2(n+1)  pre = 1, pos0 = 1                         post = 2i, idx0 = 1
+//   RODFT10  N=2n      pre = 1                                   post = 2i e^{-i (k+1) theta}, idx0 = 1
+//   RODFT01  N=2n      pre = i (2,...,2,1) e^{-i (j+1) theta}, pos0 = 1      post = 1
+//   RODFT11  N=2n      pre = e^{-i j theta}                      post = 2i e^{-i (2k+1) theta/2}
+// (cos/sin sums written as real parts of complex exponentials).  The complex transform runs on
+// whatever plan_line picks for N, so every length works; the cost is that of a length-N complex
+// transform per n real samples -- these kinds are a convenience of the API, not its hot path.
+struct R2RTables { void *pre, *post; };
+std::map<std::tuple<int, int64_t, int>, R2RTables> g_r2r_cache;
+
+int64_t r2r_logical_n(int kind, int64_t n) {
+  if (kind == GFFT_REDFT00) return 2 * (n - 1);
+  if (kind == GFFT_RODFT00) return 2 * (n + 1);
+  return 2 * n;
+}
+
+int get_r2r_tables(int kind, int64_t n, int prec, R2RTables *out) {
+  std::lock_guard<std::mutex> lock(g_tw_mutex);
+  auto key = std::make_tuple(kind, n, prec);
+  auto it = g_r2r_cache.find(key);
+  if (it == g_r2r_cache.end()) {
+    const long double PI = 3.14159265358979323846264338327950288L;
+    const long double th = PI / (2.0L * (long double)n);
+    std::vector<long double> ar(n), ai(n), br(n), bi(n);
+    auto cis = [](long double a, long double *re, long double *im) { *re = cosl(a); *im = -sinl(a); };   // e^{-ia}
+    for (int64_t j = 0; j < n; ++j) {
+      long double pr = 1, pi_ = 0, qr = 1, qi = 0, c, sre, sim;
+      switch (kind) {
+        case GFFT_REDFT00: pr = (j == 0 || j == n - 1) ? 1 : 2; break;
+        case GFFT_REDFT10: cis(th * j, &sre, &sim); qr = 2 * sre; qi = 2 * sim; break;
+        case GFFT_REDFT01: c = j == 0 ? 1 : 2; cis(th * j, &sre, &sim); pr = c * sre; pi_ = c * sim; break;
+        case GFFT_REDFT11:
+          cis(th * j, &pr, &pi_);
+          cis(th * (2 * j + 1) / 2, &sre, &sim); qr = 2 * sre; qi = 2 * sim; break;
+        case GFFT_RODFT00: qr = 0; qi = 2; break;
+        case GFFT_RODFT10: cis(th * (j + 1), &sre, &sim); qr = -2 * sim; qi = 2 * sre; break;      // 2i (sre + i sim)
+        case GFFT_RODFT01:
+          c = j == n - 1 ? 1 : 2; cis(th * (j + 1), &sre, &sim); pr = -c * sim; pi_ = c * sre; break;   // i c (..)
+        case GFFT_RODFT11:
+          cis(th * j, &pr, &pi_);
+          cis(th * (2 * j + 1) / 2, &sre, &sim); qr = -2 * sim; qi = 2 * sre; break;
+      }
+      ar[j] = pr; ai[j] = pi_; br[j] = qr; bi[j] = qi;
+    }
+    auto upload = [&](const std::vector<long double> &xr, const std::vector<long double> &xi, void **dst) -> int {
+      std::vector<unsigned char> h(xr.size() * 2 * prec);
+      for (size_t j = 0; j < xr.size(); ++j) {
+        if (prec == 8) { ((double *)h.data())[2 * j] = (double)xr[j]; ((double *)h.data())[2 * j + 1] = (double)xi[j]; }
+        else { ((float *)h.data())[2 * j] = (float)xr[j]; ((float *)h.data())[2 * j + 1] = (float)xi[j]; }
+      }
+      HIP_TRY(hipMalloc(dst, h.size()));
+      HIP_TRY(hipMemcpy(*dst, h.data(), h.size(), hipMemcpyHostToDevice));
+      return GFFT_OK;
+    };
+    R2RTables t{nullptr, nullptr};
+    int rc = upload(ar, ai, &t.pre);
+    if (rc) return rc;
+    rc = upload(br, bi, &t.post);
+    if (rc) return rc;
+    it = g_r2r_cache.emplace(key, t).first;
+  }
+  *out = it->second;
+  return GFFT_OK;
+}
+
+// one real-to-real axis: [outer][n][inner] real -> same shape; src/dst in {BUF_IN, BUF_OUT}
+int plan_r2r_line(gfft_plan_s *pl, int64_t outer, int64_t n, int64_t inner, int kind, int src, int dst) {
+  const int prec = pl->precision;
+  if (kind == GFFT_REDFT00 && n < 2) return fail(GFFT_ERR_INVALID, "REDFT00 needs at least two points");
+  const int64_t N = r2r_logical_n(kind, n);
+  R2RTables t;
+  int rc = get_r2r_tables(kind, n, prec, &t);
+  if (rc) return rc;
+  need(pl, BUF_WS, (size_t)outer * N * inner * 2 * prec);
+  PointDesc pt{};
+  pt.outer = outer;
+  pt.inner = inner;
+  pt.n = n;
+  pt.nin = pt.nout = n;
+  pt.Lw = N;
+  pt.mode = MODE_R2R;
+  pt.pre = t.pre;
+  pt.post = t.post;
+  pt.pos0 = (kind == GFFT_RODFT00 || kind == GFFT_RODFT01) ? 1 : 0;
+  pt.idx0 = (kind == GFFT_RODFT00 || kind == GFFT_RODFT10) ? 1 : 0;
+  Pass e;
+  e.kind = PK_EMBED;
+  e.pt = pt;
+  e.src = src;
+  e.dst = BUF_WS;
+  e.logical_first = true;
+  pl->passes.push_back(e);
+  Line C{outer, inner, N, N, N, MODE_C2C, false, BUF_WS, BUF_WS};
+  rc = plan_line(pl, C, false);
+  if (rc) return rc;
+  Pass x;
+  x.kind = PK_EXTRACT;
+  x.pt = pt;
+  x.src = BUF_WS;
+  x.dst = dst;
+  pl->passes.push_back(x);
+  const double lines = (double)outer * (double)inner;
+  pl->flops += 2.5 * (double)N * std::log2((double)(N > 1 ? N : 2)) * lines;
+  pl->bytes += lines * 2.0 * (double)n * prec;
+  return GFFT_OK;
+}
+
 int64_t max_prime_factor(int64_t n) {
   int64_t m = 1;
   for (int64_t p = 2; p * p <= n; ++p)
@@ -834,6 +951,51 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
     return rc;
   }
   // the scale factor rides on the last pass
+  pl->passes.back().carries_scale = true;
+  *plan = pl;
+  return GFFT_OK;
+}
+
+int gfft_plan_create_r2r(gfft_plan *plan, int ndims, const int64_t *sizes, int naxes, const int *axes,
+                         const int *kinds, int precision) {
+  if (!plan || !sizes || !axes || !kinds) return fail(GFFT_ERR_INVALID, "null argument");
+  *plan = nullptr;
+  if (ndims < 1 || ndims > 16 || naxes < 1 || naxes > ndims) return fail(GFFT_ERR_INVALID, "bad ndims/naxes");
+  if (precision != GFFT_F32 && precision != GFFT_F64) return fail(GFFT_ERR_INVALID, "precision must be 4 or 8");
+  std::vector<int> ax(axes, axes + naxes);
+  std::vector<char> seen(ndims, 0);
+  for (int i = 0; i < naxes; ++i) {
+    int &a = ax[i];
+    if (a < 0) a += ndims;
+    if (a < 0 || a >= ndims || seen[a]) return fail(GFFT_ERR_INVALID, "bad or repeated axis");
+    seen[a] = 1;
+    if (kinds[i] < GFFT_REDFT00 || kinds[i] > GFFT_RODFT11)
+      return fail(GFFT_ERR_UNSUPPORTED, "r2r kind must be one of REDFT00..RODFT11 (halfcomplex / DHT kinds are not implemented)");
+  }
+  for (int i = 0; i < ndims; ++i)
+    if (sizes[i] < 1) return fail(GFFT_ERR_INVALID, "sizes must be >= 1");
+  int rc = check_device();
+  if (rc) return rc;
+  gfft_plan_s *pl = new gfft_plan_s;
+  pl->ndims = ndims;
+  pl->kind = GFFT_R2R;
+  pl->precision = precision;
+  pl->sizes_in.assign(sizes, sizes + ndims);
+  pl->sizes_out = pl->sizes_in;
+  pl->axes = ax;
+  pl->variant_rows = opts().variant_rows;
+  pl->variant_cols = opts().variant_cols;
+  pl->xcd_swizzle = opts().xcd_swizzle;
+  for (int i = naxes - 1; i >= 0 && !rc; --i) {
+    int64_t outer = 1, inner = 1;
+    for (int k = 0; k < ax[i]; ++k) outer *= sizes[k];
+    for (int k = ax[i] + 1; k < ndims; ++k) inner *= sizes[k];
+    rc = plan_r2r_line(pl, outer, sizes[ax[i]], inner, kinds[i], i == naxes - 1 ? BUF_IN : BUF_OUT, BUF_OUT);
+  }
+  if (rc) {
+    delete pl;
+    return rc;
+  }
   pl->passes.back().carries_scale = true;
   *plan = pl;
   return GFFT_OK;

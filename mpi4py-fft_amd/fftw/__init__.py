@@ -5,8 +5,10 @@ aligned_like, get_alignment, get_normalization, fftlib, FFTW_*``), so code writt
 reference's FFTW wrapper runs on the MI355X engine.  A planner function allocates the output
 array, computes the ``1/M`` normalisation and returns a plan object (:class:`FFT`) that owns a
 ``gfft_plan`` handle of libgfft.so; calling the object executes the plan on the bound device
-arrays.  Real-to-real kinds (dctn/dstn/...) and hfftn/ihfftn, wisdom and time limits are FFTW
-features outside this path: asking for them raises ``NotImplementedError``.
+arrays.  The real-to-real planners ``dctn, idctn, dstn, idstn`` (types 1-4, FFTW's unnormalised
+REDFTxx / RODFTxx definitions) plan through ``gfft_plan_create_r2r``.  hfftn/ihfftn, the
+halfcomplex / Hartley kinds, wisdom and time limits are FFTW features outside this path: asking
+for them raises ``NotImplementedError``.
 """
 import numpy as np
 
@@ -53,12 +55,20 @@ class FFT:
     (fftw_xfftn.pyx:50-296).  Holds a ``gfft_plan`` plus the arrays it was planned for."""
     def __init__(self, input_array, output_array, axes=(-1,), kind=FFTW_FORWARD, threads=1,
                  flags=FFTW_MEASURE, normalization=1.0):
-        kind = kind[0] if isinstance(kind, (list, tuple)) else kind
-        if kind not in (C2C_FORWARD, C2C_BACKWARD, R2C, C2R):
-            raise NotImplementedError('real-to-real transform kinds are outside the PFFT hot path')
         nd = len(input_array.shape)
         self.axes = tuple(a + nd if a < 0 else a for a in axes)
-        self.kind = kind
+        kinds = list(kind) if isinstance(kind, (list, tuple)) else [kind]
+        r2r = all(FFTW_REDFT00 <= k <= FFTW_RODFT11 for k in kinds)
+        if r2r:
+            # one kind per axis (fftw_planxfftn.c:68-75)
+            kinds = kinds * len(self.axes) if len(kinds) == 1 else kinds
+            assert len(kinds) == len(self.axes)
+            assert tuple(input_array.shape) == tuple(output_array.shape)
+        else:
+            kind = kinds[0]
+            if kind not in (C2C_FORWARD, C2C_BACKWARD, R2C, C2R):
+                raise NotImplementedError('halfcomplex / Hartley kinds (R2HC, HC2R, DHT) are not implemented')
+        self.kind = tuple(kinds) if r2r else kind
         self._M = float(normalization)
         self._input_array = input_array
         self._output_array = output_array
@@ -67,8 +77,11 @@ class FFT:
         self._precision = _lib.precision_of(input_array.dtype)
         self._eng = _lib.engine()
         try:
-            self._plan = self._eng.plan_create(self.input_shape, self.output_shape, self.axes,
-                                               kind, self._precision)
+            if r2r:
+                self._plan = self._eng.plan_create_r2r(self.input_shape, self.axes, self.kind, self._precision)
+            else:
+                self._plan = self._eng.plan_create(self.input_shape, self.output_shape, self.axes,
+                                                   kind, self._precision)
         except _lib.GfftError as e:
             # same failure mode as fftw_xfftn.pyx:152-153
             raise RuntimeError('Failure creating gfft plan: %s' % e)
@@ -160,7 +173,8 @@ class FFT:
 
 def get_planned_FFT(input_array, output_array, axes=(-1,), kind=FFTW_FORWARD, threads=1,
                     flags=(FFTW_MEASURE,), normalization=1.0):
-    assert input_array.dtype.char.upper() in fftlib
+    assert input_array.dtype.char.upper() in fftlib, 'long double has no GPU type'
+    _check_in(input_array)
     return FFT(input_array, output_array, axes, kind, threads, flags, normalization)
 
 
@@ -232,30 +246,70 @@ def irfftn(input_array, s=None, axes=(-1,), threads=1, flags=(FFTW_MEASURE,), ou
     return get_planned_FFT(input_array, output_array, axes, C2R, threads, flags, 1.0 / M)
 
 
+# real-to-real planners (xfftn.py:14-36,328-614): `type` selects the FFTW kind per the tables below
+dct_type = {1: FFTW_REDFT00, 2: FFTW_REDFT10, 3: FFTW_REDFT01, 4: FFTW_REDFT11}
+idct_type = {1: FFTW_REDFT00, 2: FFTW_REDFT01, 3: FFTW_REDFT10, 4: FFTW_REDFT11}
+dst_type = {1: FFTW_RODFT00, 2: FFTW_RODFT10, 3: FFTW_RODFT01, 4: FFTW_RODFT11}
+idst_type = {1: FFTW_RODFT00, 2: FFTW_RODFT01, 3: FFTW_RODFT10, 4: FFTW_RODFT11}
+
+
+def _r2r_planner(name, table):
+    def plan(input_array, s=None, axes=(-1,), type=2, threads=1, flags=(FFTW_MEASURE,), output_array=None):
+        _check_in(input_array)
+        assert input_array.dtype.char in 'fd'
+        if output_array is None:
+            output_array = aligned_like(input_array)
+        else:
+            assert tuple(input_array.shape) == tuple(output_array.shape)
+        kind = [table[type]] * len(axes)
+        M = get_normalization(kind, input_array.shape, axes)
+        return get_planned_FFT(input_array, output_array, axes, kind, threads, flags, M)
+    plan.__name__ = name
+    plan.__doc__ = ('Plan a real-to-real %s over `axes`; `type` 1-4 -> %s (xfftn.py:328-614).  '
+                    'Unnormalised FFTW definitions; `s` is unused.' % (name, sorted(table.items())))
+    return plan
+
+
+dctn, idctn = _r2r_planner('dctn', dct_type), _r2r_planner('idctn', idct_type)
+dstn, idstn = _r2r_planner('dstn', dst_type), _r2r_planner('idstn', idst_type)
+
+
 def _out_of_scope(name):
     def f(*a, **k):
-        raise NotImplementedError('%s: real-to-real / halfcomplex transforms are FFTW features '
-                                  'outside the PFFT hot path this package accelerates' % name)
+        raise NotImplementedError('%s: halfcomplex transforms are an FFTW feature outside the PFFT '
+                                  'path this package accelerates' % name)
     f.__name__ = name
     return f
 
 
-dctn, idctn, dstn, idstn = (_out_of_scope(n) for n in ('dctn', 'idctn', 'dstn', 'idstn'))
 hfftn, ihfftn = _out_of_scope('hfftn'), _out_of_scope('ihfftn')
 
 
 def get_normalization(kind, shape, axes):
-    """1/prod(N) over the transformed axes (xfftn.py:763-816, Fourier kinds only)."""
-    kind = [kind] * len(axes) if isinstance(kind, int) else kind
+    """1 / product of the logical lengths of the transformed axes (xfftn.py:763-816): N for the
+    Fourier kinds, 2(N-1) for REDFT00, 2(N+1) for RODFT00, 2N for the other real-to-real kinds."""
+    kind = [kind] * len(axes) if isinstance(kind, (int, np.integer)) else kind
+    assert len(kind) == len(axes)
     M = 1
     for knd, axis in zip(kind, axes):
-        if knd not in (FFTW_FORWARD, FFTW_BACKWARD, R2C, C2R):
-            raise NotImplementedError('real-to-real kinds are outside the PFFT hot path')
-        M *= shape[axis]
+        N = shape[axis]
+        if knd == FFTW_RODFT00:
+            M *= 2 * (N + 1)
+        elif knd == FFTW_REDFT00:
+            M *= 2 * (N - 1)
+        elif knd in (FFTW_RODFT01, FFTW_RODFT10, FFTW_RODFT11, FFTW_REDFT01, FFTW_REDFT10, FFTW_REDFT11):
+            M *= 2 * N
+        elif knd in (FFTW_FORWARD, FFTW_BACKWARD, R2C, C2R):
+            M *= N
+        else:
+            raise NotImplementedError('halfcomplex / Hartley kinds are not implemented')
     return 1. / M
 
 
-inverse = {rfftn: irfftn, irfftn: rfftn, fftn: ifftn, ifftn: fftn}
+inverse = {FFTW_RODFT11: FFTW_RODFT11, FFTW_REDFT11: FFTW_REDFT11, FFTW_RODFT01: FFTW_RODFT10,
+           FFTW_RODFT10: FFTW_RODFT01, FFTW_REDFT01: FFTW_REDFT10, FFTW_REDFT10: FFTW_REDFT01,
+           FFTW_RODFT00: FFTW_RODFT00, FFTW_REDFT00: FFTW_REDFT00,
+           rfftn: irfftn, irfftn: rfftn, fftn: ifftn, ifftn: fftn}
 
 
 class _PrecisionLib:

@@ -132,12 +132,32 @@ def _fftmod(workers):
     return np.fft, {}
 
 
+# FFTW's real-to-real kinds (utilities.pyx:12-19) in scipy's (family, type) numbering; scipy's
+# unnormalised ("backward") transforms are FFTW's definitions -- the reference's own tests pin its
+# r2r plans against scipy.fftpack the same way (tests/test_fftw.py:101-118).
+R2R_KINDS = {3: ('dct', 1), 5: ('dct', 2), 4: ('dct', 3), 6: ('dct', 4),
+             7: ('dst', 1), 9: ('dst', 2), 8: ('dst', 3), 10: ('dst', 4)}
+R2R_INVERSE = {3: 3, 4: 5, 5: 4, 6: 6, 7: 7, 8: 9, 9: 8, 10: 10}       # xfftn.py:818-826
+
+
+def r2r_1d(a, axis, kind):
+    import scipy.fft
+    fam, typ = R2R_KINDS[int(kind)]
+    f = scipy.fft.dct if fam == 'dct' else scipy.fft.dst
+    return f(np.asarray(a, dtype=np.result_type(a.dtype, np.float32)), type=typ, axis=axis, norm=None)
+
+
+def r2r_logical_n(kind, n):
+    """Per-axis normalisation length (xfftn.py:763-816)."""
+    return 2 * (n - 1) if kind == 3 else 2 * (n + 1) if kind == 7 else 2 * n
+
+
 class OFFT:
     """Serial transform over `axes` of an array of `shape` with the reference's conventions
     (libfft.py:376-422): forward multiplies by 1/prod(N_axes) unless normalize=False, backward
     is unscaled unless normalize=True; real input -> r2c along axes[-1]; optional 3/2-rule
     padding on a single axis (libfft.py:263-311)."""
-    def __init__(self, shape, axes=None, dtype='d', padding=False, workers=None):
+    def __init__(self, shape, axes=None, dtype='d', padding=False, workers=None, r2r=None):
         self.shape = tuple(int(s) for s in shape)
         nd = len(self.shape)
         self.axes = tuple(range(nd)) if axes is None else tuple(a % nd for a in np.atleast_1d(axes))
@@ -147,6 +167,17 @@ class OFFT:
         self.cdtype = np.dtype(self.dtype.char.upper())
         self.M = 1.0 / float(np.prod([self.shape[a] for a in self.axes]))
         self.workers = workers
+        # r2r: FFTW kind (3..10) of the FORWARD transform, one int for all axes of the group or one
+        # per axis (the `transforms=` dict of libfft.py:330-340 with dctn / dstn planners)
+        self.r2r = None
+        if r2r is not None:
+            assert self.real and padding is False
+            self.r2r = [int(r2r)] * len(self.axes) if np.ndim(r2r) == 0 else [int(k) for k in r2r]
+            self.M = 1.0 / float(np.prod([r2r_logical_n(k, self.shape[a]) for k, a in zip(self.r2r, self.axes)]))
+            self.cdtype = self.dtype
+            self.padding_factor = 1.0
+            self.full_out_shape = self.out_shape = self.shape
+            return
         pf = padding[self.axes[-1]] if np.ndim(padding) else (padding or 1.0)
         self.padding_factor = float(pf) if padding is not False else 1.0
         out = list(self.shape)
@@ -212,6 +243,11 @@ class OFFT:
         mod, kw = _fftmod(self.workers)
         u = np.asarray(u)
         assert u.shape == self.shape
+        if self.r2r is not None:
+            V = u
+            for a, k in zip(self.axes, self.r2r):
+                V = r2r_1d(V, a, k)
+            return (V * self.M if normalize else V).astype(self.dtype, copy=False)
         s = [self.shape[a] for a in self.axes]
         V = (mod.rfftn if self.real else mod.fftn)(u, s=s, axes=self.axes, **kw)
         V = V.astype(self.cdtype, copy=False)
@@ -225,6 +261,11 @@ class OFFT:
         mod, kw = _fftmod(self.workers)
         V = np.asarray(V)
         assert V.shape == self.out_shape, (V.shape, self.out_shape)
+        if self.r2r is not None:
+            u = V
+            for a, k in zip(self.axes, self.r2r):
+                u = r2r_1d(u, a, R2R_INVERSE[k])
+            return (u * self.M if normalize else u).astype(self.dtype, copy=False)
         if self.padded:
             V = self._pad(V)
         s = [self.shape[a] for a in self.axes]
@@ -259,7 +300,9 @@ class OPFFT:
     mpifft.py:46-79 (execution): FFT_0, T_0, FFT_1, T_1, ... with the group order
     axes[-1], axes[-2], ... forward and the mirror backward."""
     def __init__(self, nranks, shape, axes=None, dtype='d', grid=None, padding=False,
-                 collapse=False, workers=None):
+                 collapse=False, workers=None, r2r=None):
+        # r2r: {axes group (tuple): forward FFTW kind(s)} -- the oracle's spelling of `transforms=`
+        r2r = {} if r2r is None else {tuple(k): v for k, v in r2r.items()}
         shape = [int(s) for s in shape]
         nd = len(shape)
         groups = normalize_axes(axes, nd)
@@ -307,7 +350,7 @@ class OPFFT:
             g = self.axes[-1]
             pen = OPencil(sizes, ranks, shp, g[-1])
             self.pencil_in.append(pen)
-            f = OFFT(pen.subshape, g, dt, padding, workers)
+            f = OFFT(pen.subshape, g, dt, padding, workers, r2r.get(tuple(g)))
             self.ffts[r].append(f)
             if f.out_shape[g[-1]] != shp[g[-1]]:
                 dt = f.cdtype
@@ -319,7 +362,7 @@ class OPFFT:
                 # communicator = the one axis g[-1] was distributed over before the swap
                 trs.append((pen.axis, penB.axis, owner[g[-1]], shp[g[-1]]))
                 owner[pen.axis], owner[penB.axis] = owner[penB.axis], owner[pen.axis]
-                f = OFFT(penB.subshape, g, dt, padding, workers)
+                f = OFFT(penB.subshape, g, dt, padding, workers, r2r.get(tuple(g)))
                 self.ffts[r].append(f)
                 pen = penB
                 if f.out_shape[g[-1]] != shp[g[-1]]:

@@ -26,10 +26,14 @@ class HostEngine:
         return dict(sizes_in=tuple(sizes_in), sizes_out=tuple(sizes_out), axes=tuple(axes),
                     kind=kind, precision=precision)
 
+    def plan_create_r2r(self, sizes, axes, kinds, precision):
+        return dict(sizes_in=tuple(sizes), sizes_out=tuple(sizes), axes=tuple(axes), kind='r2r',
+                    kinds=tuple(kinds), precision=precision)
+
     def plan_set_split(self, h, side, nblocks):
         # same acceptance rule as gfft_plan_set_split for what this checker can see
         n = h['sizes_in'][h['axes'][0]]
-        if len(h['axes']) != 1 or h['kind'] not in (-1, 1) or nblocks & (nblocks - 1) or nblocks > 8 or n % nblocks:
+        if len(h['axes']) != 1 or h['kind'] not in (-1, 1) or h['kind'] == 'r2r' or nblocks & (nblocks - 1) or nblocks > 8 or n % nblocks:
             return False
         h['split_in' if side == 0 else 'split_out'] = nblocks
         return True
@@ -50,6 +54,12 @@ class HostEngine:
             return
         a = _np(tin).reshape(h['sizes_in'])
         axes, kind = h['axes'], h['kind']
+        if kind == 'r2r':
+            r = a
+            for ax, k in zip(axes, h['kinds']):
+                r = O.r2r_1d(r, ax, k)
+            _np(tout).reshape(h['sizes_out'])[...] = (r * scale).astype(_np(tout).dtype)
+            return
         if kind == -1:
             r = np.fft.fftn(a, axes=axes)
         elif kind == 1:

@@ -80,7 +80,7 @@ def test_misuse_raises():
         FFT((8, 8), dtype='D', backend='numpy')
     with pytest.raises(NotImplementedError):
         from mpi4py_fft_amd import fftw
-        fftw.dctn(None)
+        fftw.hfftn(None)
 
 
 def test_chunked_transfer_pipeline(monkeypatch):
@@ -250,3 +250,35 @@ def test_callers_output_array_is_written_directly():
             assert np.abs(uh - want[r]).max() < 1e-13
             assert np.abs(host - want[r]).max() < 1e-13
             assert np.abs(back - G[sl]).max() < 1e-13
+
+
+def test_r2r_transforms_orchestration():
+    """`transforms=` with real-to-real planners through PFFT on thread ranks (host checker engine):
+    stage dtypes, normalisation (logical lengths 2N / 2(N-1) / 2(N+1)) and the Fourier stage on
+    the remaining axis (tests/test_mpifft.py:35-57)."""
+    import functools
+    from tests import thread_comm
+    from mpi4py_fft_amd import PFFT, newDistArray, fftw
+    from oracle import pfft_oracle as O
+    assert fftw.get_normalization([fftw.FFTW_REDFT00, fftw.FFTW_RODFT00, fftw.FFTW_REDFT10, fftw.FFTW_FORWARD],
+                                  (5, 6, 7, 8), (0, 1, 2, 3)) == 1.0 / (8 * 14 * 14 * 8)
+    dct = functools.partial(fftw.dctn, type=1)
+    idct = functools.partial(fftw.idctn, type=1)
+    dst = functools.partial(fftw.dstn, type=4)
+    idst = functools.partial(fftw.idstn, type=4)
+    shape, axes = (8, 9, 10), ((0,), (1,), (2,))
+    tr = {(2,): (dct, idct), (1,): (dst, idst)}
+    for P in (1, 2, 4):
+        ref = O.OPFFT(P, shape, axes=axes, dtype='d', r2r={(2,): fftw.FFTW_REDFT00, (1,): fftw.FFTW_RODFT11})
+        G = O.rng_array(shape, 'd', 4)
+        want = ref.forward(ref.scatter(G))
+
+        def body(comm):
+            fft = PFFT(comm, shape, axes=axes, dtype='d', transforms=tr)
+            u = newDistArray(fft, False)
+            u[...] = G[fft.local_slice(False)]
+            uh = np.asarray(fft.forward(u)).copy()
+            return uh, np.asarray(fft.backward()).copy(), fft.local_slice(False)
+        for r, (uh, back, sl) in enumerate(thread_comm.run(P, body)):
+            assert uh.dtype == want[r].dtype and np.abs(uh - want[r]).max() < 1e-13
+            assert np.abs(back - G[sl]).max() < 1e-12
