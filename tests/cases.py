@@ -140,6 +140,16 @@ def check_pfft_vs_oracle(P, shape, dt, seed=7, **kw):
 
     def body(comm):
         k = {a: (list(b) if isinstance(b, list) else b) for a, b in kw.items()}
+        if 'r2r' in k:
+            # the oracle's {axes: FFTW kind} spelled as the product's `transforms=` dict of planners
+            import functools
+            from mpi4py_fft_amd import fftw
+            tr = {}
+            for axes_, kind in k.pop('r2r').items():
+                fam, typ = O.R2R_KINDS[kind]
+                fwd, bck = (fftw.dctn, fftw.idctn) if fam == 'dct' else (fftw.dstn, fftw.idstn)
+                tr[tuple(axes_)] = (functools.partial(fwd, type=typ), functools.partial(bck, type=typ))
+            k['transforms'] = tr
         fft = PFFT(comm, shape, dtype=dt, **k)
         u = newDistArray(fft, False)
         u[...] = G[fft.local_slice(False)]
