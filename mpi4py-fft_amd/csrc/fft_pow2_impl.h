@@ -515,7 +515,9 @@ __device__ __forceinline__ void tile_store_trunc(const PassDesc &d, void *__rest
 }
 
 // FLAGS: 1 = non-temporal loads, 2 = non-temporal stores, 4 = skip the transform (access-pattern
-// probe), 8 = c2c only, 16 = fused truncation / padding adapters (d.tr_dir: 1 store, 2 load)
+// probe), 8 = c2c only, 16 = fused truncation / padding adapters (d.tr_dir: 1 store, 2 load),
+// 32 = transposing store (strided kernels whose OUTPUT is contiguous along the transform axis:
+// the first pass of a four-step transform)
 template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int MODE, bool BIGTW, int... RADS>
 __global__ void __launch_bounds__(T *(N / R), MINW)
 fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
@@ -625,7 +627,55 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
           if (t + q * NT == h) v[q] = v[q] + fold[c];
       }
     }
-    if (valid) {
+    if constexpr ((FLAGS & 32) != 0) {
+      // Transposing store.  Loads ran with lanes along T adjacent columns (T*16-byte segments of the
+      // strided input); the output of each column is one contiguous line, so storing in the same
+      // mapping would write T short runs per instruction.  Finish the element-wise work here
+      // (four-step twiddle, scale), transpose the thread grid through LDS -- thread (c, t) hands
+      // its R values to thread (c' = tid / NT, t' = tid % NT), same slots e = t' + q*NT -- and
+      // store with lanes along e: whole 64-lane rows of one output line.
+      static_assert(COLS && SPLIT && BIGTW && MODE == MODE_C2C, "transposing store: first four-step pass");
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        if constexpr (BIGTW) {
+          const unsigned x = m * (unsigned)(t + q * NT);
+          const cx<real> a = reinterpret_cast<const cx<real> *>(d.tw_hi)[x >> d.tw_L];
+          const cx<real> b = reinterpret_cast<const cx<real> *>(d.tw_lo)[x & ((1u << d.tw_L) - 1)];
+          v[q] = cmul(v[q], cmul(a, b));
+        }
+        v[q].x *= sx_out;
+        v[q].y *= sy_out;
+      }
+      constexpr bool PAD = is_pow2_c(N);
+      const int c2 = tid / NT, t2 = tid % NT;
+      real *w = reinterpret_cast<real *>(col);
+      real *r = reinterpret_cast<real *>(smem + (size_t)c2 * CS * WORD);
+      const int wb = pad_slot<PAD>(t), rb = pad_slot<PAD>(t2);
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < R; ++q) w[wb + pad_slot<PAD>(q * NT)] = v[q].x;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < R; ++q) v[q].x = r[rb + pad_slot<PAD>(q * NT)];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < R; ++q) w[wb + pad_slot<PAD>(q * NT)] = v[q].y;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < R; ++q) v[q].y = r[rb + pad_slot<PAD>(q * NT)];
+      // the column this thread now stores (flat tiling, as the BIGTW passes use)
+      const unsigned b2 = tile * T + c2;
+      if (b2 < batch) {
+        const unsigned bm2 = b2 / inner, i2 = b2 - bm2 * inner, o2 = bm2 / mid, m2 = bm2 - o2 * mid;
+        int64_t idx = (int64_t)o2 * d.out_os + (int64_t)m2 * d.out_ms + (int64_t)i2 * d.out_is +
+                      (int64_t)t2 * d.out_es;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          stc<real, false>(reinterpret_cast<cx<real> *>(out) + idx, v[q]);
+          idx += q_out;
+        }
+      }
+    } else if (valid) {
       int64_t idx = out0 + t_out;
       int cnt = 0;
 #pragma unroll
@@ -654,7 +704,7 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   constexpr int NT = N / R;
   constexpr int threads = T * NT;
   static_assert(threads >= 64 && threads <= 1024, "workgroup size");
-  constexpr size_t lds_x = (sizeof...(RADS) > 1) ? (size_t)T * Lds<N, COLS, T>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
+  constexpr size_t lds_x = (sizeof...(RADS) > 1 || (FLAGS & 32)) ? (size_t)T * Lds<N, COLS, T>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
   constexpr size_t lds_f = (FLAGS & 16) ? (size_t)T * 2 * sizeof(real) : 0;
   constexpr size_t lds = lds_x > lds_f ? lds_x : lds_f;
   static_assert(lds <= 160 * 1024, "LDS budget");
@@ -686,18 +736,19 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
 template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int... RADS>
 hipError_t launch_pow2_inst(const PassDesc &d, const void *in, void *out, hipStream_t s) {
   // FLAGS & 8: complex-to-complex, no four-step twiddle (fewer instantiations of fat configurations)
-  if (d.tw_hi) {
-    if constexpr (FLAGS != 0) {
-      return hipErrorInvalidValue;
-    } else {
-      if (d.mode != MODE_C2C) return hipErrorInvalidValue;
-      return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, true, RADS...>(d, in, out, s);
-    }
-  }
-  if constexpr (FLAGS != 0) {
+  if constexpr ((FLAGS & 32) != 0) {
+    // transposing store: complex strided pass, with or without the four-step twiddle
+    if (d.mode != MODE_C2C || d.tr_dir || d.in_lgp || d.out_lgp || !d.tw_hi) return hipErrorInvalidValue;
+    return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, true, RADS...>(d, in, out, s);
+  } else if constexpr (FLAGS != 0) {
+    if (d.tw_hi) return hipErrorInvalidValue;
     if (d.mode != MODE_C2C || d.tr_dir) return hipErrorInvalidValue;
     return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, false, RADS...>(d, in, out, s);
   } else {
+    if (d.tw_hi) {
+      if (d.mode != MODE_C2C) return hipErrorInvalidValue;
+      return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, true, RADS...>(d, in, out, s);
+    }
     if (d.tr_dir == 1 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2C, false, RADS...>(d, in, out, s);
     if (d.tr_dir == 1 && d.mode == MODE_R2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_R2C, false, RADS...>(d, in, out, s);
     if (d.tr_dir == 2 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2C, false, RADS...>(d, in, out, s);
