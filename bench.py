@@ -16,6 +16,7 @@ import argparse
 import json
 import os
 import sys
+import re
 import threading
 import time
 
@@ -171,7 +172,14 @@ def main():
         def stages(tr):
             st = tr.stage_times()
             allst = world.allgather_obj([b for _, b in st])
-            return [[st[i][0], round(max(r[i] for r in allst) * 1e3, 3)] for i in range(len(st))]
+            out_ = []
+            for i in range(len(st)):
+                label, ms = st[i][0], max(r[i] for r in allst) * 1e3
+                mb = re.search(r'([0-9.]+) MB out', label)
+                if mb and ms > 0:        # per-GPU outgoing wire rate of this exchange
+                    label += ' = %.1f GB/s per GPU' % (float(mb.group(1)) / ms)
+                out_.append([label, round(ms, 3)])
+            return out_
         extras['stages_ms'] = {'forward': stages(fft.forward), 'backward': stages(fft.backward)}
         if sum(1 for c in grid if c > 1) > 1 and n % size == 0 and not args.no_slab:
             fft.destroy()

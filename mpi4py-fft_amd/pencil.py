@@ -211,12 +211,14 @@ class Transfer:
         else:
             self.comm.alltoall(self._real_view(send), self._real_view(recv),
                                [c * mult for c in counts_src], [c * mult for c in counts_dst])
-        tick('exchange[%s p=%d]' % ('relay' if use_relay else 'direct', p))
+        me = self.comm.Get_rank()
+        wire = sum(c for i, c in enumerate(counts_src) if i != me) * isz
+        tick('exchange[%s p=%d %.1f MB out]' % ('relay' if use_relay else 'direct', p, wire / 1e6), wire)
         if not direct:
             eng.unpack(recv, td, shape_dst, axis_dst, p, isz)
             tick('unpack')
 
-    def _tick(self, name):
+    def _tick(self, name, nbytes=None):
         """Stage timing for bench.py's breakdown (only when `trace` is a list; synchronises)."""
         if self.trace is None:
             return
