@@ -30,38 +30,36 @@ class DistArray(DeviceArray):
     def __init__(self, global_shape, subcomm=None, val=None, dtype=float, buffer=None,
                  strides=None, alignment=None, rank=0):
         global_shape = tuple(int(s) for s in global_shape)
-        if len(global_shape[rank:]) < 2:   # 1-D: a plain undistributed array
-            self._p0, self._rank = None, rank
+        field_shape = global_shape[rank:]                 # the distributed part
+        self._rank = rank
+        if len(field_shape) < 2:                          # 1-D: a plain undistributed array
+            self._p0 = None
             self._init_storage(global_shape, dtype, buffer, val)
             return
-        if isinstance(subcomm, Subcomm):
-            pass
-        else:
-            if isinstance(subcomm, (tuple, list)):
-                assert len(subcomm) == len(global_shape[rank:])
-                if not np.all([isinstance(s, _comm.Comm) for s in subcomm]):
-                    subcomm = Subcomm(_comm.world(), subcomm)
+        subcomm, alignment = self._resolve_grid(subcomm, alignment, len(field_shape))
+        self._p0 = Pencil(subcomm, field_shape, axis=alignment)
+        self._init_storage(global_shape[:rank] + self._p0.subshape, dtype, buffer, val)
+
+    @staticmethod
+    def _resolve_grid(subcomm, alignment, ndim):
+        """(Subcomm, aligned axis) from the accepted spellings of `subcomm` (distarray.py:64-94):
+        a Subcomm, a sequence of communicators, a grid of ints with 0 = free, or None (everything
+        distributed except `alignment`, default the last axis)."""
+        if not isinstance(subcomm, Subcomm):
+            if subcomm is None:
+                grid = [0] * ndim
+                alignment = ndim - 1 if alignment is None else alignment
+                grid[alignment] = 1
+                subcomm = Subcomm(_comm.world(), grid)
             else:
-                assert subcomm is None
-                subcomm = [0] * len(global_shape[rank:])
-                if alignment is not None:
-                    subcomm[alignment] = 1
-                else:
-                    subcomm[-1] = 1
-                    alignment = len(subcomm) - 1
-                subcomm = Subcomm(_comm.world(), subcomm)
-        sizes = [s.Get_size() for s in subcomm]
-        if alignment is not None:
-            assert isinstance(alignment, (int, np.integer))
-            assert sizes[alignment] == 1
-        else:
-            alignment = np.flatnonzero(np.array(sizes) == 1)[-1]
-        p0 = Pencil(subcomm, global_shape[rank:], axis=int(alignment))
-        subshape = p0.subshape
-        if rank > 0:
-            subshape = global_shape[:rank] + subshape
-        self._p0, self._rank = p0, rank
-        self._init_storage(subshape, dtype, buffer, val)
+                assert isinstance(subcomm, (tuple, list)) and len(subcomm) == ndim
+                if not all(isinstance(c, _comm.Comm) for c in subcomm):
+                    subcomm = Subcomm(_comm.world(), subcomm)
+        undivided = [i for i, c in enumerate(subcomm) if c.Get_size() == 1]
+        if alignment is None:
+            alignment = undivided[-1]
+        assert isinstance(alignment, (int, np.integer)) and alignment in undivided
+        return subcomm, int(alignment)
 
     def _init_storage(self, shape, dtype, buffer, val):
         tensor = None
@@ -83,37 +81,15 @@ class DistArray(DeviceArray):
         out._shape, out._dtype, out._t = tuple(sub.shape), self._dtype, sub
         return out
 
-    @property
-    def alignment(self):
-        return self._p0.axis
-
-    @property
-    def global_shape(self):
-        return self.shape[:self.rank] + self._p0.shape
-
-    @property
-    def substart(self):
-        return (0,) * self.rank + self._p0.substart
-
-    @property
-    def subcomm(self):
-        return (_comm.COMM_SELF,) * self.rank + self._p0.subcomm
-
-    @property
-    def commsizes(self):
-        return [s.Get_size() for s in self.subcomm]
-
-    @property
-    def pencil(self):
-        return self._p0
-
-    @property
-    def rank(self):
-        return self._rank
-
-    @property
-    def dimensions(self):
-        return len(self._p0.shape)
+    # metadata (distarray.py:103-153)
+    alignment = property(lambda self: self._p0.axis)
+    pencil = property(lambda self: self._p0)
+    rank = property(lambda self: self._rank)
+    dimensions = property(lambda self: len(self._p0.shape))
+    global_shape = property(lambda self: self.shape[:self._rank] + self._p0.shape)
+    substart = property(lambda self: (0,) * self._rank + self._p0.substart)
+    subcomm = property(lambda self: (_comm.COMM_SELF,) * self._rank + self._p0.subcomm)
+    commsizes = property(lambda self: [c.Get_size() for c in self.subcomm])
 
     @property
     def v(self):
@@ -123,8 +99,9 @@ class DistArray(DeviceArray):
         return out
 
     def local_slice(self):
-        v = [slice(start, start + shape) for start, shape in zip(self._p0.substart, self._p0.subshape)]
-        return tuple([slice(0, s) for s in self.shape[:self.rank]] + v)
+        lead = [slice(0, n) for n in self.shape[:self._rank]]
+        block = [slice(s, s + n) for s, n in zip(self._p0.substart, self._p0.subshape)]
+        return tuple(lead + block)
 
     def get_pencil_and_transfer(self, axis):
         p1 = self._p0.pencil(axis)
@@ -156,15 +133,9 @@ class DistArray(DeviceArray):
         if out is None:
             out = DistArray(self.global_shape, subcomm=p1.subcomm, dtype=self.dtype,
                             alignment=axis, rank=self.rank)
-        if self.rank == 0:
-            transfer.forward(self.v, out.v)
-        elif self.rank == 1:
-            for i in range(self.shape[0]):
-                transfer.forward(self.v[i], out.v[i])
-        elif self.rank == 2:
-            for i in range(self.shape[0]):
-                for j in range(self.shape[1]):
-                    transfer.forward(self.v[i, j], out.v[i, j])
+        src, dst = self.v, out.v
+        for comp in np.ndindex(*self.shape[:self._rank]):       # one exchange per field component
+            transfer.forward(src[comp] if comp else src, dst[comp] if comp else dst)
         transfer.destroy()
         return out
 

@@ -159,33 +159,24 @@ class PFFT:
             assert darray is not None
             shape = darray.pencil.shape
 
-        if axes is not None:
-            axes = list(axes) if not isinstance(axes, (int, np.integer)) else [int(axes)]
-        else:
-            axes = list(range(len(shape)))
-            if darray is not None:
-                # the array's aligned axis must be transformed first
-                axes = list(np.roll(axes, len(shape) - 1 - darray.alignment))
-                axes = [int(a) for a in axes]
-
-        for i, ax in enumerate(axes):
-            if isinstance(ax, (int, np.integer)):
-                ax = int(ax)
-                if ax < 0:
-                    ax += len(shape)
-                axes[i] = (ax,)
-            else:
-                assert isinstance(ax, (tuple, list))
-                ax = list(ax)
-                for j, a in enumerate(ax):
-                    assert isinstance(a, (int, np.integer))
-                    if a < 0:
-                        ax[j] = int(a) + len(shape)
-                axes[i] = ax
-            assert min(axes[i]) >= 0
-            assert max(axes[i]) < len(shape)
-            assert 0 < len(axes[i]) <= len(shape)
-            assert sorted(axes[i]) == sorted(set(axes[i]))
+        nd = len(shape)
+        if axes is None:
+            order = list(range(nd))
+            if darray is not None:         # the array's aligned axis must be transformed first
+                order = [int(a) for a in np.roll(order, nd - 1 - darray.alignment)]
+            axes = order
+        elif isinstance(axes, (int, np.integer)):
+            axes = [int(axes)]
+        # axis groups: every entry becomes a sequence of non-negative axes (mpifft.py:226-247)
+        groups = []
+        for entry in axes:
+            members = [entry] if isinstance(entry, (int, np.integer)) else entry
+            assert isinstance(members, (tuple, list)) and 0 < len(members) <= nd
+            assert all(isinstance(a, (int, np.integer)) for a in members)
+            members = [int(a) + nd if a < 0 else int(a) for a in members]
+            assert all(0 <= a < nd for a in members) and len(set(members)) == len(members)
+            groups.append(tuple(members) if isinstance(entry, (int, np.integer)) else members)
+        axes = groups
 
         self.axes = axes
         shape = list(shape)
