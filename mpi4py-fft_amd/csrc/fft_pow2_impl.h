@@ -474,43 +474,49 @@ __device__ __forceinline__ void tile_store(const PassDesc &d, void *__restrict__
 // rule (`N0 % 2 == 0`) applies.
 template <typename real, int MODE>
 __device__ __forceinline__ cx<real> tile_load_pad(const PassDesc &d, const void *__restrict__ in,
-                                                  int64_t base, int e, real sy) {
-  cx<real> v = {0, 0};
-  const cx<real> *p = reinterpret_cast<const cx<real> *>(in) + base;
+                                                  int64_t base, int64_t idx, int64_t shift, int e, real sy) {
+  // idx = base + e*in_es (built incrementally by the caller); the upper half of the padded
+  // spectrum sits `shift` = (n - tr_N)*in_es elements lower in the truncated array
+  // Loads are unconditional (entries outside the kept band read the line's first element and are
+  // zeroed by a select): a load inside a branch cannot be issued ahead of the previous one, and a
+  // pass that waits for R loads one after the other is latency bound (measured on the backward
+  // row pass of a padded 1024^3: 8.2 ms branching).
+  cx<real> v;
   if constexpr (MODE == MODE_C2R) {
+    const cx<real> *p = reinterpret_cast<const cx<real> *>(in) + base;
     const bool mirror = e > (d.n >> 1);
     const int ee = mirror ? d.n - e : e;
-    if (ee < d.tr_n) {
-      v = p[(int64_t)ee * d.in_es];
-      if (d.tr_even && ee == d.tr_n - 1) { v.x *= (real)0.5; v.y = 0; }
-    }
+    const bool ok = ee < d.tr_n;
+    v = p[ok ? (int64_t)ee * d.in_es : 0];
+    if (d.tr_even && ee == d.tr_n - 1) { v.x *= (real)0.5; v.y = 0; }
+    if (!ok) v = {0, 0};
     v.y *= mirror ? -sy : sy;
   } else {
     const int h = d.tr_N >> 1;
     const bool lo = e <= h, hi = h > 0 && e >= d.n - h;
-    if (lo || hi) {
-      v = p[(int64_t)(lo ? e : e - (d.n - d.tr_N)) * d.in_es];
-      if (d.tr_even && (e == h || e == d.n - h)) { v.x *= (real)0.5; v.y *= (real)0.5; }
-    }
+    v = reinterpret_cast<const cx<real> *>(in)[lo ? idx : (hi ? idx - shift : base)];
+    if (d.tr_even && (e == h || e == d.n - h)) { v.x *= (real)0.5; v.y *= (real)0.5; }
+    if (!(lo || hi)) v = {0, 0};
     v.y *= sy;
   }
   return v;
 }
 
 template <typename real, int MODE>
-__device__ __forceinline__ void tile_store_trunc(const PassDesc &d, void *__restrict__ out, int64_t base,
-                                                 int e, cx<real> v, real sx, real sy) {
-  cx<real> *p = reinterpret_cast<cx<real> *>(out) + base;
+__device__ __forceinline__ void tile_store_trunc(const PassDesc &d, void *__restrict__ out, int64_t idx,
+                                                 int64_t shift, int e, cx<real> v, real sx, real sy) {
+  // idx = out0 + e*out_es (incremental); shift = (n - tr_N)*out_es for the upper half
+  cx<real> *p = reinterpret_cast<cx<real> *>(out);
   if constexpr (MODE == MODE_R2C) {
     if (e < d.tr_n) {
       if (d.tr_even && e == d.tr_n - 1) { v.x *= 2; v.y = 0; }
-      p[(int64_t)e * d.out_es] = {v.x * sx, v.y * sy};
+      p[idx] = {v.x * sx, v.y * sy};
     }
   } else {
     const int h = d.tr_N >> 1;
     const bool lo = e <= h, hi = h > 0 && e >= d.n - h;
     if (d.tr_even && e == d.n - h) return;            // folded onto entry h by the kernel body
-    if (lo || hi) p[(int64_t)(lo ? e : e - (d.n - d.tr_N)) * d.out_es] = {v.x * sx, v.y * sy};
+    if (lo || hi) p[lo ? idx : idx - shift] = {v.x * sx, v.y * sy};
   }
 }
 
@@ -544,6 +550,9 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   const real sx_out = (real)d.scale;
   const real sy_out = d.conj_out ? -sx_out : sx_out;
   const int64_t t_in = (int64_t)t * d.in_es, t_out = (int64_t)t * d.out_es;   // per thread
+  // fused padding / truncation: distance between the two halves of the padded spectrum (uniform)
+  const int64_t pad_shift_in = (FLAGS & 16) ? (int64_t)(d.n - d.tr_N) * d.in_es : 0;
+  const int64_t pad_shift_out = (FLAGS & 16) ? (int64_t)(d.n - d.tr_N) * d.out_es : 0;
   const int64_t q_in = (int64_t)NT * d.in_es, q_out = (int64_t)NT * d.out_es; // uniform steps
 
   // Tile order.  Plain: tile = block + k*grid (adjacent tiles run at the same time on different
@@ -588,7 +597,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         if constexpr ((FLAGS & 16) != 0) {
-          v[q] = d.tr_dir == 2 ? tile_load_pad<real, MODE>(d, in, in0, t + q * NT, sy_in)
+          v[q] = d.tr_dir == 2 ? tile_load_pad<real, MODE>(d, in, in0, idx, pad_shift_in, t + q * NT, sy_in)
                                : tile_load<real, MODE, false>(d, in, in0, idx, t + q * NT, sy_in);
         } else {
           v[q] = tile_load<real, MODE, (FLAGS & 1) != 0>(d, in, in0, idx, t + q * NT, sy_in);
@@ -681,7 +690,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         if constexpr ((FLAGS & 16) != 0) {
-          if (d.tr_dir == 1) tile_store_trunc<real, MODE>(d, out, out0, t + q * NT, v[q], sx_out, sy_out);
+          if (d.tr_dir == 1) tile_store_trunc<real, MODE>(d, out, idx, pad_shift_out, t + q * NT, v[q], sx_out, sy_out);
           else tile_store<real, MODE, false, false>(d, out, idx, t + q * NT, m, v[q], sx_out, sy_out);
         } else {
           tile_store<real, MODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, t + q * NT, m, v[q], sx_out, sy_out);
