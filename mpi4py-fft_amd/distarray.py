@@ -4,8 +4,10 @@ Mirror of mpi4py_fft/distarray.py: ``DistArray`` carries a :class:`Pencil` descr
 of the global array this rank holds, supports tensor-valued fields (``rank`` leading axes that
 are never distributed) and ``redistribute``; ``newDistArray(pfft, ...)`` allocates the input or
 output array of a :class:`PFFT`.  The reference subclasses ``np.ndarray``; here the storage is a
-:class:`DeviceArray` (see array.py for the ndarray behaviour it keeps).  ``get / write / read``
-(HDF5 / NetCDF I/O, distarray.py:182-241,365-439) are storage features outside this path.
+:class:`DeviceArray` (see array.py for the ndarray behaviour it keeps).  ``get(gslice)`` gathers a
+global slice on rank 0 over the communicator (the reference detours through a parallel HDF5
+file); ``write / read`` (HDF5 / NetCDF I/O, distarray.py:365-439) are storage features outside
+this path.
 """
 from numbers import Number
 
@@ -140,10 +142,39 @@ class DistArray(DeviceArray):
         return out
 
     def get(self, gslice=None):
+        """Without arguments: this rank's block as a host array.  With `gslice` (a sequence of
+        ``slice(None)`` and ints, one per global axis): that slice of the GLOBAL array, on rank 0
+        (None elsewhere), as distarray.py:182-235 -- which routes the gather through a parallel
+        HDF5 file; here the ranks' pieces travel over the communicator."""
         if gslice is None:
             return DeviceArray.get(self)
-        raise NotImplementedError('global-slice gather goes through HDF5 in the reference '
-                                  '(distarray.py:182-241); storage I/O is outside this path')
+        gslice = tuple(gslice)
+        assert len(gslice) == len(self.global_shape)
+        mine = self.local_slice()
+        kept = [i for i, g in enumerate(gslice) if isinstance(g, slice)]
+        index, here = [], True
+        for g, blk in zip(gslice, mine):
+            if isinstance(g, slice):
+                assert g == slice(None), 'only full slices and integer indices'
+                index.append(slice(None))
+            elif blk.start <= g < blk.stop:
+                index.append(int(g) - blk.start)
+            else:
+                here = False
+        piece = np.asarray(self.v[tuple(index)]) if here else None
+        parent = next((c.relay_parent for c in self._p0.subcomm if getattr(c, 'relay_parent', None)), None)
+        parts = [(tuple(mine[i] for i in kept), piece)]
+        rank0 = True
+        if parent is not None:
+            parts = parent.allgather_obj(parts[0])
+            rank0 = parent.Get_rank() == 0
+        if not rank0:
+            return None
+        out = np.zeros([self.global_shape[i] for i in kept], dtype=self.dtype)
+        for where, data in parts:
+            if data is not None:
+                out[where] = data
+        return out
 
     def write(self, *a, **k):
         raise NotImplementedError('HDF5/NetCDF output is outside the PFFT hot path')

@@ -282,3 +282,24 @@ def test_r2r_transforms_orchestration():
         for r, (uh, back, sl) in enumerate(thread_comm.run(P, body)):
             assert uh.dtype == want[r].dtype and np.abs(uh - want[r]).max() < 1e-13
             assert np.abs(back - G[sl]).max() < 1e-12
+
+
+def test_distarray_get_global_slice():
+    """DistArray.get(gslice): the docstring example of distarray.py:196-212 (4 ranks, N = 6^3,
+    alignment 0, z[:] = rank -> z.get((0, :, 0)) == [0 0 0 2 2 2] on rank 0), and a 2-D slice."""
+    from tests import thread_comm
+    from mpi4py_fft_amd import DistArray, Subcomm
+
+    def body(comm):
+        N = (6, 6, 6)
+        z = DistArray(N, subcomm=Subcomm(comm, [1, 0, 0]), dtype=float, alignment=0)
+        z[...] = float(comm.Get_rank())
+        g = z.get((0, slice(None), 0))
+        G = np.arange(216, dtype=float).reshape(N)
+        z[...] = G[z.local_slice()]
+        plane = z.get((slice(None), 3, slice(None)))
+        return g, plane
+    res = thread_comm.run(4, body)
+    assert np.array_equal(res[0][0], [0, 0, 0, 2, 2, 2])
+    assert np.array_equal(res[0][1], np.arange(216, dtype=float).reshape(6, 6, 6)[:, 3, :])
+    assert all(r[0] is None and r[1] is None for r in res[1:])
