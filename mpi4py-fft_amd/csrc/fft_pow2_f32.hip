@@ -41,8 +41,7 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
     }
   } else {
     // plain c2c along a strided axis: 32 adjacent columns = 256-byte segments up to n = 512
-    // (measured on (2048,512,1024) c64: 3.88 -> 3.35 ms; n = 256: 3.53 -> 3.37 ms).  n = 1024 would
-    // need R = 32 to stay within 1024 threads, which spills (variant 1: 4.01 -> 4.40 ms).
+    // (measured on (2048,512,1024) c64: 3.88 -> 3.35 ms; n = 256: 3.53 -> 3.37 ms).
     switch (d.n) {
       case 16: return P32F(16, 4, 32, true, false, 1, 8, 4, 4);
       case 32: return P32F(32, 8, 32, true, false, 1, 8, 8, 4);
@@ -58,13 +57,25 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
           default: return P32F(512, 16, 32, true, true, 1, 8, 16, 8, 4);
           case 1: return P32(512, 8, 16, true, true, 1, 8, 8, 8);
         }
+      // n >= 1024: R = 32 elements per thread (the 64 data VGPRs R = 16 costs in fp64) doubles the
+      // columns per workgroup at the same 1024 threads: 256-byte segments at n = 1024, 128 at 2048.
+      // Measured ((.,n,1024) c64 axis 1, R = 16 -> R = 32): n=1024 4.03 -> 3.65 ms, n=2048
+      // 5.83 -> 4.13 ms, n=4096 (x512) 4.85 -> 3.37 ms; variant 1 = the R = 16 plans.
       case 1024:
         switch (variant) {
-          default: return P32(1024, 16, 16, true, true, 1, 16, 16, 4);
-          case 1: return P32F(1024, 32, 32, true, true, 1, 8, 16, 16, 4);    // 256-B segments, R = 32: spills
+          default: return P32F(1024, 32, 32, true, true, 1, 8, 16, 16, 4);
+          case 1: return P32(1024, 16, 16, true, true, 1, 16, 16, 4);
         }
-      case 2048: return P32(2048, 16, 8, true, true, 4, 16, 16, 8);
-      case 4096: return P32(4096, 16, 4, true, true, 4, 16, 16, 16);
+      case 2048:
+        switch (variant) {
+          default: return P32F(2048, 32, 16, true, true, 1, 8, 16, 16, 8);
+          case 1: return P32(2048, 16, 8, true, true, 4, 16, 16, 8);
+        }
+      case 4096:
+        switch (variant) {
+          default: return P32F(4096, 32, 8, true, true, 1, 8, 16, 16, 16);
+          case 1: return P32(4096, 16, 4, true, true, 4, 16, 16, 16);
+        }
     }
   }
   return hipErrorInvalidValue;

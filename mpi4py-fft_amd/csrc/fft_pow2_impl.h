@@ -618,7 +618,12 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     // (40 VGPRs at fp64 n=1024), costing a wave of occupancy per SIMD.
     const cx<real> *twl = tw;
     asm volatile("" : "+s"(twl));
-    if constexpr (!(FLAGS & 4)) Stage<real, N, R, SPLIT, 1, RADS...>::run(v, t, col, twl);
+    // ... and the thread's row index: the table offsets k*step derived from it are loop invariant
+    // too, and hoisted they sit in (or spill from) 2 VGPRs per twiddle lookup for the whole kernel
+    // (fp32 n=1024 R=32: 104 bytes of scratch -> none; fp64 n=1024 R=16 T=16: 127 -> 107 VGPRs)
+    int tl = t;
+    asm volatile("" : "+v"(tl));
+    if constexpr (!(FLAGS & 4)) Stage<real, N, R, SPLIT, 1, RADS...>::run(v, tl, col, twl);
     if constexpr ((FLAGS & 16) != 0 && MODE == MODE_C2C) {
       // complex truncation with even N: entries h = N/2 and n - h of the padded spectrum both land
       // on truncated entry h (libfft.py:281-284).  They live in different threads: pass the upper
