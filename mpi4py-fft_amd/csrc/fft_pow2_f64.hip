@@ -58,9 +58,20 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
       case 4096: return P64F(4096, 16, 4, true, 4, 32, 16, 16, 16);
     }
   } else if (d.mode != MODE_C2C || d.tw_hi || d.tr_dir || d.out_es == 1 || d.in_es == 1) {
-    // Strided passes that are not plain c2c column passes -- r2c / c2r along a strided axis
-    // (halved axis is not the array's last axis) and the four-step passes (fused big twiddle,
-    // transposed store) -- take the register-lean R = 8 plans with 128-byte segments.
+    // Strided passes that are not plain c2c column passes: r2c / c2r along a strided axis (halved
+    // axis is not the array's last axis), fused truncation / padding, the second four-step pass.
+    // Up to n = 1024 they now take 16 columns per tile like the plain passes (these variants
+    // used to spill at R = 16 until the row index was laundered, see fft_pow2_impl.h); the lean
+    // R = 8 plans with 128-byte segments remain for n >= 2048 and as variant 9.
+    if (variant != 9) {
+      switch (d.n) {
+        case 64: return P64(64, 8, 16, true, 1, 8, 8);
+        case 128: return P64(128, 8, 16, true, 1, 8, 8, 2);
+        case 256: return P64(256, 8, 16, true, 1, 8, 8, 4);
+        case 512: return P64(512, 8, 16, true, 1, 8, 8, 8);
+        case 1024: return P64(1024, 16, 16, true, 4, 16, 16, 4);
+      }
+    }
     switch (d.n) {
       case 16: return P64(16, 4, 16, true, 1, 4, 4);
       case 32: return P64(32, 8, 16, true, 1, 8, 4);

@@ -566,6 +566,11 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   for (unsigned k = d.swizzle ? blockIdx.x / 8 : blockIdx.x; k < kend; k += kstep) {
     const unsigned tile = d.swizzle ? (blockIdx.x % 8) * per_xcd + k : k;
     if (tile >= ntiles) continue;
+    // The thread's row index, laundered once per tile: everything derived from it inside the loop
+    // (twiddle-table offsets k*step, LDS slots, mirrored c2r offsets) is loop invariant, and
+    // hoisted it sits in -- or spills from -- 2 VGPRs per use for the whole kernel.
+    int tl = t;
+    asm volatile("" : "+v"(tl));
     bool valid;
     unsigned o, m, i;
     if constexpr (ROWTILES) {
@@ -597,10 +602,10 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         if constexpr ((FLAGS & 16) != 0) {
-          v[q] = d.tr_dir == 2 ? tile_load_pad<real, MODE>(d, in, in0, idx, pad_shift_in, t + q * NT, sy_in)
-                               : tile_load<real, MODE, false>(d, in, in0, idx, t + q * NT, sy_in);
+          v[q] = d.tr_dir == 2 ? tile_load_pad<real, MODE>(d, in, in0, idx, pad_shift_in, tl + q * NT, sy_in)
+                               : tile_load<real, MODE, false>(d, in, in0, idx, tl + q * NT, sy_in);
         } else {
-          v[q] = tile_load<real, MODE, (FLAGS & 1) != 0>(d, in, in0, idx, t + q * NT, sy_in);
+          v[q] = tile_load<real, MODE, (FLAGS & 1) != 0>(d, in, in0, idx, tl + q * NT, sy_in);
         }
         int64_t step = q_in;
         if (++cnt == seg_in) {
@@ -618,11 +623,8 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     // (40 VGPRs at fp64 n=1024), costing a wave of occupancy per SIMD.
     const cx<real> *twl = tw;
     asm volatile("" : "+s"(twl));
-    // ... and the thread's row index: the table offsets k*step derived from it are loop invariant
-    // too, and hoisted they sit in (or spill from) 2 VGPRs per twiddle lookup for the whole kernel
-    // (fp32 n=1024 R=32: 104 bytes of scratch -> none; fp64 n=1024 R=16 T=16: 127 -> 107 VGPRs)
-    int tl = t;
-    asm volatile("" : "+v"(tl));
+    // (the row index `tl` is laundered for the same reason: fp32 n=1024 R=32 104 bytes of scratch
+    // -> none; fp64 n=1024 R=16 T=16 127 -> 107 VGPRs)
     if constexpr (!(FLAGS & 4)) Stage<real, N, R, SPLIT, 1, RADS...>::run(v, tl, col, twl);
     if constexpr ((FLAGS & 16) != 0 && MODE == MODE_C2C) {
       // complex truncation with even N: entries h = N/2 and n - h of the padded spectrum both land
@@ -634,11 +636,11 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < R; ++q)
-          if (t + q * NT == d.n - h) fold[c] = v[q];
+          if (tl + q * NT == d.n - h) fold[c] = v[q];
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < R; ++q)
-          if (t + q * NT == h) v[q] = v[q] + fold[c];
+          if (tl + q * NT == h) v[q] = v[q] + fold[c];
       }
     }
     if constexpr ((FLAGS & 32) != 0) {
@@ -652,7 +654,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         if constexpr (BIGTW) {
-          const unsigned x = m * (unsigned)(t + q * NT);
+          const unsigned x = m * (unsigned)(tl + q * NT);
           const cx<real> a = reinterpret_cast<const cx<real> *>(d.tw_hi)[x >> d.tw_L];
           const cx<real> b = reinterpret_cast<const cx<real> *>(d.tw_lo)[x & ((1u << d.tw_L) - 1)];
           v[q] = cmul(v[q], cmul(a, b));
@@ -695,10 +697,10 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         if constexpr ((FLAGS & 16) != 0) {
-          if (d.tr_dir == 1) tile_store_trunc<real, MODE>(d, out, idx, pad_shift_out, t + q * NT, v[q], sx_out, sy_out);
-          else tile_store<real, MODE, false, false>(d, out, idx, t + q * NT, m, v[q], sx_out, sy_out);
+          if (d.tr_dir == 1) tile_store_trunc<real, MODE>(d, out, idx, pad_shift_out, tl + q * NT, v[q], sx_out, sy_out);
+          else tile_store<real, MODE, false, false>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
         } else {
-          tile_store<real, MODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, t + q * NT, m, v[q], sx_out, sy_out);
+          tile_store<real, MODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
         }
         int64_t step = q_out;
         if (++cnt == seg_out) {
