@@ -27,7 +27,20 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 4096: return P32(4096, 16, 1, false, false, 1, 16, 16, 16);
     }
   } else if (d.mode != MODE_C2C || d.tw_hi || d.tr_dir || d.out_es == 1 || d.in_es == 1) {
-    // real modes along a strided axis and the four-step passes: lean R = 8 plans
+    // real modes along a strided axis, fused truncation / padding, four-step passes: the widest
+    // tile whose every mode compiles without spills (R = 16 up to n = 4096; the four-step twiddle
+    // variant only up to n = 1024); variant 9 = the former lean R = 8 plans
+    if (variant != 9 && !(d.tw_hi && d.n > 1024)) {
+      switch (d.n) {
+        case 64: return P32(64, 8, 32, true, false, 1, 8, 8);
+        case 128: return P32(128, 8, 32, true, false, 1, 8, 8, 2);
+        case 256: return P32(256, 8, 32, true, false, 1, 8, 8, 4);
+        case 512: return P32(512, 16, 32, true, true, 1, 16, 8, 4);
+        case 1024: return P32(1024, 16, 16, true, true, 1, 16, 16, 4);
+        case 2048: return P32(2048, 16, 8, true, true, 4, 16, 16, 8);
+        case 4096: return P32(4096, 16, 4, true, true, 4, 16, 16, 16);
+      }
+    }
     switch (d.n) {
       case 16: return P32(16, 4, 16, true, false, 1, 4, 4);
       case 32: return P32(32, 8, 16, true, false, 1, 8, 4);
