@@ -213,6 +213,9 @@ def main():
         flops = 2 * flops_c2c(shape)
         whole = dict(gbs=round(2 * bytes_f * size / (elapsed / args.steps) / 1e9, 1))
         whole['frac_of_peak_per_gpu'] = round(whole['gbs'] / size / HBM_PEAK_GBS, 4)
+        # SURVEY.md 8d also asks for the read-only variant (3 S per transform instead of 6 S)
+        whole['read_only_gbs'] = round(whole['gbs'] / 2, 1)
+        whole['read_only_frac_of_peak_per_gpu'] = round(whole['gbs'] / 2 / size / HBM_PEAK_GBS, 4)
         out = {
             'metric': 'pfft_3d_c2c_%dcubed_fp64_gflops' % n,
             'value': round(flops / (elapsed / args.steps) / 1e9, 1),
