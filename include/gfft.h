@@ -159,6 +159,11 @@ int gfft_probe_copy(const void *d_src, void *d_dst, size_t bytes, void *stream);
  * array [outer][n][inner] of 16-byte elements, tiles of `tcols` consecutive inner elements */
 int gfft_probe_tile_copy(const void *d_src, void *d_dst, int64_t outer, int64_t n, int64_t inner,
                          int tcols, void *stream);
+/* single-pass probe: run ONE power-of-two pass with explicit batch geometry and strides (element
+ * units), bypassing the planner.  geom = {n, outer, mid, inner, in_os, in_ms, in_is, in_es, out_os,
+ * out_ms, out_is, out_es}.  A measuring aid (tools/layout_probe.py), not part of the drop-in path. */
+int gfft_debug_pass(const int64_t *geom, int precision, int cols, int variant, int inverse,
+                    const void *d_in, void *d_out, void *stream);
 
 #ifdef __cplusplus
 }

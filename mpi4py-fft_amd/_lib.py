@@ -52,6 +52,7 @@ def _declare(lib):
         'gfft_ps_cross': (c.c_int, [vp, vp, vp, c.c_int64, c.c_int, vp]),
         'gfft_ps_project': (c.c_int, [vp, vp, vp, vp, vp, c.c_int64, c.c_int64, c.c_int64, c.c_double, c.c_int, vp]),
         'gfft_ps_rk_stage': (c.c_int, [vp, vp, vp, vp, c.c_int64, c.c_double, c.c_double, c.c_int, vp]),
+        'gfft_debug_pass': (c.c_int, [i64p, c.c_int, c.c_int, c.c_int, c.c_int, vp, vp, vp]),
         'gfft_malloc': (c.c_int, [c.POINTER(vp), c.c_size_t]),
         'gfft_free': (c.c_int, [vp]),
         'gfft_memcpy_h2d': (c.c_int, [vp, vp, c.c_size_t, vp]),
