@@ -172,9 +172,72 @@ fft_generic_kernel(PassDesc d, Factors f, int T, const void *__restrict__ in, vo
 
 int generic_max_n(int precision) { return precision == 8 ? 4096 : 8192; }
 
+// ---- lengths 3 / 5 / 7 / 11 / 13: one column per thread, everything in registers ----------------
+// The small factor of a two-pass split (896 = 128 x 7, 1408 = 128 x 11, ...) has thousands of
+// adjacent columns: lanes run along them (fully coalesced 16-byte accesses), each thread loads
+// its A strided elements, evaluates the DFT by definition with the A roots of unity in registers
+// (A*A constant-index multiply-adds), and stores.  No LDS, no synchronisation.
+constexpr int TINY_THREADS = 256;
+
+template <typename real, int A>
+__global__ void __launch_bounds__(TINY_THREADS)
+tiny_dft_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
+  const cx<real> *tw = reinterpret_cast<const cx<real> *>(d.tw);
+  cx<real> w[A];
+#pragma unroll
+  for (int q = 0; q < A; ++q) w[q] = tw[q];
+  const real sy_in = d.conj_in ? (real)-1 : (real)1;
+  const real sx = (real)d.scale, sy = d.conj_out ? -sx : sx;
+  const cx<real> *src = reinterpret_cast<const cx<real> *>(in);
+  cx<real> *dst = reinterpret_cast<cx<real> *>(out);
+  for (int64_t b = (int64_t)blockIdx.x * TINY_THREADS + threadIdx.x; b < d.batch;
+       b += (int64_t)gridDim.x * TINY_THREADS) {
+    const int64_t bm = b / d.inner, i = b - bm * d.inner, o = bm / d.mid, m = bm - o * d.mid;
+    const int64_t in0 = o * d.in_os + m * d.in_ms + i * d.in_is;
+    const int64_t out0 = o * d.out_os + m * d.out_ms + i * d.out_is;
+    cx<real> x[A];
+#pragma unroll
+    for (int q = 0; q < A; ++q) {
+      x[q] = src[in0 + q * d.in_es];
+      x[q].y *= sy_in;
+    }
+#pragma unroll
+    for (int p = 0; p < A; ++p) {
+      cx<real> acc = x[0];
+#pragma unroll
+      for (int q = 1; q < A; ++q) acc = acc + cmul(x[q], w[(p * q) % A]);
+      dst[out0 + p * d.out_es] = {acc.x * sx, acc.y * sy};
+    }
+  }
+}
+
+template <typename real, int A>
+static hipError_t launch_tiny(const PassDesc &d, const void *in, void *out, hipStream_t s) {
+  const int64_t blocks = (d.batch + TINY_THREADS - 1) / TINY_THREADS;
+  const int grid = (int)(blocks < 8192 ? blocks : 8192);
+  hipLaunchKernelGGL((tiny_dft_kernel<real, A>), dim3(grid), dim3(TINY_THREADS), 0, s, d, in, out);
+  return hipGetLastError();
+}
+
+template <typename real>
+static bool try_tiny(const PassDesc &d, const void *in, void *out, hipStream_t s, hipError_t *err) {
+  // worthwhile when lanes can run along adjacent columns
+  if (d.mode != MODE_C2C || d.tw_hi || d.tr_dir || d.in_is != 1 || d.out_is != 1 || d.inner < 64) return false;
+  switch (d.n) {
+    case 3: *err = launch_tiny<real, 3>(d, in, out, s); return true;
+    case 5: *err = launch_tiny<real, 5>(d, in, out, s); return true;
+    case 7: *err = launch_tiny<real, 7>(d, in, out, s); return true;
+    case 11: *err = launch_tiny<real, 11>(d, in, out, s); return true;
+    case 13: *err = launch_tiny<real, 13>(d, in, out, s); return true;
+  }
+  return false;
+}
+
 template <typename real>
 static hipError_t launch_generic_t(const PassDesc &d, const Factors &f, const void *in, void *out,
                                    hipStream_t s) {
+  hipError_t terr;
+  if (try_tiny<real>(d, in, out, s, &terr)) return terr;
   const size_t esz = sizeof(cx<real>);
   // columns per tile: aim for ~32 KiB per ping-pong buffer, at least 1, at most 64 (wider tiles measured slower)
   int T = (int)((32 * 1024) / ((size_t)d.n * esz));

@@ -635,6 +635,10 @@ int plan_line(gfft_plan_s *pl, const Line &L, bool top) {
   // a register-kernel pass plus a tiny generic pass.
   if (L.mode == MODE_C2C && n >= 240 && !opts().force_generic) {
     int64_t both = 0, one = 0;
+    // a single prime factor 7 / 11 / 13 beside a register-kernel length: that pass is one column
+    // per thread (fft_generic.hip, tiny_dft_kernel) and runs at strided-copy speed
+    for (int64_t a : {7, 11, 13})
+      if (n % a == 0 && regk_ok(n / a, prec)) one = a;
     for (int64_t a = (int64_t)std::sqrt((double)n); a >= 2; --a) {
       if (n % a) continue;
       const int64_t b = n / a;
