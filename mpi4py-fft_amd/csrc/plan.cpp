@@ -1086,7 +1086,9 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
     if (bytes) *bytes = 0;
     return GFFT_OK;
   }
-  snprintf(buf, len, "%s n=%d", p.regk ? (p.cols ? "pow2-cols" : "pow2-rows") : "generic", p.d.n);
+  const bool percol = !p.regk && (p.d.n == 3 || p.d.n == 5 || p.d.n == 7 || p.d.n == 11 || p.d.n == 13) &&
+                      p.d.mode == MODE_C2C && !p.d.tw_hi && p.d.in_is == 1 && p.d.out_is == 1 && p.d.inner >= 64;
+  snprintf(buf, len, "%s n=%d", p.regk ? (p.cols ? "pow2-cols" : "pow2-rows") : (percol ? "percol" : "generic"), p.d.n);
   if (bytes) {
     const double esz = 2.0 * pl->precision;
     const double nc = p.d.mode == MODE_C2C ? p.d.n : p.d.n / 2 + 1;
