@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Developer tool: randomised PFFT stress on one GPU (thread ranks): power-of-two and awkward
+shapes, 1-8 ranks, paddings, slabs, collapse, forced relay / pack-fusion settings, vs the oracle."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tests import cases
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
+rng = np.random.default_rng(seed)
+pool = [8, 12, 13, 16, 16, 18, 24, 27, 28, 32, 32, 40, 48, 56, 64, 64, 96, 128]
+t0, done, skipped = time.time(), 0, 0
+while time.time() - t0 < budget:
+    nd = int(rng.choice([2, 3, 3, 3, 4]))
+    shape = tuple(int(rng.choice(pool)) for _ in range(nd))
+    if np.prod(shape) > 3_000_000:
+        continue
+    P = int(rng.choice([1, 2, 4, 4, 8, 8, 3, 6]))
+    dt = str(rng.choice(list('dDfF')))
+    kw = {}
+    if rng.random() < 0.3:
+        kw['collapse'] = True
+    if rng.random() < 0.25 and nd >= 3:
+        kw['grid'] = (-1,)
+    if rng.random() < 0.25:
+        kw['padding'] = [1.5] * nd
+        kw['axes'] = tuple((i,) for i in range(nd))
+        kw.pop('collapse', None)
+    os.environ['GFFT_RELAY'] = str(rng.choice(['0', '1', 'measure']))
+    os.environ['GFFT_FUSE_PACK'] = str(rng.choice(['0', '1', '1']))
+    try:
+        cases.check_pfft_vs_oracle(P, shape, dt, seed=int(rng.integers(1 << 30)), **kw)
+        done += 1
+    except AssertionError as e:
+        msg = str(e)
+        if msg == '' or 'size' in msg or 'assert n >= size' in msg:
+            skipped += 1
+            continue
+        print('FAIL', P, shape, dt, kw, os.environ['GFFT_RELAY'], os.environ['GFFT_FUSE_PACK'], msg[:300], flush=True)
+        raise
+    except RuntimeError as e:
+        if 'AssertionError' in str(e) and 'n >= size' in str(e):
+            skipped += 1
+            continue
+        print('FAIL', P, shape, dt, kw, os.environ['GFFT_RELAY'], os.environ['GFFT_FUSE_PACK'], flush=True)
+        raise
+print('stress seed %d: %d configurations checked, %d skipped (invalid for the rank count), %.0f s' % (seed, done, skipped, time.time() - t0))
