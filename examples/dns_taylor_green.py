@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 
-def solve(world, M=6, nsteps=10, dt=0.01, nu=0.000625, verbose=False, fused=True):
+def solve(world, M=6, nsteps=10, dt=0.01, nu=0.000625, verbose=False, fused=True, graph=False):
     from mpi4py_fft_amd import PFFT, newDistArray, spectral
     N = [2 ** M] * 3
     L = np.array([2 * np.pi, 4 * np.pi, 4 * np.pi])
@@ -95,7 +95,7 @@ def solve(world, M=6, nsteps=10, dt=0.01, nu=0.000625, verbose=False, fused=True
     if dev.type == 'cuda':
         torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(nsteps):
+    def step():
         uh0.copy_(uh)
         uh1.copy_(uh)
         for rk in range(4):
@@ -114,11 +114,35 @@ def solve(world, M=6, nsteps=10, dt=0.01, nu=0.000625, verbose=False, fused=True
                 FFT.backward(U_hat[i], U[i])
             else:
                 bwd(uh[i], u[i])
+
+    if graph:
+        # One RK4 step is ~130 small kernels at 64^3: launch bound.  Every kernel of this package
+        # is enqueued on torch's current stream and nothing allocates or synchronises after the
+        # first execution, so the step can be captured into a HIP graph and replayed.
+        assert fused and world.Get_size() == 1 and dev.type == 'cuda'
+        keep = uh.clone()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            step()                               # warm-up on the capture stream: scratch, tables
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        uh.copy_(keep)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            step()
+        uh.copy_(keep)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(nsteps):
+            g.replay()
+    else:
+        for _ in range(nsteps):
+            step()
     energy = sum(world.allgather_obj(float((u * u).sum().item()))) / N[0] / N[1] / N[2] / 2
     elapsed = time.time() - t0
     if verbose and world.Get_rank() == 0:
         print('%d^3, %d steps, %s pointwise path: %.3f s (%.2f ms per RK4 step), energy = %.12f'
-              % (N[0], nsteps, 'fused-kernel' if fused else 'torch-expression', elapsed,
+              % (N[0], nsteps, ('fused-kernel' if fused else 'torch-expression') + (' + HIP graph replay' if graph else ''), elapsed,
                  elapsed / nsteps * 1e3, energy))
     FFT.destroy()
     return energy
@@ -131,6 +155,9 @@ if __name__ == '__main__':
     assert round(e - 0.124953117517, 7) == 0, e
     e = solve(w, verbose=True, fused=False)
     assert round(e - 0.124953117517, 7) == 0, e
+    if w.Get_size() == 1:
+        e = solve(w, verbose=True, graph=True)
+        assert round(e - 0.124953117517, 7) == 0, e
     if len(sys.argv) > 1:                       # e.g. `dns_taylor_green.py 8` for 256^3 timings
         for f in (True, False):
             solve(w, M=int(sys.argv[1]), nsteps=5, verbose=True, fused=f)

@@ -19,7 +19,9 @@
  * `int`, fftw_planxfftn.c:11-22; 1024^3 is its edge).  Arrays are C-contiguous (row-major), the
  * only layout the reference plans for (fftw_planxfftn.c:25-30).  Caller is single-threaded per
  * plan.  No host fallback exists: without a HIP device every compute entry point returns
- * GFFT_ERR_NO_DEVICE.
+ * GFFT_ERR_NO_DEVICE.  A plan allocates its scratch at its first gfft_execute; after that,
+ * gfft_execute and the pointwise entries only enqueue kernels (no allocation, no synchronisation),
+ * so a stream running them can be captured into a HIP graph.
  */
 #ifndef GFFT_H
 #define GFFT_H
