@@ -94,4 +94,29 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
   return hipErrorInvalidValue;
 }
 
+hipError_t launch_pow2_r2r_f32(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s) {
+  if (!cols) {
+    switch (d.n) {
+      case 64: return launch_pow2_one<float, 64, 8, 8, false, false, 1, 0, MODE_R2R, false, 8, 8>(d, in, out, s);
+      case 128: return launch_pow2_one<float, 128, 8, 4, false, false, 1, 0, MODE_R2R, false, 8, 8, 2>(d, in, out, s);
+      case 256: return launch_pow2_one<float, 256, 16, 4, false, false, 1, 0, MODE_R2R, false, 16, 16>(d, in, out, s);
+      case 512: return launch_pow2_one<float, 512, 8, 1, false, false, 1, 0, MODE_R2R, false, 8, 8, 8>(d, in, out, s);
+      case 1024: return launch_pow2_one<float, 1024, 16, 1, false, false, 1, 0, MODE_R2R, false, 16, 16, 4>(d, in, out, s);
+      case 2048: return launch_pow2_one<float, 2048, 16, 1, false, false, 1, 0, MODE_R2R, false, 16, 16, 8>(d, in, out, s);
+      case 4096: return launch_pow2_one<float, 4096, 16, 1, false, false, 1, 0, MODE_R2R, false, 16, 16, 16>(d, in, out, s);
+    }
+  } else {
+    switch (d.n) {
+      case 64: return launch_pow2_one<float, 64, 8, 32, true, false, 1, 0, MODE_R2R, false, 8, 8>(d, in, out, s);
+      case 128: return launch_pow2_one<float, 128, 8, 32, true, false, 1, 0, MODE_R2R, false, 8, 8, 2>(d, in, out, s);
+      case 256: return launch_pow2_one<float, 256, 8, 32, true, false, 1, 0, MODE_R2R, false, 8, 8, 4>(d, in, out, s);
+      case 512: return launch_pow2_one<float, 512, 16, 32, true, true, 1, 0, MODE_R2R, false, 16, 8, 4>(d, in, out, s);
+      case 1024: return launch_pow2_one<float, 1024, 16, 16, true, true, 1, 0, MODE_R2R, false, 16, 16, 4>(d, in, out, s);
+      case 2048: return launch_pow2_one<float, 2048, 16, 8, true, true, 1, 0, MODE_R2R, false, 16, 16, 8>(d, in, out, s);
+      case 4096: return launch_pow2_one<float, 4096, 16, 4, true, true, 1, 0, MODE_R2R, false, 16, 16, 16>(d, in, out, s);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
 }  // namespace gfft

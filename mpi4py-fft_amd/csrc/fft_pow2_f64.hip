@@ -115,4 +115,32 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
   return hipErrorInvalidValue;
 }
 
+// ---- real-to-real (DCT / DST) passes: the same kernel with the MODE_R2R load / store adapters ----
+bool pow2_r2r_supported(int n) { return n >= 64 && n <= 4096 && (n & (n - 1)) == 0; }
+
+hipError_t launch_pow2_r2r_f64(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s) {
+  if (!cols) {
+    switch (d.n) {
+      case 64: return launch_pow2_one<double, 64, 8, 8, false, true, 1, 0, MODE_R2R, false, 8, 8>(d, in, out, s);
+      case 128: return launch_pow2_one<double, 128, 8, 4, false, true, 1, 0, MODE_R2R, false, 8, 8, 2>(d, in, out, s);
+      case 256: return launch_pow2_one<double, 256, 8, 8, false, true, 1, 0, MODE_R2R, false, 8, 8, 4>(d, in, out, s);
+      case 512: return launch_pow2_one<double, 512, 8, 4, false, true, 1, 0, MODE_R2R, false, 8, 8, 8>(d, in, out, s);
+      case 1024: return launch_pow2_one<double, 1024, 16, 4, false, true, 1, 0, MODE_R2R, false, 16, 16, 4>(d, in, out, s);
+      case 2048: return launch_pow2_one<double, 2048, 16, 2, false, true, 1, 0, MODE_R2R, false, 16, 16, 8>(d, in, out, s);
+      case 4096: return launch_pow2_one<double, 4096, 16, 1, false, true, 1, 0, MODE_R2R, false, 16, 16, 16>(d, in, out, s);
+    }
+  } else {
+    switch (d.n) {
+      case 64: return launch_pow2_one<double, 64, 8, 16, true, true, 1, 0, MODE_R2R, false, 8, 8>(d, in, out, s);
+      case 128: return launch_pow2_one<double, 128, 8, 16, true, true, 1, 0, MODE_R2R, false, 8, 8, 2>(d, in, out, s);
+      case 256: return launch_pow2_one<double, 256, 8, 16, true, true, 1, 0, MODE_R2R, false, 8, 8, 4>(d, in, out, s);
+      case 512: return launch_pow2_one<double, 512, 8, 16, true, true, 1, 0, MODE_R2R, false, 8, 8, 8>(d, in, out, s);
+      case 1024: return launch_pow2_one<double, 1024, 16, 16, true, true, 1, 0, MODE_R2R, false, 16, 16, 4>(d, in, out, s);
+      case 2048: return launch_pow2_one<double, 2048, 8, 4, true, true, 1, 0, MODE_R2R, false, 8, 8, 8, 4>(d, in, out, s);
+      case 4096: return launch_pow2_one<double, 4096, 8, 2, true, true, 1, 0, MODE_R2R, false, 8, 8, 8, 8>(d, in, out, s);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
 }  // namespace gfft

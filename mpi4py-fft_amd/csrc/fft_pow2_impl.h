@@ -430,7 +430,15 @@ template <typename real, int MODE, bool NT>
 __device__ __forceinline__ cx<real> tile_load(const PassDesc &d, const void *__restrict__ in,
                                               int64_t base, int64_t idx, int e, real sy) {
   cx<real> v;
-  if constexpr (MODE == MODE_R2C) {
+  if constexpr (MODE == MODE_R2R) {
+    // real entry j = e - pos0 times its pre-factor; zero outside the line (unconditional load of
+    // the line's first entry there, zeroed by a select)
+    const int j = e - d.r2r_pos0;
+    const bool ok = (unsigned)j < (unsigned)d.r2r_n;
+    const real x = reinterpret_cast<const real *>(in)[ok ? idx - (int64_t)d.r2r_pos0 * d.in_es : base];
+    const cx<real> a = reinterpret_cast<const cx<real> *>(d.r2r_pre)[ok ? j : 0];
+    v = {ok ? a.x * x : (real)0, ok ? a.y * x : (real)0};
+  } else if constexpr (MODE == MODE_R2C) {
     v.x = reinterpret_cast<const real *>(in)[idx];
     v.y = 0;
   } else if constexpr (MODE == MODE_C2R) {
@@ -454,6 +462,14 @@ __device__ __forceinline__ void tile_store(const PassDesc &d, void *__restrict__
     const cx<real> a = reinterpret_cast<const cx<real> *>(d.tw_hi)[x >> d.tw_L];
     const cx<real> b = reinterpret_cast<const cx<real> *>(d.tw_lo)[x & ((1u << d.tw_L) - 1)];
     v = cmul(v, cmul(a, b));
+  }
+  if constexpr (MODE == MODE_R2R) {
+    const int k = e - d.r2r_idx0;
+    if ((unsigned)k < (unsigned)d.r2r_n) {
+      const cx<real> b = reinterpret_cast<const cx<real> *>(d.r2r_post)[k];
+      reinterpret_cast<real *>(out)[idx - (int64_t)d.r2r_idx0 * d.out_es] = (b.x * v.x - b.y * v.y) * sx;
+    }
+    return;
   }
   v.x *= sx;
   v.y *= sy;

@@ -40,6 +40,13 @@ struct PassDesc {
   // an all-to-all send / receive buffer); 0 / 0 = natural layout
   int in_lgp, out_lgp;
   int64_t in_jump, out_jump;
+  // MODE_R2R in the register kernels (DCT / DST kinds as one complex transform of the logical
+  // length n = 2 r2r_n, see plan.cpp plan_r2r_line): the load reads REAL entry j = e - r2r_pos0
+  // (zero outside [0, r2r_n)) times r2r_pre[j]; the store writes the REAL value
+  // Re(r2r_post[k] * Z[e]) to entry k = e - r2r_idx0 when it lies in [0, r2r_n).  Strides are in
+  // real elements on both sides.
+  const void *r2r_pre, *r2r_post;
+  int r2r_n, r2r_pos0, r2r_idx0;
   double scale;           // applied on store
   const void *tw;         // cx<real>[n]: exp(-2 pi i k / n)
   // optional four-step twiddle: output element k of a column with mid index m is multiplied
@@ -84,6 +91,10 @@ bool pow2_supported_f64(int n);
 bool pow2_supported_f32(int n);
 hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void *in, void *out, hipStream_t s);
 hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void *in, void *out, hipStream_t s);
+// MODE_R2R passes (power-of-two logical lengths 64 ... 4096)
+bool pow2_r2r_supported(int n);
+hipError_t launch_pow2_r2r_f64(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
+hipError_t launch_pow2_r2r_f32(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
 int pow2_grid_cap();
 // lengths 3^b * 2^k handled by the same register-resident kernel with R = 12 (fft_mix3_*.hip)
 bool mix3_supported(int n);

@@ -559,6 +559,38 @@ int plan_r2r_line(gfft_plan_s *pl, int64_t outer, int64_t n, int64_t inner, int 
   R2RTables t;
   int rc = get_r2r_tables(kind, n, prec, &t);
   if (rc) return rc;
+  const double lines = (double)outer * (double)inner;
+  pl->flops += 2.5 * (double)N * std::log2((double)(N > 1 ? N : 2)) * lines;
+  pl->bytes += lines * 2.0 * (double)n * prec;
+  if (pow2_r2r_supported((int)N) && !opts().force_generic && outer * inner < ((int64_t)1 << 31)) {
+    // one register-kernel pass: the pointwise steps are load / store adapters of the length-N
+    // complex transform (MODE_R2R), so the line is read once and written once
+    Pass p;
+    p.regk = true;
+    p.cols = inner > 1;
+    p.logical_first = true;
+    p.src = src;
+    p.dst = dst;
+    PassDesc &d = p.d;
+    d.n = (int)N;
+    d.mode = MODE_R2R;
+    d.batch = outer * inner;
+    d.mid = 1;
+    d.inner = inner;
+    d.in_os = d.out_os = n * inner;
+    d.in_is = d.out_is = 1;
+    d.in_es = d.out_es = inner;
+    d.scale = 1.0;
+    d.r2r_pre = t.pre;
+    d.r2r_post = t.post;
+    d.r2r_n = (int)n;
+    d.r2r_pos0 = (kind == GFFT_RODFT00 || kind == GFFT_RODFT01) ? 1 : 0;
+    d.r2r_idx0 = (kind == GFFT_RODFT00 || kind == GFFT_RODFT10) ? 1 : 0;
+    rc = get_twiddles(N, prec, &d.tw);
+    if (rc) return rc;
+    pl->passes.push_back(p);
+    return GFFT_OK;
+  }
   need(pl, BUF_WS, (size_t)outer * N * inner * 2 * prec);
   PointDesc pt{};
   pt.outer = outer;
@@ -587,9 +619,6 @@ int plan_r2r_line(gfft_plan_s *pl, int64_t outer, int64_t n, int64_t inner, int 
   x.src = BUF_WS;
   x.dst = dst;
   pl->passes.push_back(x);
-  const double lines = (double)outer * (double)inner;
-  pl->flops += 2.5 * (double)N * std::log2((double)(N > 1 ? N : 2)) * lines;
-  pl->bytes += lines * 2.0 * (double)n * prec;
   return GFFT_OK;
 }
 
@@ -797,9 +826,11 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   // half spectra): neighbouring chunks then meet in one L2 and their partial lines merge
   // (measured 1024^3 r2c: 5.4 -> 5.0 ms fp64, 3.6 -> 2.6 ms fp32; neutral-to-slightly-negative on
   // aligned arrays, so it stays off there)
-  const int64_t esz_out = (d.mode == MODE_C2R ? 1 : 2) * (int64_t)pl->precision;
+  const int64_t esz_out = ((d.mode == MODE_C2R || d.mode == MODE_R2R) ? 1 : 2) * (int64_t)pl->precision;
   d.swizzle = pl->xcd_swizzle >= 0 ? pl->xcd_swizzle
                                    : (p.cols && ((d.out_es * esz_out) % 128 != 0) ? 1 : 0);
+  if (p.regk && d.mode == MODE_R2R)
+    return pl->precision == 8 ? launch_pow2_r2r_f64(d, p.cols, in, out, s) : launch_pow2_r2r_f32(d, p.cols, in, out, s);
   if (p.regk && mix3_supported(d.n)) {
     return pl->precision == 8 ? launch_mix3_f64(d, p.cols, in, out, s) : launch_mix3_f32(d, p.cols, in, out, s);
   }
@@ -1095,6 +1126,7 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
     const double ein = p.d.mode == MODE_R2C ? p.d.n * (double)pl->precision : nc * esz;
     const double eout = p.d.mode == MODE_C2R ? p.d.n * (double)pl->precision : nc * esz;
     *bytes = (double)p.d.batch * (ein + eout);
+    if (p.d.mode == MODE_R2R) *bytes = (double)p.d.batch * 2.0 * p.d.r2r_n * (double)pl->precision;
   }
   return GFFT_OK;
 }

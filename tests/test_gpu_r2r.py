@@ -36,7 +36,12 @@ def test_all_kinds_against_scipy(typ, dt):
     tol = 1e-12 if dt == 'd' else 5e-5
     for shape, axes in (((16,), (0,)), ((5, 12), (1,)), ((9, 8), (0,)), ((4, 7, 6), (1,)), ((3, 30, 4), (1,)),
                         ((6, 5, 4), (0, 1, 2)), ((4, 8, 16), (2, 1)), ((2, 257), (1,)), ((2, 1000), (1,)),
-                        ((1024, 3), (0,)), ((3, 67), (1,))):
+                        ((1024, 3), (0,)), ((3, 67), (1,)),
+                        # logical lengths 64 ... 4096 = powers of two: one register-kernel pass with
+                        # the pre / post steps as load / store adapters (rows and strided mappings;
+                        # 33 / 31 points make N = 64 for the type-1 kinds)
+                        ((5, 64), (1,)), ((64, 5), (0,)), ((3, 128, 70), (1,)), ((2, 33), (1,)), ((2, 31), (1,)),
+                        ((33, 70), (0,)), ((31, 3), (0,)), ((3, 2048), (1,)), ((512, 6), (0,)), ((32, 64, 128), (0, 1, 2))):
         A = O.rng_array(shape, dt, 3)
         for planner, iplanner, table in ((fftw.dctn, fftw.idctn, fftw.dct_type), (fftw.dstn, fftw.idstn, fftw.dst_type)):
             a = asdevice(A)
