@@ -1,9 +1,9 @@
 // fp64 (complex128) instantiations of the power-of-two pass kernels.
 //
-// Plan table (R = elements per thread, T = columns per workgroup, radices per stage):
-// R = 8 keeps a thread at <= 128 VGPRs (32 for data), so 16 waves/CU stay resident; R = 16
-// variants (256 VGPRs, fewer exchanges) exist for N = 1024 as measurable alternatives
-// (`variant` argument; see DESIGN.md for the A/B numbers that picked the default).
+// Plan table (R = elements per thread, T = columns per workgroup, radices per stage).
+// Defaults at N = 1024: rows R = 16 / T = 4 (111 VGPRs), strided R = 16 / T = 16 = 256-byte
+// segments (107 VGPRs, 1024 threads); the `variant` argument selects the measured alternatives
+// (DESIGN.md section 4.1 has the A/B numbers that picked the defaults).
 #include "fft_pow2_impl.h"
 
 namespace gfft {

@@ -7,11 +7,11 @@
 // from HBM, last-stage outputs go straight to HBM, so a pass reads and writes the array once.
 //
 //   ROWS kernel: lanes run along the transform axis (contiguous rows, 16 B/lane coalesced).
-//   COLS kernel: lanes run along T adjacent columns (T*sizeof(complex) = 128 B segments), the
-//                transform axis is strided: no transposes anywhere in a 3-D transform.
+//   COLS kernel: lanes run along T adjacent columns (T*sizeof(complex) = 128 / 256 B segments),
+//                the transform axis is strided: no transposes anywhere in a 3-D transform.
 //
-// LDS exchange is either SPLIT (real plane, then imaginary plane: halves the footprint, e.g.
-// 2 workgroups/CU at fp64 N=1024 T=8) or whole complex values (fp32 only).
+// LDS exchange is either SPLIT (real plane, then imaginary plane: halves the footprint, which is
+// what lets 16 fp64 columns of N = 1024 fit the 160 KiB) or whole complex values (fp32 only).
 // Twiddles: log2(r) table lookups per butterfly (w^k, w^2k, w^4k, w^8k; exact table built in
 // long double on the host), the other powers by <=3 multiplications.  Inverse transforms swap
 // re/im on load and store (pass_io.h), so only forward butterflies exist.
