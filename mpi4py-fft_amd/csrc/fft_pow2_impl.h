@@ -790,6 +790,9 @@ hipError_t launch_pow2_inst(const PassDesc &d, const void *in, void *out, hipStr
       case MODE_C2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, false, RADS...>(d, in, out, s);
       case MODE_R2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_R2C, false, RADS...>(d, in, out, s);
       case MODE_C2R: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2R, false, RADS...>(d, in, out, s);
+#ifdef GFFT_INST_R2R   // translation units whose tables also serve the real-to-real adapters
+      case MODE_R2R: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_R2R, false, RADS...>(d, in, out, s);
+#endif
     }
   }
   return hipErrorInvalidValue;

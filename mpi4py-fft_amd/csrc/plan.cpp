@@ -562,7 +562,8 @@ int plan_r2r_line(gfft_plan_s *pl, int64_t outer, int64_t n, int64_t inner, int 
   const double lines = (double)outer * (double)inner;
   pl->flops += 2.5 * (double)N * std::log2((double)(N > 1 ? N : 2)) * lines;
   pl->bytes += lines * 2.0 * (double)n * prec;
-  if (pow2_r2r_supported((int)N) && !opts().force_generic && outer * inner < ((int64_t)1 << 31)) {
+  if ((pow2_r2r_supported((int)N) || (N <= 4096 && (mix3_supported((int)N) || mix5_supported((int)N)))) &&
+      !opts().force_generic && outer * inner < ((int64_t)1 << 31)) {
     // one register-kernel pass: the pointwise steps are load / store adapters of the length-N
     // complex transform (MODE_R2R), so the line is read once and written once
     Pass p;
@@ -829,7 +830,7 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   const int64_t esz_out = ((d.mode == MODE_C2R || d.mode == MODE_R2R) ? 1 : 2) * (int64_t)pl->precision;
   d.swizzle = pl->xcd_swizzle >= 0 ? pl->xcd_swizzle
                                    : (p.cols && ((d.out_es * esz_out) % 128 != 0) ? 1 : 0);
-  if (p.regk && d.mode == MODE_R2R)
+  if (p.regk && d.mode == MODE_R2R && pow2_r2r_supported(d.n))
     return pl->precision == 8 ? launch_pow2_r2r_f64(d, p.cols, in, out, s) : launch_pow2_r2r_f32(d, p.cols, in, out, s);
   if (p.regk && mix3_supported(d.n)) {
     return pl->precision == 8 ? launch_mix3_f64(d, p.cols, in, out, s) : launch_mix3_f32(d, p.cols, in, out, s);

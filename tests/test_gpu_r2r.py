@@ -41,7 +41,10 @@ def test_all_kinds_against_scipy(typ, dt):
                         # the pre / post steps as load / store adapters (rows and strided mappings;
                         # 33 / 31 points make N = 64 for the type-1 kinds)
                         ((5, 64), (1,)), ((64, 5), (0,)), ((3, 128, 70), (1,)), ((2, 33), (1,)), ((2, 31), (1,)),
-                        ((33, 70), (0,)), ((31, 3), (0,)), ((3, 2048), (1,)), ((512, 6), (0,)), ((32, 64, 128), (0, 1, 2))):
+                        ((33, 70), (0,)), ((31, 3), (0,)), ((3, 2048), (1,)), ((512, 6), (0,)), ((32, 64, 128), (0, 1, 2)),
+                        # ... and 3^b 2^k / 5^c 2^k logical lengths (n = 48, 768, 500, 10; 49 / 47 for type 1)
+                        ((3, 48), (1,)), ((768, 4), (0,)), ((2, 500), (1,)), ((70, 10), (1,)), ((49, 5), (0,)),
+                        ((2, 47), (1,)), ((96, 80, 72), (0, 1, 2))):
         A = O.rng_array(shape, dt, 3)
         for planner, iplanner, table in ((fftw.dctn, fftw.idctn, fftw.dct_type), (fftw.dstn, fftw.idstn, fftw.dst_type)):
             a = asdevice(A)
