@@ -110,6 +110,13 @@ class Transfer:
         members = tuple(parent._ranks.index(r) for r in self.comm._ranks)
         meta = parent.allgather_obj((members, [c * mult for c in self._countsA],
                                      [c * mult for c in self._countsB]))
+        # small exchanges are latency bound: two rounds cannot win.  Every rank sees the same
+        # table, so every rank takes the same decision.
+        scalar = self.dtype.itemsize // mult
+        largest = max(sum(a) for _, a, _ in meta) * scalar
+        if mode == 'measure' and largest < self.RELAY_MIN_BYTES:
+            self.exchange = 'direct'
+            return None
         me = parent.Get_rank()
         fwd = _relay.Schedule([(m, a) for m, a, b in meta], me)
         bwd = _relay.Schedule([(m, b) for m, a, b in meta], me)
@@ -133,6 +140,7 @@ class Transfer:
     # overlap the wire time of slab k.  CHUNK_MIN_BYTES / CHUNKS are tunables.
     CHUNKS = 4
     CHUNK_MIN_BYTES = 64 << 20
+    RELAY_MIN_BYTES = 8 << 20       # per-rank exchange volume below which routes are not measured
 
     def _nchunks(self, shape_src, axis_src, axis_dst, nbytes):
         if self._p == 1 or 0 in (axis_src, axis_dst) or nbytes < self.CHUNK_MIN_BYTES:

@@ -22,6 +22,7 @@ def main():
     from mpi4py_fft_amd import pencil
     pencil.Transfer.CHUNK_MIN_BYTES = 0     # exercise the chunked asynchronous exchange over gloo
     pencil.Transfer.CHUNKS = 3
+    pencil.Transfer.RELAY_MIN_BYTES = 0     # measure the routes even on these tiny arrays
     cases = [((16, 12, 10), "D", {}), ((13, 12, 10), "d", {}), ((7, 8, 9), "D", {}),
              ((12, 13), 'D', {}), ((16, 12, 10), 'd', dict(padding=[1.5, 1.5, 1.5])),
              ((12, 10, 8), 'D', dict(grid=(-1,))), ((12, 9, 8, 6), 'd', dict(axes=((0,), (1,), (2, 3))))]

@@ -157,6 +157,7 @@ def test_measured_route_choice(monkeypatch):
     data is right either way."""
     monkeypatch.setenv('GFFT_RELAY', 'measure')
     from mpi4py_fft_amd import pencil
+    monkeypatch.setattr(pencil.Transfer, 'RELAY_MIN_BYTES', 0)
     seen, measure = [], pencil.Transfer._measure_routes
     monkeypatch.setattr(pencil.Transfer, '_measure_routes',
                         lambda self, *a: (lambda r: (seen.append((self.comm.Get_size(), r)), r)[1])(measure(self, *a)))
