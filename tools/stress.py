@@ -27,6 +27,12 @@ while time.time() - t0 < budget:
         kw['padding'] = [1.5] * nd
         kw['axes'] = tuple((i,) for i in range(nd))
         kw.pop('collapse', None)
+    if dt in 'df' and 'padding' not in kw and rng.random() < 0.3:
+        # real-to-real stages on a random suffix of single-axis groups (transforms= dict)
+        kw['axes'] = tuple((i,) for i in range(nd))
+        kw.pop('collapse', None)
+        first = int(rng.integers(1, nd)) if nd > 1 else 0
+        kw['r2r'] = {(i,): int(rng.integers(3, 11)) for i in range(first, nd)}
     os.environ['GFFT_RELAY'] = str(rng.choice(['0', '1', 'measure']))
     os.environ['GFFT_FUSE_PACK'] = str(rng.choice(['0', '1', '1']))
     try:
