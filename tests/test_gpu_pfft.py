@@ -276,3 +276,35 @@ def test_callers_output_array_is_written_directly(P):
         assert untouched
         assert np.abs(uh - want[r]).max() < 1e-13 and np.abs(host - want[r]).max() < 1e-13
         assert np.abs(back - G[sl]).max() < 1e-13
+
+
+@pytest.mark.parametrize('P', [1, 2])
+def test_reference_docstring_example(P):
+    """The usage example of the reference's PFFT docstring (mpifft.py:176-199), verbatim but for
+    the import line: numpy shape array, np.zeros_like on a DistArray, numpy output arrays, and the
+    DCT-III `transforms=` configuration."""
+    import functools
+
+    def body(comm):
+        from mpi4py_fft_amd import PFFT, newDistArray
+        N = np.array([12, 14, 15], dtype=int)
+        fft = PFFT(comm, N, axes=(0, 1, 2))
+        u = newDistArray(fft, False)
+        u[:] = np.random.random(u.shape).astype(u.dtype)
+        u_hat = fft.forward(u)
+        uj = np.zeros_like(u)
+        uj = fft.backward(u_hat, uj)
+        assert np.allclose(uj, u)
+        from mpi4py_fft_amd.fftw import rfftn, irfftn, dctn, idctn
+        dct = functools.partial(dctn, type=3)
+        idct = functools.partial(idctn, type=3)
+        transforms = {(1, 2): (dct, idct)}
+        r2c = PFFT(comm, N, axes=((0,), (1, 2)), transforms=transforms)
+        u = newDistArray(r2c, False)
+        u[:] = np.random.random(u.shape).astype(u.dtype)
+        u_hat = r2c.forward(u)
+        uj = np.zeros_like(u)
+        uj = r2c.backward(u_hat, uj)
+        assert np.allclose(uj, u)
+        return True
+    assert all(cases.run_ranks(P, body))
