@@ -183,7 +183,9 @@ class DeviceArray:
     def __rsub__(self, other):
         return self._new(self._bin(other) - self._t)
 
-    def sum(self, axis=None):
+    def sum(self, axis=None, dtype=None, out=None, **kw):
+        # signature numpy's np.sum(a) dispatches to for non-ndarray objects
+        assert out is None
         r = self._t.sum() if axis is None else self._t.sum(dim=axis)
         return r.item() if r.ndim == 0 else self._new(r)
 

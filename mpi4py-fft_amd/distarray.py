@@ -71,13 +71,24 @@ class DistArray(DeviceArray):
         DeviceArray.__init__(self, shape, dtype, tensor=tensor,
                              val=val if (buffer is None and isinstance(val, Number)) else None)
 
-    def _view(self, sub):
-        # slicing returns a DistArray only while the shape is intact (distarray.py:155-175)
+    def __getitem__(self, key):
+        """A component of a tensor field stays a DistArray of lower rank (``v[0]`` of a rank-1
+        field is a rank-0 DistArray that ``PFFT(darray=...)`` accepts); anything that cuts into the
+        distributed axes is a plain array view (distarray.py:155-175)."""
+        if isinstance(key, DeviceArray):
+            key = key.tensor
+        sub = self._t[key]
         if sub.ndim == 0:
             return sub.item()
-        if tuple(sub.shape) == self._shape:
+        lead = None
+        if self._p0 is not None and self.ndim > 1:
+            if isinstance(key, (int, np.integer, slice)):
+                lead = self._rank > 0
+            elif isinstance(key, tuple) and all(isinstance(k, (int, np.integer, slice)) for k in key):
+                lead = len(key) <= self._rank
+        if lead:
             out = DistArray.__new__(DistArray)
-            out._p0, out._rank = self._p0, self._rank
+            out._p0, out._rank = self._p0, self._rank - (self.ndim - sub.ndim)
         else:
             out = DeviceArray.__new__(DeviceArray)
         out._shape, out._dtype, out._t = tuple(sub.shape), self._dtype, sub
@@ -161,7 +172,7 @@ class DistArray(DeviceArray):
                 index.append(int(g) - blk.start)
             else:
                 here = False
-        piece = np.asarray(self.v[tuple(index)]) if here else None
+        piece = np.array(self.v[tuple(index)], copy=True) if here else None    # own memory: ranks move on
         parent = next((c.relay_parent for c in self._p0.subcomm if getattr(c, 'relay_parent', None)), None)
         parts = [(tuple(mine[i] for i in kept), piece)]
         rank0 = True
