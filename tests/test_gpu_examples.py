@@ -1,8 +1,9 @@
-"""The reference's own example scripts (examples/transforms.py, examples/darray.py) with the import
-lines switched to this package and MPI.COMM_WORLD replaced by the communicator under test; reductions
-over ranks go through allgather_obj.  They exercise the drop-in surface end to end: numpy interop
-(np.sum / np.linalg.norm / np.zeros_like / np.allclose on device arrays), `darray=`, rank-1/2
-fields, `redistribute(out=)`, `get(gslice)`, `transforms=` with collapse / slab grid / padding."""
+"""Drop-in checks modelled on what the reference's example scripts do with the public API
+(examples/transforms.py: r2r `transforms=` with collapse / slab grid / per-axis padding and numpy
+in/out arrays; examples/darray.py: redistribute chains, `PFFT(darray=...)`, rank-1/2 fields,
+`redistribute(out=)`, `get(gslice)`), written against this package's communicators.  What matters
+is the numpy interop on device arrays: np.sum / np.linalg.norm / np.zeros_like / np.allclose,
+`field[i] = fft.forward(field[i], spec[i])`, and tensor components staying DistArrays."""
 import functools
 
 import numpy as np
@@ -13,121 +14,102 @@ pytestmark = pytest.mark.gpu
 from tests import cases
 
 
-def _transforms_example(comm):
-    from mpi4py_fft_amd import PFFT, newDistArray
-    from mpi4py_fft_amd.fftw import dctn, idctn
-    N = np.array([18, 18, 18], dtype=int)
-    dct = functools.partial(dctn, type=3)
-    idct = functools.partial(idctn, type=3)
-    transforms = {(1, 2): (dct, idct)}
-    fft = PFFT(comm, N, axes=None, collapse=True, grid=(-1,), transforms=transforms)
-    pfft = PFFT(comm, N, axes=((0,), (1, 2)), grid=(-1,), padding=[1.5, 1.0, 1.0], transforms=transforms)
-    assert fft.axes == pfft.axes
-    u = newDistArray(fft, forward_output=False)
-    u[:] = np.random.random(u.shape).astype(u.dtype)
-    u_hat = newDistArray(fft, forward_output=True)
-    u_hat = fft.forward(u, u_hat)
-    uj = np.zeros_like(u)
-    uj = fft.backward(u_hat, uj)
-    assert np.allclose(uj, u)
-    u_padded = newDistArray(pfft, forward_output=False)
-    uc = u_hat.copy()
-    u_padded = pfft.backward(u_hat, u_padded)
-    u_hat = pfft.forward(u_padded, u_hat)
-    assert np.allclose(u_hat, uc)
-    cfft = PFFT(comm, N, dtype=complex)
-    uc = np.random.random(cfft.backward.input_array.shape).astype(complex)
-    u2 = cfft.backward(uc)
-    u3 = uc.copy()
-    u3 = cfft.forward(u2, u3)
-    assert np.allclose(uc, u3)
-    fft.destroy()
-    pfft.destroy()
-    cfft.destroy()
+def _total(comm, x):
+    return sum(comm.allgather_obj(float(x)))
+
+
+def _field(comm, shape, aligned, **kw):
+    """DistArray distributed over every axis but `aligned` (what `DistArray(N, alignment=a)` gives
+    on COMM_WORLD in the reference)."""
+    from mpi4py_fft_amd import DistArray, Subcomm
+    grid = [0] * (len(shape) - kw.get('rank', 0))
+    grid[aligned] = 1
+    return DistArray(shape, subcomm=Subcomm(comm, grid), alignment=aligned, **kw)
+
+
+def r2r_slab_roundtrips(comm):
+    from mpi4py_fft_amd import PFFT, newDistArray, fftw
+    shape = np.array([18, 18, 18], dtype=int)
+    pair = (functools.partial(fftw.dctn, type=3), functools.partial(fftw.idctn, type=3))
+    plain = PFFT(comm, shape, axes=None, collapse=True, grid=(-1,), transforms={(1, 2): pair})
+    padded = PFFT(comm, shape, axes=((0,), (1, 2)), grid=(-1,), padding=[1.5, 1.0, 1.0], transforms={(1, 2): pair})
+    assert plain.axes == padded.axes == ((0,), (1, 2))
+    x = newDistArray(plain, forward_output=False)
+    x[:] = np.random.default_rng(comm.Get_rank()).random(x.shape).astype(x.dtype)
+    spec = plain.forward(x, newDistArray(plain, forward_output=True))
+    back = plain.backward(spec, np.zeros_like(x))            # numpy output array
+    assert isinstance(back, np.ndarray) and np.allclose(back, x)
+    keep = spec.copy()
+    wide = padded.backward(spec, newDistArray(padded, forward_output=False))
+    spec = padded.forward(wide, spec)
+    assert np.allclose(spec, keep)                            # pad then truncate = identity
+    cplx = PFFT(comm, shape, dtype=complex)
+    c0 = np.random.default_rng(1).random(cplx.backward.input_array.shape).astype(complex)
+    c1 = cplx.forward(cplx.backward(c0), c0.copy())           # numpy in, numpy out
+    assert np.allclose(c0, c1)
+    for f in (plain, padded, cplx):
+        f.destroy()
     return True
 
 
-def _darray_example(comm):
-    from mpi4py_fft_amd.distarray import DistArray, newDistArray
-    from mpi4py_fft_amd.mpifft import PFFT
-    from mpi4py_fft_amd import Subcomm
-    allreduce = lambda x: sum(comm.allgather_obj(float(x)))
-
-    def darr(N, alignment, **kw):
-        nd = len(N) - kw.get('rank', 0)
-        grid = [0] * nd
-        grid[alignment] = 1
-        return DistArray(N, subcomm=Subcomm(comm, grid), alignment=alignment, **kw)
-    N = (16, 14, 12)
-    z0 = darr(N, 0, dtype=float)
-    z0[:] = np.random.randint(0, 10, z0.shape)
-    s0 = allreduce(np.sum(z0))
-    z1 = z0.redistribute(2)
-    s1 = allreduce(np.sum(z1))
-    z2 = z1.redistribute(1)
-    s2 = allreduce(np.sum(z2))
-    assert s0 == s1 == s2
-    fft = PFFT(comm, darray=z2, axes=(0, 2, 1))
-    z3 = newDistArray(fft, forward_output=True)
-    z2c = z2.copy()
-    fft.forward(z2, z3)
-    fft.backward(z3, z2)
-    s0, s1 = np.linalg.norm(z2), np.linalg.norm(z2c)
-    assert abs(s0 - s1) < 1e-12, s0 - s1
-    v0 = newDistArray(fft, forward_output=False, rank=1)
-    v0[:] = np.random.random(v0.shape)
-    v0c = v0.copy()
-    v1 = newDistArray(fft, forward_output=True, rank=1)
-    for i in range(3):
-        v1[i] = fft.forward(v0[i], v1[i])
-    for i in range(3):
-        v0[i] = fft.backward(v1[i], v0[i])
-    s0, s1 = np.linalg.norm(v0c), np.linalg.norm(v0)
-    assert abs(s0 - s1) < 1e-12
-    nfft = PFFT(comm, darray=v0[0], axes=(0, 2, 1))
-    for i in range(3):
-        v1[i] = nfft.forward(v0[i], v1[i])
-    for i in range(3):
-        v0[i] = nfft.backward(v1[i], v0[i])
-    s0, s1 = np.linalg.norm(v0c), np.linalg.norm(v0)
-    assert abs(s0 - s1) < 1e-12
-    N = (6, 6, 6)
-    z = darr(N, 0, dtype=float)
+def distarray_tour(comm):
+    from mpi4py_fft_amd import PFFT, newDistArray
+    # alignment 0 -> 2 -> 1 conserves the sum
+    a0 = _field(comm, (16, 14, 12), 0, dtype=float)
+    a0[:] = np.random.default_rng(3 + comm.Get_rank()).integers(0, 10, a0.shape)
+    a2 = a0.redistribute(2)
+    a1 = a2.redistribute(1)
+    sums = [_total(comm, np.sum(a)) for a in (a0, a2, a1)]
+    assert sums[0] == sums[1] == sums[2]
+    # a transform planned from a distributed array, its aligned axis first
+    fft = PFFT(comm, darray=a1, axes=(0, 2, 1))
+    spec = newDistArray(fft, forward_output=True)
+    before = a1.copy()
+    fft.forward(a1, spec)
+    fft.backward(spec, a1)
+    assert abs(np.linalg.norm(a1) - np.linalg.norm(before)) < 1e-12
+    # vector fields, component by component, through two differently built plans
+    vec = newDistArray(fft, forward_output=False, rank=1)
+    vec[:] = np.random.default_rng(9).random(vec.shape)
+    vec0 = vec.copy()
+    vspec = newDistArray(fft, forward_output=True, rank=1)
+    component_plan = PFFT(comm, darray=vec[0], axes=(0, 2, 1))   # vec[0] is itself a DistArray
+    for plan in (fft, component_plan):
+        for c in range(3):
+            vspec[c] = plan.forward(vec[c], vspec[c])
+        for c in range(3):
+            vec[c] = plan.backward(vspec[c], vec[c])
+        assert abs(np.linalg.norm(vec0) - np.linalg.norm(vec)) < 1e-12
+    # global slices survive a round trip through another alignment
+    z = _field(comm, (6, 6, 6), 0, dtype=float)
     z[:] = comm.Get_rank()
-    g0 = z.get((0, slice(None), 0))
-    z2 = z.redistribute(2)
-    z = z2.redistribute(out=z)
-    g1 = z.get((0, slice(None), 0))
-    assert np.all(g0 == g1)
-    s0 = allreduce(np.linalg.norm(z) ** 2)
-    s1 = allreduce(np.linalg.norm(z2) ** 2)
-    assert abs(s0 - s1) < 1e-12
-    N = (3, 3, 6, 6, 6)
-    z2 = darr(N, 2, dtype=float, val=1, rank=2)
-    z2[:] = comm.Get_rank()
-    z1 = z2.redistribute(1)
-    z0 = z1.redistribute(0)
-    s0 = allreduce(np.linalg.norm(z2) ** 2)
-    s1 = allreduce(np.linalg.norm(z0) ** 2)
-    assert abs(s0 - s1) < 1e-12
-    z1 = z0.redistribute(out=z1)
-    z0 = z1.redistribute(out=z0)
-    N = (6, 6, 6, 6, 6)
-    m0 = darr(N, 2, dtype=float)
+    line0 = z.get((0, slice(None), 0))
+    z_other = z.redistribute(2)
+    z = z_other.redistribute(out=z)
+    line1 = z.get((0, slice(None), 0))
+    assert np.all(line0 == line1)
+    assert abs(_total(comm, np.linalg.norm(z) ** 2) - _total(comm, np.linalg.norm(z_other) ** 2)) < 1e-12
+    # rank-2 tensor field and a 5-D scalar field
+    t2 = _field(comm, (3, 3, 6, 6, 6), 2, dtype=float, val=1, rank=2)
+    t2[:] = comm.Get_rank()
+    t1 = t2.redistribute(1)
+    t0 = t1.redistribute(0)
+    assert abs(_total(comm, np.linalg.norm(t2) ** 2) - _total(comm, np.linalg.norm(t0) ** 2)) < 1e-12
+    t1 = t0.redistribute(out=t1)
+    t0 = t1.redistribute(out=t0)
+    m0 = _field(comm, (6, 6, 6, 6, 6), 2, dtype=float)
     m0[:] = comm.Get_rank()
-    m1 = m0.redistribute(4)
-    m0 = m1.redistribute(out=m0)
-    s0 = allreduce(np.linalg.norm(m0) ** 2)
-    s1 = allreduce(np.linalg.norm(m1) ** 2)
-    assert abs(s0 - s1) < 1e-12
+    m4 = m0.redistribute(4)
+    m0 = m4.redistribute(out=m0)
+    assert abs(_total(comm, np.linalg.norm(m0) ** 2) - _total(comm, np.linalg.norm(m4) ** 2)) < 1e-12
     return True
 
 
 @pytest.mark.parametrize('P', [2, 4])     # on one rank collapse merges all three axes (in the reference too)
-def test_examples_transforms(P):
-    assert all(cases.run_ranks(P, _transforms_example))
+def test_r2r_slab_roundtrips(P):
+    assert all(cases.run_ranks(P, r2r_slab_roundtrips))
 
 
 @pytest.mark.parametrize('P', [1, 2, 4])
-def test_examples_darray(P):
-    assert all(cases.run_ranks(P, _darray_example))
+def test_distarray_tour(P):
+    assert all(cases.run_ranks(P, distarray_tour))
