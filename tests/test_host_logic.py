@@ -304,3 +304,29 @@ def test_distarray_get_global_slice():
     assert np.array_equal(res[0][0], [0, 0, 0, 2, 2, 2])
     assert np.array_equal(res[0][1], np.arange(216, dtype=float).reshape(6, 6, 6)[:, 3, :])
     assert all(r[0] is None and r[1] is None for r in res[1:])
+
+
+def test_distarray_get_on_tensor_fields():
+    """get(gslice) with leading tensor indices, rank 0-2, 2-D and 3-D (what tests/test_darray.py:30-45,
+    82-97 probe): a line of a unit-filled field sums to its length on rank 0."""
+    from tests import thread_comm
+    from mpi4py_fft_amd import DistArray, Subcomm
+
+    def body(comm):
+        got = []
+        for N, grid in (((8, 12), [0, 1]), ((8, 6, 10), [0, 0, 1])):
+            for rank in (0, 1, 2):
+                a = DistArray((len(N),) * rank + N, subcomm=Subcomm(comm, grid), val=1, rank=rank)
+                assert a.rank == rank and a.global_shape == (len(N),) * rank + N
+                lines = []
+                for ax in range(len(N)):
+                    g = [0] * len(N)
+                    g[ax] = slice(None)
+                    lines.append(a.get((0,) * rank + tuple(g)))
+                got.append((N, lines))
+        return got
+    res = thread_comm.run(4, body)
+    for N, lines in res[0]:
+        for ax, k in enumerate(lines):
+            assert len(k) == N[ax] and np.sum(k) == N[ax]
+    assert all(k is None for r in res[1:] for _, lines in r for k in lines)
