@@ -109,6 +109,7 @@ class DistArray(DeviceArray):
         """The plain array view (``.view(np.ndarray)`` in the reference)."""
         out = DeviceArray.__new__(DeviceArray)
         out._shape, out._dtype, out._t = self._shape, self._dtype, self._t
+        out.base = self            # as ndarray views expose the array they were taken from
         return out
 
     def local_slice(self):

@@ -330,3 +330,28 @@ def test_distarray_get_on_tensor_fields():
         for ax, k in enumerate(lines):
             assert len(k) == N[ax] and np.sum(k) == N[ax]
     assert all(k is None for r in res[1:] for _, lines in r for k in lines)
+
+
+def test_newdistarray_variants_plan_transforms():
+    """newDistArray(view / rank / forward_output) and PFFT(darray=component) for every variant
+    (the combinations tests/test_darray.py:111-133 walks through)."""
+    from tests import thread_comm
+    from mpi4py_fft_amd import PFFT, DistArray, newDistArray
+    from mpi4py_fft_amd.array import DeviceArray
+
+    def body(comm):
+        pfft = PFFT(comm, (8, 8, 8))
+        for spectral in (True, False):
+            for rank in (0, 1, 2):
+                a = newDistArray(pfft, forward_output=spectral, rank=rank)
+                assert isinstance(a, DistArray) and a.rank == rank
+                comp = a[(0,) * rank] if rank else a
+                assert isinstance(comp, DistArray) and comp.rank == 0
+                q = PFFT(comm, darray=comp)
+                assert q.forward.input_array.shape == comp.shape
+                q.destroy()
+                w = newDistArray(pfft, forward_output=spectral, rank=rank, view=True)
+                assert isinstance(w, DeviceArray) and not isinstance(w, DistArray) and w.base.rank == rank
+        pfft.destroy()
+        return True
+    assert all(thread_comm.run(2, body))
