@@ -267,16 +267,31 @@ class Transfer:
         assert self.subshapeB == tuple(arrayB.shape)
         assert self.dtype == arrayA.dtype
         assert self.dtype == arrayB.dtype
-        self._move(arrayA, arrayB, self.subshapeA, self.axisA, self._countsA,
+        src, dst = self._on_device(arrayA, True), self._on_device(arrayB, False)
+        self._move(src, dst, self.subshapeA, self.axisA, self._countsA,
                    self.subshapeB, self.axisB, self._countsB, self.packedA, self.packedB)
+        if dst is not arrayB:
+            arrayB[...] = np.asarray(dst)
 
     def backward(self, arrayB, arrayA):
         assert self.subshapeA == tuple(arrayA.shape)
         assert self.subshapeB == tuple(arrayB.shape)
         assert self.dtype == arrayA.dtype
         assert self.dtype == arrayB.dtype
-        self._move(arrayB, arrayA, self.subshapeB, self.axisB, self._countsB,
+        src, dst = self._on_device(arrayB, True), self._on_device(arrayA, False)
+        self._move(src, dst, self.subshapeB, self.axisB, self._countsB,
                    self.subshapeA, self.axisA, self._countsA, self.packedB, self.packedA)
+        if dst is not arrayA:
+            arrayA[...] = np.asarray(dst)
+
+    @staticmethod
+    def _on_device(a, load):
+        """Host (numpy) arrays are accepted as the reference's callers pass them (pencil.py:168-201
+        works on ndarrays): staged through a device array, copied back by the caller."""
+        if isinstance(a, DeviceArray):
+            return a
+        from .array import asdevice, empty
+        return asdevice(np.ascontiguousarray(a)) if load else empty(a.shape, a.dtype)
 
     def destroy(self):
         self._stage = {}

@@ -355,3 +355,37 @@ def test_newdistarray_variants_plan_transforms():
         pfft.destroy()
         return True
     assert all(thread_comm.run(2, body))
+
+
+def test_transfer_accepts_numpy_arrays_and_typecodes():
+    """Pencil.transfer(pencilA, pencilB, 'd') called as an unbound method with a typecode, Subcomm
+    from None / an int, pencils of lower-dimensional subcomms, host arrays in and out: the calling
+    conventions of tests/test_pencil.py:28-55."""
+    from tests import thread_comm
+    from mpi4py_fft_amd.pencil import Subcomm, Pencil
+
+    def body(comm):
+        for shape in ((7, 8), (7, 8, 9)):
+            for pdim in [None] + list(range(1, len(shape) - 1)):
+                sub = Subcomm(comm, pdim)
+                p0 = Pencil(sub, shape)
+                pA = p0.pencil(0)
+                pB = pA.pencil(1)
+                pC = pB.pencil(0 if len(shape) == 2 else -1)
+                for code in 'fD':
+                    t1, t2 = Pencil.transfer(pA, pB, code), Pencil.transfer(pB, pC, code)
+                    X = np.random.default_rng(comm.Get_rank()).random(pA.subshape).astype(code)
+                    A, B, C = (np.zeros(p.subshape, dtype=code) for p in (pA, pB, pC))
+                    A[...] = X
+                    t1.forward(A, B)
+                    t2.forward(B, C)
+                    B.fill(0)
+                    t2.backward(C, B)
+                    A.fill(0)
+                    t1.backward(B, A)
+                    assert np.allclose(A, X)
+                    t1.destroy()
+                    t2.destroy()
+                sub.destroy()
+        return True
+    assert all(thread_comm.run(3, body))
