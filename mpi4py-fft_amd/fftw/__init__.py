@@ -6,9 +6,10 @@ reference's FFTW wrapper runs on the MI355X engine.  A planner function allocate
 array, computes the ``1/M`` normalisation and returns a plan object (:class:`FFT`) that owns a
 ``gfft_plan`` handle of libgfft.so; calling the object executes the plan on the bound device
 arrays.  The real-to-real planners ``dctn, idctn, dstn, idstn`` (types 1-4, FFTW's unnormalised
-REDFTxx / RODFTxx definitions) plan through ``gfft_plan_create_r2r``.  hfftn/ihfftn, the
-halfcomplex / Hartley kinds, wisdom and time limits are FFTW features outside this path: asking
-for them raises ``NotImplementedError``.
+REDFTxx / RODFTxx definitions) plan through ``gfft_plan_create_r2r``; ``hfftn / ihfftn`` are the
+c2r / r2c plans under their other names, as in the reference.  The halfcomplex / Hartley kinds,
+wisdom and time limits are FFTW features outside this path: asking for them raises
+``NotImplementedError``.
 """
 import numpy as np
 
@@ -274,15 +275,15 @@ dctn, idctn = _r2r_planner('dctn', dct_type), _r2r_planner('idctn', idct_type)
 dstn, idstn = _r2r_planner('dstn', dst_type), _r2r_planner('idstn', idst_type)
 
 
-def _out_of_scope(name):
-    def f(*a, **k):
-        raise NotImplementedError('%s: halfcomplex transforms are an FFTW feature outside the PFFT '
-                                  'path this package accelerates' % name)
-    f.__name__ = name
-    return f
+def hfftn(input_array, s=None, axes=(-1,), threads=1, flags=(FFTW_MEASURE,), output_array=None):
+    """Plan the transform of an array with Hermitian symmetry (xfftn.py:684-761): the same
+    complex-to-real plan `irfftn` builds (kind C2R), without its PRESERVE_INPUT restriction."""
+    return irfftn(input_array, s, axes, threads, tuple(f for f in flags if f != FFTW_PRESERVE_INPUT), output_array)
 
 
-hfftn, ihfftn = _out_of_scope('hfftn'), _out_of_scope('ihfftn')
+def ihfftn(input_array, s=None, axes=(-1,), threads=1, flags=(FFTW_MEASURE,), output_array=None):
+    """Plan the inverse of `hfftn` (xfftn.py:616-682): the real-to-complex plan of `rfftn`."""
+    return rfftn(input_array, s, axes, threads, flags, output_array)
 
 
 def get_normalization(kind, shape, axes):

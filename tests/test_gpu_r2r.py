@@ -88,8 +88,6 @@ def test_r2r_refusals():
         fftw.get_planned_FFT(a, asdevice(np.ones(1)), (0,), [fftw.FFTW_REDFT00])
     with pytest.raises(NotImplementedError):
         fftw.get_planned_FFT(asdevice(np.ones(8)), asdevice(np.ones(8)), (0,), [fftw.FFTW_R2HC])
-    with pytest.raises(NotImplementedError):
-        fftw.hfftn(a)
 
 
 @pytest.mark.parametrize('dt', ['d', 'f'])
@@ -142,3 +140,34 @@ def test_pfft_with_r2r_transforms(P):
             assert uh.shape == want[r].shape and uh.dtype == want[r].dtype, (shape, axes)
             assert np.abs(uh - want[r]).max() <= 1e-12 * max(1e-30, np.abs(want[r]).max()), (shape, axes)
             assert np.abs(back - G[sl]).max() <= 1e-12, (shape, axes)
+
+
+def test_hermitian_planners():
+    """hfftn / ihfftn (xfftn.py:616-761): docstring known answers and the round trip of
+    tests/test_fftw.py:77-83 (explicit input array, implicit=False, normalize=True)."""
+    from mpi4py_fft_amd import fftw
+    A = fftw.aligned(4, dtype='D')
+    h = fftw.hfftn(A, flags=(fftw.FFTW_ESTIMATE,))
+    A[:] = 1, 2, 3, 4
+    assert np.allclose(h(), [15., -4., 0., -1., 0., -4.], atol=1e-13)
+    h7 = fftw.hfftn(A, s=(7,), flags=(fftw.FFTW_ESTIMATE,))
+    A[:] = 1, 2, 3, 4
+    assert np.allclose(h7(), [19., -5.04891734, -0.30797853, -0.64310413, -0.64310413, -0.30797853, -5.04891734], atol=1e-7)
+    assert h7.input_array is A
+    R = fftw.aligned(4, dtype='d')
+    ih = fftw.ihfftn(R, flags=(fftw.FFTW_ESTIMATE,))
+    R[:] = 1, 2, 3, 4
+    assert np.allclose(ih(), [10, -2 + 2j, -2], atol=1e-13)
+    for shape, axes in (((7, 8), (1,)), ((8, 10, 7), (2, 1))):
+        x = np.random.default_rng(2).random(shape)
+        r = fftw.aligned(shape, dtype='d')
+        fwd = fftw.rfftn(r, None, axes)
+        r[:] = x
+        B = np.asarray(fwd()).copy()
+        sa = np.take(shape, axes) if shape[axes[-1]] % 2 == 1 else None
+        hp = fftw.hfftn(fwd.output_array, sa, axes, output_array=r)
+        hp.input_array[...] = B
+        AC = hp().copy()
+        ip = fftw.ihfftn(r, None, axes, output_array=fwd.output_array)
+        A2 = ip(AC, implicit=False, normalize=True)
+        assert np.allclose(A2, B, atol=1e-12)
