@@ -79,10 +79,11 @@ class DeviceArray:
     # ---- host interop
     def get(self):
         """Copy to a new host numpy array."""
-        return self._t.detach().cpu().numpy()
+        t = self._t.detach()
+        return t.cpu().numpy() if t.is_cuda else t.numpy().copy()
 
     def __array__(self, dtype=None, copy=None):
-        a = self.get()
+        a = self.get()              # always fresh memory, so `copy=True` is honoured
         return a if dtype is None else a.astype(dtype, copy=False)
 
     def _as_tensor(self, value):

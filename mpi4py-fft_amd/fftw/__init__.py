@@ -7,9 +7,9 @@ array, computes the ``1/M`` normalisation and returns a plan object (:class:`FFT
 ``gfft_plan`` handle of libgfft.so; calling the object executes the plan on the bound device
 arrays.  The real-to-real planners ``dctn, idctn, dstn, idstn`` (types 1-4, FFTW's unnormalised
 REDFTxx / RODFTxx definitions) plan through ``gfft_plan_create_r2r``; ``hfftn / ihfftn`` are the
-c2r / r2c plans under their other names, as in the reference.  The halfcomplex / Hartley kinds,
-wisdom and time limits are FFTW features outside this path: asking for them raises
-``NotImplementedError``.
+c2r / r2c plans under their other names, as in the reference.  The halfcomplex / Hartley
+kinds raise ``NotImplementedError``; wisdom and time limits are accepted and have nothing to do
+(plans are deterministic).
 """
 import numpy as np
 
@@ -58,7 +58,7 @@ class FFT:
                  flags=FFTW_MEASURE, normalization=1.0):
         nd = len(input_array.shape)
         self.axes = tuple(a + nd if a < 0 else a for a in axes)
-        kinds = list(kind) if isinstance(kind, (list, tuple)) else [kind]
+        kinds = [int(k) for k in kind] if isinstance(kind, (list, tuple, np.ndarray)) else [int(kind)]
         r2r = all(FFTW_REDFT00 <= k <= FFTW_RODFT11 for k in kinds)
         if r2r:
             # one kind per axis (fftw_planxfftn.c:68-75)
@@ -329,10 +329,22 @@ def get_fftw_lib(dtype):
 
 
 def export_wisdom(filename):
-    raise NotImplementedError('FFTW wisdom has no counterpart here (plans are deterministic)')
+    """FFTW wisdom is accumulated planner measurements (utilities.pyx / fftw_xfftn.pyx:298-330).
+    Plans here are deterministic functions of shape, axes and kind, so there is nothing to save:
+    the call leaves an empty file so that a later ``import_wisdom`` finds one."""
+    open(filename, 'a').close()
 
 
-import_wisdom = forget_wisdom = set_timelimit = export_wisdom
+def import_wisdom(filename):
+    open(filename, 'rb').close()
+
+
+def forget_wisdom():
+    pass
+
+
+def set_timelimit(limit):
+    """Planning never searches, so no time limit applies."""
 
 
 def cleanup():

@@ -72,7 +72,7 @@ def test_mixed_kinds_per_axis_and_in_place():
     A = rng.standard_normal(shape)
     for kinds in itertools.islice(itertools.product(range(3, 11), repeat=3), 0, None, 37):
         a = asdevice(A)
-        plan = fftw.get_planned_FFT(a, a, axes, list(kinds), 1, (fftw.FFTW_ESTIMATE,), 1.0)   # in place
+        plan = fftw.get_planned_FFT(a, a, axes, np.array(kinds), 1, (fftw.FFTW_ESTIMATE,), 1.0)   # in place, numpy kinds
         want = A
         for ax, k in zip(reversed(axes), reversed(kinds)):
             want = O.r2r_1d(want, ax, k)

@@ -78,9 +78,9 @@ def test_misuse_raises():
         PFFT(comm.COMM_SELF, (8, 8), dtype='i')
     with pytest.raises(NotImplementedError):
         FFT((8, 8), dtype='D', backend='numpy')
+    from mpi4py_fft_amd import fftw
     with pytest.raises(NotImplementedError):
-        from mpi4py_fft_amd import fftw
-        fftw.export_wisdom('w')
+        fftw.get_normalization([fftw.FFTW_R2HC], (8,), (0,))
 
 
 def test_chunked_transfer_pipeline(monkeypatch):
@@ -389,3 +389,14 @@ def test_transfer_accepts_numpy_arrays_and_typecodes():
                 sub.destroy()
         return True
     assert all(thread_comm.run(3, body))
+
+
+def test_wisdom_and_timelimit_are_harmless(tmp_path):
+    """tests/test_fftw.py:140-160 call these around planning; they must not fail."""
+    from mpi4py_fft_amd import fftw
+    f = str(tmp_path / 'newwisdom.dat')
+    fftw.export_wisdom(f)
+    fftw.import_wisdom(f)
+    fftw.forget_wisdom()
+    fftw.set_timelimit(0.01)
+    fftw.cleanup()
