@@ -122,13 +122,18 @@ def test_pfft_with_r2r_transforms(P):
             ((12, 14, 16), ((0,), (1, 2)), {(1, 2): (dct, idct)}, {(1, 2): fftw.FFTW_REDFT01}),
             ((12, 14, 16), ((0,), (1,), (2,)), {(2,): (dst, idst), (1,): (dct, idct)}, {(2,): fftw.FFTW_RODFT10, (1,): fftw.FFTW_REDFT01}),
             ((8, 9, 10, 12), ((0,), (1, 2), (3,)), {(1, 2): (dct, idct), (3,): (dst, idst)}, {(1, 2): fftw.FFTW_REDFT01, (3,): fftw.FFTW_RODFT10}),
-            ((12, 16), ((0,), (1,)), {(0,): (dct, idct), (1,): (dct, idct)}, {(0,): fftw.FFTW_REDFT01, (1,): fftw.FFTW_REDFT01})):
-        ref = O.OPFFT(P, shape, axes=axes, dtype='d', r2r=spec)
+            ((12, 16), ((0,), (1,)), {(0,): (dct, idct), (1,): (dct, idct)}, {(0,): fftw.FFTW_REDFT01, (1,): fftw.FFTW_REDFT01}),
+            # the configuration of tests/test_mpifft.py:35-43 (5-D, slab, DCT-III and DST-III pairs)
+            ((5, 6, 7, 8, 9), ((0,), (1, 2), (3, 4)),
+             {(1, 2): (dct, idct), (3, 4): (functools.partial(fftw.dstn, type=3), functools.partial(fftw.idstn, type=3))},
+             {(1, 2): fftw.FFTW_REDFT01, (3, 4): fftw.FFTW_RODFT01})):
+        grid = dict(grid=(-1,)) if len(shape) == 5 else {}
+        ref = O.OPFFT(P, shape, axes=axes, dtype='d', r2r=spec, **grid)
         G = O.rng_array(shape, 'd', 11)
         want = ref.forward(ref.scatter(G))
 
         def body(comm):
-            fft = PFFT(comm, shape, axes=axes, dtype='d', transforms=tr)
+            fft = PFFT(comm, shape, axes=axes, dtype='d', transforms=tr, **grid)
             u = newDistArray(fft, False)
             u[...] = G[fft.local_slice(False)]
             uh = np.asarray(fft.forward(u)).copy()
