@@ -15,3 +15,5 @@ from .pencil import Pencil, Subcomm, Transfer
 from .libfft import FFT
 from . import fftw
 from .fftw import fftlib
+from . import spectral
+from .io import HDF5File, NCFile, generate_xdmf
