@@ -157,6 +157,29 @@ def main():
                         algorithmic_bytes_per_launch=k['bytes'],
                         all_kernels={kk: round(v['ms'] / v['launches'], 4) for kk, v in kern.items()})
 
+    # streaming-copy ceiling of this very box and run (same byte count per launch as one pass of the
+    # dominant kernel when it fits): what "100 % of achievable HBM" means next to roofline.frac
+    copy_ceiling = None
+    if rank == 0:
+        try:
+            nbytes = min(16 << 30, (u.tensor.numel() * 16) // 256 * 256)
+            src, dst = u.tensor, fft.forward.output_array.tensor
+            L, st = _lib.lib(), _lib.current_stream()
+            for _ in range(2):
+                _lib.check(L.gfft_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, st))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                _lib.check(L.gfft_probe_copy(src.data_ptr(), dst.data_ptr(), nbytes, st))
+            e1.record()
+            torch.cuda.synchronize()
+            gbs = 2 * nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            copy_ceiling = {'gbs': round(gbs, 1), 'frac_of_peak': round(gbs / HBM_PEAK_GBS, 4),
+                            'bytes_per_launch': 2 * nbytes,
+                            'what': 'dst[i] = src[i], 16 B per lane x 4 in flight (gfft_probe_copy), HIP events'}
+        except Exception as e:
+            copy_ceiling = {'gbs': None, 'what': 'failed: %r' % (e,)}
+    world.barrier()
     grid = [c.Get_size() for c in fft.subcomm]
     exchange = [dict(ranks=t.comm.Get_size(), route=t.exchange,
                      **({'measured_s': [round(x, 5) for x in t.route_times]} if hasattr(t, 'route_times') else {}))
@@ -229,7 +252,10 @@ def main():
                        'round_trip_rel_err': rt_err},
             'whole_transform_hbm': whole,
             'roofline': roofline,
+            'hbm_copy_ceiling': copy_ceiling,
         }
+        if roofline and copy_ceiling and copy_ceiling.get('gbs'):
+            roofline['frac_of_copy_ceiling'] = round(roofline['achieved'] / copy_ceiling['gbs'], 4)
         if not args.no_cpu and size == 1:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
             try:
