@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('nranks,port', [(2, 29551), (4, 29552)])
+@pytest.mark.parametrize('nranks,port', [(2, 29551), (4, 29552), (8, 29553)])
 def test_pfft_across_processes_on_one_gpu(nranks, port):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nranks),
            '--master-addr', '127.0.0.1', '--master-port', str(port),
