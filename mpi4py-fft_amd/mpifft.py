@@ -2,9 +2,10 @@
 
 Same public behaviour as mpi4py_fft/mpifft.py (constructor arguments, ``forward``/``backward``
 callables, ``shape/local_slice/global_shape/dimensions/dtype`` queries, pencils, axes groups,
-grid rules, collapse, padding).  The plan it builds drives device objects: one
+grid rules, collapse, padding, ``transforms=``).  The plan it builds drives device objects: one
 :class:`libfft.FFT` per axis group (HIP kernels) and one :class:`pencil.Transfer` per change of
-alignment (pack kernel + RCCL all-to-all + unpack kernel).
+alignment (RCCL all-to-all between exchange buffers that the neighbouring transforms write and
+read directly where they can, see ``_fuse_packs``).
 
 Two things are done differently because they only cost time in the reference:
   * a ``Transfer`` over a single-rank communicator is a whole-array self copy there

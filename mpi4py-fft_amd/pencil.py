@@ -3,11 +3,13 @@
 Mirrors the public surface of mpi4py_fft/pencil.py (``Subcomm``, ``Pencil``, ``Transfer``,
 ``_blockdist``) so callers and tests read the same.  What differs is the engine underneath
 ``Transfer``: the reference hands MPI a pair of subarray datatypes per peer and lets
-``Alltoallw`` gather/scatter (pencil.py:12-29,182-183); here a HIP kernel packs the p sub-blocks
-into one contiguous send buffer, RCCL's all-to-all(v) moves them over xGMI
-(``torch.distributed.all_to_all_single`` on the "nccl" backend), and a second kernel unpacks --
-and when the split axis is the outermost axis the pack (or unpack) is skipped because the
-sub-blocks already are contiguous.
+``Alltoallw`` gather/scatter (pencil.py:12-29,182-183); here the p sub-blocks travel as one
+contiguous send buffer through RCCL's all-to-all(v) over xGMI
+(``torch.distributed.all_to_all_single`` on the "nccl" backend, or the relayed all-link route of
+relay.py).  Inside a PFFT the neighbouring FFT kernels write the send buffer and read the receive
+buffer themselves (``packedA`` / ``packedB``); otherwise a HIP kernel packs and a second one
+unpacks -- skipped when the split axis is the outermost axis, whose sub-blocks already are
+contiguous.
 """
 import numpy as np
 import torch
