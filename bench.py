@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark: 3-D c2c PFFT, 1024^3 complex128, forward + backward per step.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run,
-                                                        one rank per GPU, RCCL over xGMI)
+  python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  `value` = whole-job GFLOP/s with the work model of BASELINE.md
-section 3 (5 N log2 N flops per 1-D line => 1.6106e11 per 1024^3 transform, fwd + bwd per step),
-inputs resident in HBM before the timed region, barrier + device sync on both sides, max over
-ranks.  `roofline` is for the dominant kernel (the strided-axis pass kernel): algorithmic bytes
-per launch (one read + one write of the local array) / its mean launch duration from HIP events
-recorded on the launch stream inside the timed region.  `cpu_baseline` times the oracle (numpy
-restatement of the reference path; scipy pocketfft on all host cores) on a bounded sample.
+N > 1 from a plain shell re-launches itself under `torch.distributed.run` (one rank per GPU, RCCL
+over xGMI); a launch that already carries RANK / WORLD_SIZE (the driver's torchrun line) is used
+as it is.  Rank 0 prints ONE JSON line.
+
+`value` = whole-job GFLOP/s with the work model of BASELINE.md section 3 (5 N log2 N flops per
+1-D line => 1.6106e11 per 1024^3 transform, fwd + bwd per step), inputs resident in HBM before the
+timed region, barrier + device sync on both sides, max over ranks.  `roofline` is for the dominant
+kernel: algorithmic bytes per launch (one read + one write of the local array) / its mean launch
+duration from HIP events recorded on the launch stream inside the timed region.  `cpu_baseline`
+times the CPU path on this box's host cores on a bounded sample (N = 1 only): FFTW through its guru
+interface when a libfftw3 (or MKL's FFTW3 interface) can be loaded, else the oracle (pocketfft).
+
+At N > 1 the headline is timed FIRST on the plain route (one RCCL all-to-all per redistribution,
+exchange buffers written / read by the FFT kernels).  Everything after that -- the measured route
+choice (relay.py), the stage breakdown, the slab grid -- runs under a deadline and can only add to
+the line, never lose it: if a later phase hangs or raises, rank 0 prints what it has.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import re
 import threading
@@ -23,20 +33,173 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ~5.3-5.6 TB/s
 
 
 def flops_c2c(shape):
+    import numpy as np
     n = float(np.prod(shape))
     return 5.0 * n * np.log2(n)
 
 
-def cpu_baseline(cores, budget_s=25.0):
-    """Oracle (port of the reference path) on the host: 3-D c2c fwd+bwd, largest power-of-two
-    cube whose estimated time fits the budget."""
+# ---- cpu_baseline leg: the CPU path timed on this box's host cores ------------------------------
+class _Fftw:
+    """An FFTW3 (double precision) implementation loaded through ctypes, driven through the guru
+    interface exactly as the reference's C planner drives it (fftw_planxfftn.c:20-76: row-major
+    strides, one transform dim per listed axis, every other dim a batch dim).  Candidates in
+    order: libfftw3 (+ libfftw3_threads / _omp), then MKL's FFTW3 interface inside libmkl_rt."""
+    MEASURE, ESTIMATE = 0, 64
+
+    def __init__(self, cores):
+        import ctypes
+        import ctypes.util
+        import glob
+        c = ctypes
+        cands = []
+        p = ctypes.util.find_library('fftw3')
+        if p:
+            cands.append((p, 'fftw3'))
+        for q in [ctypes.util.find_library('mkl_rt')] + sorted(glob.glob('/opt/conda/lib/libmkl_rt.so*')):
+            if q:
+                cands.append((q, 'mkl'))
+        self.lib = None
+        for path, kind in cands:
+            try:
+                self.lib = c.CDLL(path, mode=c.RTLD_GLOBAL)
+                self.kind, self.path = kind, path
+                break
+            except OSError:
+                continue
+        if self.lib is None:
+            raise OSError('no FFTW3 implementation found (fftw3, mkl_rt)')
+        L = self.lib
+
+        class iodim(c.Structure):
+            _fields_ = [('n', c.c_int), ('is_', c.c_int), ('os', c.c_int)]
+        self.iodim = iodim
+        L.fftw_plan_guru_dft.restype = c.c_void_p
+        L.fftw_plan_guru_dft.argtypes = [c.c_int, c.POINTER(iodim), c.c_int, c.POINTER(iodim), c.c_void_p,
+                                         c.c_void_p, c.c_int, c.c_uint]
+        L.fftw_execute_dft.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p]
+        L.fftw_destroy_plan.argtypes = [c.c_void_p]
+        self.threads = 1
+        if kind == 'fftw3':
+            for nm in ('fftw3_threads', 'fftw3_omp'):
+                tp = ctypes.util.find_library(nm)
+                if tp:
+                    T = c.CDLL(tp, mode=c.RTLD_GLOBAL)
+                    T.fftw_init_threads()
+                    T.fftw_plan_with_nthreads(c.c_int(cores))
+                    self.threads = cores
+                    break
+            try:
+                self.version = c.c_char_p.in_dll(L, 'fftw_version').value.decode()
+            except Exception:
+                self.version = 'fftw3'
+        else:
+            try:
+                L.MKL_Set_Num_Threads(c.c_int(cores))
+                buf = c.create_string_buffer(256)
+                L.MKL_Get_Version_String(buf, 256)
+                self.version = buf.value.decode().strip()
+                self.threads = int(L.MKL_Get_Max_Threads())
+            except Exception:
+                self.version, self.threads = 'MKL FFTW3 interface', cores
+
+    def plan(self, arr_in, arr_out, axes, sign, flags):
+        """fftw_planxfftn for a c2c kind (fftw_planxfftn.c:10-57)."""
+        import ctypes
+        nd = arr_in.ndim
+        sizes = arr_in.shape
+        strides = [1] * nd
+        for i in range(nd - 2, -1, -1):
+            strides[i] = sizes[i + 1] * strides[i + 1]
+        ranks = (self.iodim * len(axes))(*[self.iodim(sizes[a], strides[a], strides[a]) for a in axes])
+        rest = [i for i in range(nd) if i not in axes]
+        dims = (self.iodim * max(1, len(rest)))(*[self.iodim(sizes[i], strides[i], strides[i]) for i in rest])
+        return self.lib.fftw_plan_guru_dft(len(axes), ranks, len(rest), dims, arr_in.ctypes.data,
+                                           arr_out.ctypes.data, sign, flags)
+
+
+def _cpu_fftw(cores, budget_s):
+    """3-D c2c fwd+bwd through FFTW's guru interface with the stage structure of a 1-rank PFFT
+    (mpifft.py:313-331: axis 2, then 1, then 0, forward scaled by 1/N); when the library cannot plan
+    a one-axis transform with two batch dims (MKL's interface) the collapse=True form -- one 3-D
+    plan -- is used instead."""
+    import numpy as np
+    F = _Fftw(cores)
+    n, best = 128, None
+    while n <= 1024:
+        shape = (n, n, n)
+        u = np.empty(shape, dtype='D')
+        v = np.empty(shape, dtype='D')
+        t_plan = time.perf_counter()
+        form = 'per-axis plans (2, 1, 0)'
+        flags = F.MEASURE if n <= 256 else F.ESTIMATE   # MEASURE at 512^3+ would eat the time budget
+        fwd = [F.plan(u, v, [2], -1, flags), F.plan(v, v, [1], -1, flags), F.plan(v, v, [0], -1, flags)]
+        bwd = [F.plan(v, v, [0], 1, flags), F.plan(v, v, [1], 1, flags), F.plan(v, u, [2], 1, flags)]
+        if not all(fwd + bwd):
+            for p in fwd + bwd:
+                if p:
+                    F.lib.fftw_destroy_plan(p)
+            form = 'one 3-D plan (collapse=True)'
+            fwd, bwd = [F.plan(u, v, [0, 1, 2], -1, flags)], [F.plan(v, u, [0, 1, 2], 1, flags)]
+            if not all(fwd + bwd):
+                raise RuntimeError('guru planner returned NULL')
+        t_plan = time.perf_counter() - t_plan
+        # synthetic input: a random complex plane times a random complex factor per slab (filling
+        # 16 GiB with the generator itself would take longer than the transforms being timed)
+        rng = np.random.default_rng(1234)
+        plane = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        w = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        for i in range(n):
+            np.multiply(plane, w[i], out=u[i])
+        u0 = u[:4].copy()
+        ex = F.lib.fftw_execute_dft
+        times = []
+        t_all = time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            srcs = [u] + [v] * (len(fwd) - 1)
+            for p, a in zip(fwd, srcs):
+                ex(p, a.ctypes.data, v.ctypes.data)
+            v *= 1.0 / u.size                           # libfft.py:412-413
+            dsts = [v] * (len(bwd) - 1) + [u]
+            for p, b in zip(bwd, dsts):
+                ex(p, v.ctypes.data, b.ctypes.data)
+            times.append(time.perf_counter() - t0)
+            if len(times) >= 5 or time.perf_counter() - t_all > 0.5 * budget_s:
+                break
+        err = float(np.linalg.norm(u[:4] - u0) / np.linalg.norm(u0))
+        for p in fwd + bwd:
+            F.lib.fftw_destroy_plan(p)
+        dt = min(times)
+        best = dict(value=round(2 * flops_c2c(shape) / dt / 1e9, 2), unit='GFLOP/s', cores=F.threads, kind='port',
+                    library='%s (%s)' % (F.version, os.path.basename(F.path)),
+                    sample='%d^3 complex128 fwd+bwd, best of %d, FFTW guru interface as fftw_planxfftn.c builds it, %s, '
+                    '%s, %d threads, round-trip rel err %.1e, %.3f s per fwd+bwd (planning %.1f s)'
+                    % (n, len(times), form, 'FFTW_MEASURE' if flags == F.MEASURE else 'FFTW_ESTIMATE',
+                       F.threads, err, dt, t_plan))
+        assert err < 1e-10, best
+        del u, v
+        if max(times[0], t_plan) * 9 > budget_s or n == 1024:
+            break
+        avail = 0
+        try:
+            with open('/proc/meminfo') as f:
+                avail = int(re.search(r'MemAvailable:\s+(\d+)', f.read()).group(1)) * 1024
+        except Exception:
+            pass
+        if 8 * n ** 3 * 16 * 3 > avail:              # next cube: two arrays + slack
+            break
+        n *= 2
+    return best
+
+
+def _cpu_pocketfft(cores, budget_s):
+    """Oracle (numpy restatement of the reference path, scipy pocketfft): 3-D c2c fwd+bwd, largest
+    power-of-two cube whose estimated time fits the budget."""
+    import numpy as np
     from oracle import pfft_oracle as O
     n = 128
     best = None
@@ -57,7 +220,8 @@ def cpu_baseline(cores, budget_s=25.0):
         dt = min(times)
         err = float(np.linalg.norm(ub[0] - u[0]) / np.linalg.norm(u[0]))
         best = dict(value=round(2 * flops_c2c(shape) / dt / 1e9, 2), unit='GFLOP/s', cores=cores,
-                    kind='port', sample='%d^3 complex128 fwd+bwd, best of %d, scipy pocketfft workers=%d, '
+                    kind='port', library='scipy pocketfft',
+                    sample='%d^3 complex128 fwd+bwd, best of %d, oracle (scipy pocketfft workers=%d), '
                     'round-trip rel err %.1e, %.2f s per fwd+bwd' % (n, len(times), cores, err, dt))
         del fft, u, uh, ub
         if times[0] * 9 > budget_s:      # the next cube costs ~9x
@@ -66,67 +230,116 @@ def cpu_baseline(cores, budget_s=25.0):
     return best
 
 
+def cpu_baseline(cores, budget_s=25.0):
+    """FFTW with all threads when a libfftw3 can be loaded (none ships in
+    this image; MKL's FFTW3 interface does), else pocketfft; the line says which."""
+    try:
+        return _cpu_fftw(cores, budget_s)
+    except Exception as e:
+        out = _cpu_pocketfft(cores, budget_s)
+        out['sample'] += ' [FFTW probe: %s]' % (repr(e)[:120],)
+        return out
+
+
+def relaunch(args):
+    """`python bench.py --gpus N` from a plain shell: one process per GPU under torch.distributed.run."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (RCCL needs it on this driver)
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def timed_steps(world, sync, step, steps):
+    world.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    world.barrier()
+    return world.allreduce_max(time.perf_counter() - t0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', dest='n', type=int, default=1024, help='cube edge (default: the BASELINE config)')
-    ap.add_argument('--extras-deadline', type=float, default=240.0)
+    ap.add_argument('--extras-deadline', type=float, default=200.0,
+                    help='seconds the phases after the headline may take at N > 1')
     ap.add_argument('--no-slab', action='store_true', help='skip the slab-grid extra at N > 1')
+    ap.add_argument('--no-tune', action='store_true', help='skip the measured route choice at N > 1')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        sys.exit(relaunch(args))
+
+    import numpy as np
+    import torch
     from mpi4py_fft_amd import PFFT, comm, _lib
     world = comm.init_distributed()
     rank, size = world.Get_rank(), world.Get_size()
     assert size == args.gpus, 'launched with %d ranks but --gpus %d' % (size, args.gpus)
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback exists)'
-    dev = torch.cuda.current_device()
+    hip = _lib.engine().name == 'hip'      # anything else was injected by a CPU test of this script
+    if hip:
+        assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback exists)'
+    dev = 'cuda' if torch.cuda.is_available() else 'cpu'
+
+    def sync():
+        if dev == 'cuda':
+            torch.cuda.synchronize()
 
     n = args.n
     shape = (n, n, n)
-    fft = PFFT(world, shape, dtype='D')
+    # the plain route first (see the module docstring); `exchange='auto'` comes later, guarded
+    fft = PFFT(world, shape, dtype='D', exchange='direct')
     u = fft.forward.input_array
-    g = torch.Generator(device='cuda').manual_seed(1234 + rank)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
     ur = torch.view_as_real(u.tensor)
-    for i in range(0, ur.shape[0], max(1, min(64, ur.shape[0]))):
+    for i in range(0, ur.shape[0], 64):
         sl = ur[i:i + 64]
-        sl.copy_(torch.randn(sl.shape, generator=g, device='cuda', dtype=torch.float64))
+        sl.copy_(torch.randn(sl.shape, generator=g, device=dev, dtype=torch.float64))
     u0 = u.tensor.clone()
+
+    def round_trip_error(f):
+        """north-star parity gate: forward -> backward on the planned arrays, relative l2 error"""
+        f.forward()
+        f.backward()
+        sync()
+        t = f.forward.input_array.tensor
+        num = float((torch.view_as_real(t) - torch.view_as_real(u0)).pow(2).sum().item())
+        den = float(torch.view_as_real(u0).pow(2).sum().item())
+        sums = world.allgather_obj((num, den))
+        return float(np.sqrt(sum(s[0] for s in sums) / sum(s[1] for s in sums)))
 
     def one_step():
         fft.forward()
         fft.backward()
 
-    # parity gate (north-star tolerance): forward -> backward round trip on this rank's block
-    one_step()
-    torch.cuda.synchronize()
-    num = float((torch.view_as_real(u.tensor) - torch.view_as_real(u0)).pow(2).sum().item())
-    den = float(torch.view_as_real(u0).pow(2).sum().item())
-    sums = world.allgather_obj((num, den))
-    rt_err = float(np.sqrt(sum(s[0] for s in sums) / sum(s[1] for s in sums)))
+    rt_err = round_trip_error(fft)
     assert rt_err <= 1e-10, 'round-trip rel err %.3e exceeds 1e-10' % rt_err
-    del u0
 
     for _ in range(args.warmup):
         one_step()
-    _lib.set_option('profile', 1)
-    world.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize()
-    world.barrier()
-    t1 = time.perf_counter()
-    _lib.set_option('profile', 0)
-    elapsed = world.allreduce_max(t1 - t0)
+    if hip:
+        _lib.set_option('profile', 1)
+    elapsed = timed_steps(world, sync, one_step, args.steps)
+    if hip:
+        _lib.set_option('profile', 0)
 
     # per-kernel launch durations inside the timed region (HIP events on the launch stream)
     kern = {}
-    plans = list(fft._fused_plans) if fft._fused_plans else \
-        [x.fwd for x in fft.xfftn] + [x.bck for x in fft.xfftn]
+    plans = []
+    if hip:
+        plans = list(fft._fused_plans) if fft._fused_plans else \
+            [x.fwd for x in fft.xfftn] + [x.bck for x in fft.xfftn]
     for p in plans:
         for name, nbytes, ms, launches in p.profile():
             if launches:
@@ -160,7 +373,7 @@ def main():
     # streaming-copy ceiling of this very box and run (same byte count per launch as one pass of the
     # dominant kernel when it fits): what "100 % of achievable HBM" means next to roofline.frac
     copy_ceiling = None
-    if rank == 0:
+    if rank == 0 and hip:
         try:
             nbytes = min(16 << 30, (u.tensor.numel() * 16) // 256 * 256)
             src, dst = u.tensor, fft.forward.output_array.tensor
@@ -181,79 +394,40 @@ def main():
             copy_ceiling = {'gbs': None, 'what': 'failed: %r' % (e,)}
     world.barrier()
     grid = [c.Get_size() for c in fft.subcomm]
-    exchange = [dict(ranks=t.comm.Get_size(), route=t.exchange,
+
+    def exchange_report(f):
+        return [dict(ranks=t.comm.Get_size(), route=t.exchange,
                      **({'measured_s': [round(x, 5) for x in t.route_times]} if hasattr(t, 'route_times') else {}))
-                for t in fft.transfer if t.comm.Get_size() > 1]
+                for t in f.transfer if t.comm.Get_size() > 1]
     fl_f, bytes_f = fft.cost()
-    def multi_gpu_extras():
-        """Outside the timed region: where a step spends its time, stage by stage (synchronised,
-        max over ranks), and the same cube on the slab grid (N,1,1), whose single exchange spans
-        all ranks and therefore all xGMI links."""
-        nonlocal fft, u, ur
-        extras = {}
+    flops = 2 * flops_c2c(shape)
 
-        def stages(tr):
-            st = tr.stage_times()
-            allst = world.allgather_obj([b for _, b in st])
-            out_ = []
-            for i in range(len(st)):
-                label, ms = st[i][0], max(r[i] for r in allst) * 1e3
-                mb = re.search(r'([0-9.]+) MB out', label)
-                if mb and ms > 0:        # per-GPU outgoing wire rate of this exchange
-                    label += ' = %.1f GB/s per GPU' % (float(mb.group(1)) / ms)
-                out_.append([label, round(ms, 3)])
-            return out_
-        extras['stages_ms'] = {'forward': stages(fft.forward), 'backward': stages(fft.backward)}
-        if sum(1 for c in grid if c > 1) > 1 and n % size == 0 and not args.no_slab:
-            fft.destroy()
-            del fft, u, ur
-            torch.cuda.empty_cache()
-            slab = PFFT(world, shape, dtype='D', grid=(-1,))
-            torch.view_as_real(slab.forward.input_array.tensor).normal_()
-            ksteps = max(1, min(args.steps, 5))
-            for _ in range(2):
-                slab.forward()
-                slab.backward()
-            world.barrier()
-            torch.cuda.synchronize()
-            s0 = time.perf_counter()
-            for _ in range(ksteps):
-                slab.forward()
-                slab.backward()
-            torch.cuda.synchronize()
-            world.barrier()
-            sel = world.allreduce_max(time.perf_counter() - s0)
-            extras['slab_grid'] = {'grid': [c.Get_size() for c in slab.subcomm], 'steps': ksteps,
-                                   'ms_per_step': round(sel / ksteps * 1e3, 3),
-                                   'gflops': round(2 * flops_c2c(shape) / (sel / ksteps) / 1e9, 1),
-                                   'stages_ms': {'forward': stages(slab.forward)}}
-            slab.destroy()
-        return extras
-
-    out = None
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        flops = 2 * flops_c2c(shape)
-        whole = dict(gbs=round(2 * bytes_f * size / (elapsed / args.steps) / 1e9, 1))
+    def headline(f, secs, err):
+        ms_per_step = secs / args.steps * 1e3
+        whole = dict(gbs=round(2 * bytes_f * size / (secs / args.steps) / 1e9, 1))
         whole['frac_of_peak_per_gpu'] = round(whole['gbs'] / size / HBM_PEAK_GBS, 4)
         # SURVEY.md 8d also asks for the read-only variant (3 S per transform instead of 6 S)
         whole['read_only_gbs'] = round(whole['gbs'] / 2, 1)
         whole['read_only_frac_of_peak_per_gpu'] = round(whole['gbs'] / 2 / size / HBM_PEAK_GBS, 4)
-        out = {
+        return {
             'metric': 'pfft_3d_c2c_%dcubed_fp64_gflops' % n,
-            'value': round(flops / (elapsed / args.steps) / 1e9, 1),
+            'value': round(flops / (secs / args.steps) / 1e9, 1),
             'unit': 'GFLOP/s',
             'n_gpus': size, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'PFFT 3D c2c %d^3 complex128 forward+backward per step' % n,
-                       'grid': grid, 'exchange': exchange,
-                       'round_trip_rel_err': rt_err},
+                       'grid': grid, 'exchange': exchange_report(f),
+                       'round_trip_rel_err': err},
             'whole_transform_hbm': whole,
-            'roofline': roofline,
-            'hbm_copy_ceiling': copy_ceiling,
         }
+
+    out = None
+    if rank == 0:
+        out = headline(fft, elapsed, rt_err)
+        out['roofline'] = roofline
+        out['hbm_copy_ceiling'] = copy_ceiling
         if roofline and copy_ceiling and copy_ceiling.get('gbs'):
             roofline['frac_of_copy_ceiling'] = round(roofline['achieved'] / copy_ceiling['gbs'], 4)
         if not args.no_cpu and size == 1:
@@ -264,25 +438,118 @@ def main():
                 out['cpu_baseline'] = {'value': None, 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
 
-    extras = {}
-    if size > 1:
-        # the extras below must never cost the headline line: after the deadline every rank
-        # leaves, rank 0 printing what it has
-        def bail():
+    def finish(code=0):
+        """Print the line (rank 0) and leave without touching the communicator again."""
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os._exit(code)
+
+    if size == 1:
+        print(json.dumps(out), flush=True)
+        fft.destroy()
+        return
+
+    # ---------------------------------------------------------------- N > 1: guarded phases
+    state = {'phase': 'start'}
+
+    def bail():
+        if rank == 0:
+            out['extras_error'] = 'deadline of %.0f s hit in phase %r' % (args.extras_deadline, state['phase'])
+        finish(0)
+    guard = threading.Timer(args.extras_deadline, bail)
+    guard.daemon = True
+    guard.start()
+
+    def stages(tr):
+        st = tr.stage_times()
+        allst = world.allgather_obj([b for _, b in st])
+        out_ = []
+        for i in range(len(st)):
+            label, ms = st[i][0], max(r[i] for r in allst) * 1e3
+            mb = re.search(r'([0-9.]+) MB out', label)
+            if mb and ms > 0:        # per-GPU outgoing wire rate of this exchange
+                label += ' = %.1f GB/s per GPU' % (float(mb.group(1)) / ms)
+            out_.append([label, round(ms, 3)])
+        return out_
+
+    try:
+        # where a step spends its time, stage by stage (synchronised, max over ranks)
+        state['phase'] = 'stage breakdown'
+        if os.environ.get('GFFT_BENCH_TEST_HANG') == state['phase']:     # tests/test_bench_launcher.py
+            time.sleep(3600)
+        st = {'forward': stages(fft.forward), 'backward': stages(fft.backward)}
+        if rank == 0:
+            out['stages_ms'] = st
+
+        # measured route choice: the planner times the plain and the relayed all-link exchange on
+        # the transform's own buffers and keeps the faster one (as FFTW_MEASURE does for serial
+        # plans); the headline becomes this plan's number if it beats the plain route
+        if not args.no_tune:
+            state['phase'] = 'route measurement'
+            tuned = PFFT(world, shape, dtype='D')      # exchange: GFFT_RELAY, default 'auto'
+            tuned.forward.input_array.tensor.copy_(u0)
+            err2 = round_trip_error(tuned)
+            routes = [t.exchange for t in tuned.transfer if t.comm.Get_size() > 1]
+            info = {'exchange': exchange_report(tuned), 'round_trip_rel_err': err2}
+            if any(r != 'direct' for r in routes) and err2 <= 1e-10:
+                def tuned_step():
+                    tuned.forward()
+                    tuned.backward()
+                for _ in range(args.warmup):
+                    tuned_step()
+                el2 = timed_steps(world, sync, tuned_step, args.steps)
+                info['ms_per_step'] = round(el2 / args.steps * 1e3, 3)
+                if rank == 0 and el2 < elapsed:
+                    plain = {'ms_per_step': out['ms_per_step'], 'value': out['value'],
+                             'exchange': out['config']['exchange']}
+                    keep = {k: out[k] for k in ('roofline', 'hbm_copy_ceiling', 'stages_ms') if k in out}
+                    out.clear()
+                    out.update(headline(tuned, el2, err2))
+                    out.update(keep)
+                    out['plain_route'] = plain
+                state['phase'] = 'stage breakdown (tuned routes)'
+                st2 = {'forward': stages(tuned.forward), 'backward': stages(tuned.backward)}
+                if rank == 0:
+                    out['stages_ms_tuned'] = st2
             if rank == 0:
-                out['extras_error'] = 'deadline'
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-        guard = threading.Timer(args.extras_deadline, bail)
-        guard.daemon = True
-        guard.start()
-        try:
-            extras = multi_gpu_extras()
-        except Exception as e:
-            extras = {'extras_error': repr(e)[:300]}
+                out['route_measurement'] = info
+            tuned.destroy()
+            del tuned
+
+        # the same cube on the slab grid (N,1,1), whose single exchange spans all ranks and
+        # therefore all xGMI links (SURVEY.md 8e)
+        if sum(1 for c in grid if c > 1) > 1 and n % size == 0 and not args.no_slab:
+            state['phase'] = 'slab grid'
+            fft.destroy()
+            del fft, u, ur
+            if dev == 'cuda':
+                torch.cuda.empty_cache()
+            slab = PFFT(world, shape, dtype='D', grid=(-1,), exchange='direct')
+            torch.view_as_real(slab.forward.input_array.tensor).normal_()
+            ksteps = max(1, min(args.steps, 5))
+
+            def slab_step():
+                slab.forward()
+                slab.backward()
+            for _ in range(2):
+                slab_step()
+            sel = timed_steps(world, sync, slab_step, ksteps)
+            res = {'grid': [c.Get_size() for c in slab.subcomm], 'steps': ksteps,
+                   'ms_per_step': round(sel / ksteps * 1e3, 3),
+                   'gflops': round(flops / (sel / ksteps) / 1e9, 1)}
+            state['phase'] = 'slab grid stage breakdown'
+            res['stages_ms'] = {'forward': stages(slab.forward)}
+            if rank == 0:
+                out['slab_grid'] = res
+            slab.destroy()
+    except BaseException as e:      # never lose the headline to an extra
+        if rank == 0:
+            out['extras_error'] = 'phase %r: %s' % (state['phase'], repr(e)[:300])
         guard.cancel()
+        finish(0)
+    guard.cancel()
     if rank == 0:
-        out.update(extras)
         print(json.dumps(out), flush=True)
     world.barrier()
     import torch.distributed as dist

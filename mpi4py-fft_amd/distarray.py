@@ -121,6 +121,17 @@ class DistArray(DeviceArray):
         p1 = self._p0.pencil(axis)
         return p1, self._p0.transfer(p1, self.dtype)
 
+    def _cached_transfer(self, axis):
+        """The Transfer (exchange plan + staging buffers) towards alignment `axis`, kept on this
+        array's pencil: the reference builds and frees the MPI datatypes on every redistribute
+        (distarray.py:352-361), which costs it little; here a Transfer owns device staging
+        buffers, so arrays that are redistributed every time step reuse theirs."""
+        cache = self._p0.__dict__.setdefault('_transfers', {})
+        key = (self._p0.axis, int(axis), self.dtype.char)
+        if key not in cache:
+            cache[key] = self.get_pencil_and_transfer(axis)
+        return cache[key]
+
     def redistribute(self, axis=None, out=None):
         """Global redistribution so that `axis` (or `out`'s aligned axis) becomes undivided
         (distarray.py:298-363).  Vector/tensor components are moved one transfer each."""
@@ -143,14 +154,13 @@ class DistArray(DeviceArray):
                 if i not in (self.alignment, out.alignment):
                     assert self.pencil.subcomm[i] == out.pencil.subcomm[i]
                     assert self.pencil.subshape[i] == out.pencil.subshape[i]
-        p1, transfer = self.get_pencil_and_transfer(axis)
+        p1, transfer = self._cached_transfer(axis)
         if out is None:
             out = DistArray(self.global_shape, subcomm=p1.subcomm, dtype=self.dtype,
                             alignment=axis, rank=self.rank)
         src, dst = self.v, out.v
         for comp in np.ndindex(*self.shape[:self._rank]):       # one exchange per field component
             transfer.forward(src[comp] if comp else src, dst[comp] if comp else dst)
-        transfer.destroy()
         return out
 
     def get(self, gslice=None):

@@ -153,144 +153,61 @@ class PFFT:
     backend : accepted for compatibility ('fftw'/'gfft'); there is one engine
     transforms : optional {axes: (forward planner, backward planner)} from ``fftw``
     darray : take shape/dtype/distribution from a DistArray
+
+    Keywords of this engine (absent from the reference, all optional):
+    exchange : route of the global redistributions: 'direct' (one RCCL all-to-all on the
+        sub-communicator), 'relay' (two rounds over all xGMI links of the grid, relay.py) or
+        'auto' (time both at the first call and keep the faster).  Default: the GFFT_RELAY
+        environment switch, else 'auto'.
+    fuse : single-GPU transforms run as one all-axes plan (default True)
+    fuse_pack : serial transforms write / read the exchange buffers directly (default True)
     """
     def __init__(self, comm, shape=None, axes=None, dtype=float, grid=None, padding=False,
                  collapse=False, backend='fftw', transforms=None, darray=None, **kw):
+        # keywords of this engine (not in the reference): see the class docstring
+        exchange = kw.pop('exchange', None)
+        fuse = kw.pop('fuse', True)
+        fuse_pack = kw.pop('fuse_pack', os.environ.get('GFFT_FUSE_PACK', '1') != '0')
+        slab = kw.pop('slab', False)
         if shape is None:
             assert darray is not None
             shape = darray.pencil.shape
-
-        nd = len(shape)
-        if axes is None:
-            order = list(range(nd))
-            if darray is not None:         # the array's aligned axis must be transformed first
-                order = [int(a) for a in np.roll(order, nd - 1 - darray.alignment)]
-            axes = order
-        elif isinstance(axes, (int, np.integer)):
-            axes = [int(axes)]
-        # axis groups: every entry becomes a sequence of non-negative axes (mpifft.py:226-247)
-        groups = []
-        for entry in axes:
-            members = [entry] if isinstance(entry, (int, np.integer)) else entry
-            assert isinstance(members, (tuple, list)) and 0 < len(members) <= nd
-            assert all(isinstance(a, (int, np.integer)) for a in members)
-            members = [int(a) + nd if a < 0 else int(a) for a in members]
-            assert all(0 <= a < nd for a in members) and len(set(members)) == len(members)
-            groups.append(tuple(members) if isinstance(entry, (int, np.integer)) else members)
-        axes = groups
-
-        self.axes = axes
-        shape = list(shape)
-
+        shape = [int(n) for n in shape]
+        groups = self._axis_groups(axes, len(shape), darray)
+        self.axes = groups
         if darray is None:
             dtype = np.dtype(dtype)
             assert dtype.char in 'fdgFDG'
-            if padding is not False:
-                padding = list(padding)
-                assert len(padding) == len(shape)
-                for ax in axes:
-                    if len(ax) == 1 and padding[ax[0]] > 1.0 + 1e-6:
-                        old = float(shape[ax[0]])
-                        shape[ax[0]] = int(np.floor(shape[ax[0]] * padding[ax[0]]))
-                        padding[ax[0]] = shape[ax[0]] / old
-            self._input_shape = tuple(shape)
+            padding = self._inflate(shape, groups, padding)
             assert len(shape) > 0
             assert min(shape) > 0
-            slab = kw.pop('slab', False)
-            if grid is not None:
-                assert not isinstance(comm, Subcomm)
-                assert slab is False
-                grid = tuple(grid)
-                assert len(grid) <= len(shape)
-                dims = list(grid) + [1] * (len(shape) - len(grid))
-                comm = Subcomm(comm, dims)
-            if isinstance(comm, Subcomm):
-                assert slab is False
-                assert len(comm) == len(shape)
-                assert np.all([comm[ax].Get_size() == 1 for ax in axes[-1]])
-                self.subcomm = comm
-            else:
-                if slab is False or slab is None:
-                    dims = [0] * len(shape)
-                    for ax in axes[-1]:
-                        dims[ax] = 1
-                else:
-                    if slab is True:
-                        axis = (axes[-1][-1] + 1) % len(shape)
-                    else:
-                        axis = slab
-                        if axis < 0:
-                            axis = axis + len(shape)
-                        assert 0 <= axis < len(shape)
-                    dims = [1] * len(shape)
-                    dims[axis] = comm.Get_size()
-                self.subcomm = Subcomm(comm, dims)
+            self.subcomm = self._process_grid(comm, len(shape), groups[-1], grid, slab)
         else:
             dtype = darray.dtype
             self.subcomm = darray.subcomm
-            self._input_shape = tuple(shape)
-            commsizes = darray.commsizes
-            assert np.all([commsizes[ax] == 1 for ax in axes[-1]]), \
+            sizes = darray.commsizes
+            assert np.all([sizes[a] == 1 for a in groups[-1]]), \
                 "Set keyword axes such that axes to transform first are aligned"
-
+        self._input_shape = tuple(shape)
         self.collapse = collapse
         if collapse is True:
-            groups = [[]]
-            for ax in reversed(axes):
-                if np.all([self.subcomm[axis].Get_size() == 1 for axis in ax]):
-                    [groups[0].insert(0, axis) for axis in reversed(ax)]
-                else:
-                    groups.insert(0, ax)
-            axes = groups
+            groups = self._merge_local_groups(groups)
+        self.axes = tuple(tuple(g) for g in groups)
+        self._transforms = transforms
+        self._chain(shape, dtype, padding, backend, transforms, kw)
 
-        self.axes = tuple(map(tuple, axes))
-        self.xfftn = []
-        self.transfer = []
-        self.pencil = [None, None]
-
-        axes = self.axes[-1]
-        pencil = Pencil(self.subcomm, shape, axes[-1])
-        xfftn = FFT(pencil.subshape, axes, dtype, padding, backend=backend,
-                    transforms=transforms, **kw)
-        self.xfftn.append(xfftn)
-        self.pencil[0] = pencilA = pencil
-        if not shape[axes[-1]] == xfftn.forward.output_array.shape[axes[-1]]:
-            dtype = xfftn.forward.output_array.dtype
-            shape[axes[-1]] = xfftn.forward.output_array.shape[axes[-1]]
-            pencilA = Pencil(self.subcomm, shape, axes[-1])
-
-        for axes in reversed(self.axes[:-1]):
-            pencilB = pencilA.pencil(axes[-1])
-            transAB = pencilA.transfer(pencilB, dtype)
-            # single-rank redistribution: chain the stages through one buffer instead of copying
-            share = shareV = None
-            if transAB.comm.Get_size() == 1 and tuple(pencilB.subshape) == tuple(pencilA.subshape):
-                share = self.xfftn[-1].forward.output_array
-                if padding is False and np.dtype(dtype).kind == 'c':
-                    shareV = share        # complex stage on one rank: transform in place
-            xfftn = FFT(pencilB.subshape, axes, dtype, padding, backend=backend,
-                        transforms=transforms, U=share, V=shareV, **kw)
-            self.xfftn.append(xfftn)
-            self.transfer.append(transAB)
-            pencilA = pencilB
-            if not shape[axes[-1]] == xfftn.forward.output_array.shape[axes[-1]]:
-                dtype = xfftn.forward.output_array.dtype
-                shape[axes[-1]] = xfftn.forward.output_array.shape[axes[-1]]
-                pencilA = Pencil(pencilB.subcomm, shape, axes[-1])
-
-        self.pencil[1] = pencilA
-        self._output_shape = tuple(shape)
-
+        # every redistribution local (one GPU): ONE all-axes plan replaces the chain of stages
         fused_fwd = fused_bck = None
         self._fused_plans = None
         local = all(t.comm.Get_size() == 1 for t in self.transfer)
-        if (local and padding is False and transforms is None and len(self.xfftn) > 1
-                and kw.get('fuse', True)):
+        if local and padding is False and transforms is None and len(self.xfftn) > 1 and fuse:
             fused_fwd, fused_bck = self._plan_fused()
-
-        self._transforms = transforms
-        if not local and kw.get('fuse_pack', os.environ.get('GFFT_FUSE_PACK', '1') != '0'):
-            self._fuse_packs()
+        if not local:
+            if fuse_pack:
+                self._fuse_packs()
+            # the route of every exchange (relay.py): collective over the grid, same order everywhere
+            for t in self.transfer:
+                t.plan_relay(exchange)
 
         self.forward = Transform(
             [o.forward for o in self.xfftn],
@@ -300,6 +217,119 @@ class PFFT:
             [o.backward for o in self.xfftn[::-1]],
             [o.backward for o in self.transfer[::-1]],
             self.pencil[::-1], fused_bck)
+
+    # ---- planning steps (what mpifft.py:202-347 decides, one decision per helper) ---------------
+    @staticmethod
+    def _axis_groups(axes, nd, darray):
+        """`axes` in any accepted spelling -> list of groups of non-negative axes; a bare int entry
+        becomes a 1-tuple, sequences keep their type (mpifft.py:213-240).  Default: all axes in
+        order -- rolled, for a `darray`, so that its aligned axis is transformed first (:217-219)."""
+        if axes is None:
+            axes = list(range(nd))
+            if darray is not None:
+                axes = [int(a) for a in np.roll(axes, nd - 1 - darray.alignment)]
+        elif isinstance(axes, (int, np.integer)):
+            axes = [int(axes)]
+        groups = []
+        for entry in axes:
+            bare = isinstance(entry, (int, np.integer))
+            members = [entry] if bare else entry
+            assert isinstance(members, (tuple, list)) and 0 < len(members) <= nd
+            assert all(isinstance(a, (int, np.integer)) for a in members)
+            members = [int(a) + nd if a < 0 else int(a) for a in members]
+            assert all(0 <= a < nd for a in members) and len(set(members)) == len(members)
+            groups.append(tuple(members) if bare else members)
+        return groups
+
+    @staticmethod
+    def _inflate(shape, groups, padding):
+        """3/2-rule: single-axis groups with a factor > 1 plan on the inflated length
+        floor(N * factor); the factor is then restated as inflated / N so that truncation lands
+        back on N exactly (mpifft.py:247-257).  `shape` is updated in place; returns the factors."""
+        if padding is False:
+            return False
+        padding = list(padding)
+        assert len(padding) == len(shape)
+        for g in groups:
+            if len(g) == 1 and padding[g[0]] > 1.0 + 1e-6:
+                a = g[0]
+                n = float(shape[a])
+                shape[a] = int(np.floor(shape[a] * padding[a]))
+                padding[a] = shape[a] / n
+        return padding
+
+    @staticmethod
+    def _process_grid(comm, nd, first_group, grid, slab):
+        """The tuple of 1-D sub-communicators, one per array axis (mpifft.py:258-290):
+          * `grid` given: that Cartesian grid, right-padded with ones (non-positive = wildcard);
+          * a ready Subcomm: used as is;
+          * slab: every rank on ONE axis -- the one after the first transformed axis, or `slab`;
+          * else pencils: all axes free except the first group's, which stays whole."""
+        if grid is not None:
+            assert not isinstance(comm, Subcomm)
+            assert slab is False
+            grid = tuple(grid)
+            assert len(grid) <= nd
+            comm = Subcomm(comm, list(grid) + [1] * (nd - len(grid)))
+        if isinstance(comm, Subcomm):
+            assert slab is False
+            assert len(comm) == nd
+            assert np.all([comm[a].Get_size() == 1 for a in first_group])
+            return comm
+        if slab is False or slab is None:
+            dims = [1 if a in first_group else 0 for a in range(nd)]
+        else:
+            axis = (first_group[-1] + 1) % nd if slab is True else (slab + nd if slab < 0 else slab)
+            assert 0 <= axis < nd
+            dims = [comm.Get_size() if a == axis else 1 for a in range(nd)]
+        return Subcomm(comm, dims)
+
+    def _merge_local_groups(self, groups):
+        """collapse=True: walking from the first-transformed group, groups whose axes are all
+        undistributed fuse into the leading serial transform (mpifft.py:299-306)."""
+        merged = [[]]
+        for g in reversed(groups):
+            if np.all([self.subcomm[a].Get_size() == 1 for a in g]):
+                merged[0] = list(g) + merged[0]
+            else:
+                merged.insert(0, g)
+        return merged
+
+    def _chain(self, shape, dtype, padding, backend, transforms, kw):
+        """Pencils, serial transforms and redistributions in execution order (mpifft.py:308-338):
+        the last group first, on the pencil aligned with its last axis; every further group after
+        a redistribution that aligns ITS last axis.  A stage whose output is shorter than its
+        input along that axis (r2c half spectrum, truncation) re-bases the global shape -- and the
+        element type -- for everything downstream."""
+        self.xfftn, self.transfer, self.pencil = [], [], [None, None]
+        shape = list(shape)
+        pen = None
+        for group in reversed(self.axes):
+            lead = group[-1]
+            U = V = None
+            if pen is None:
+                pen = self.pencil[0] = Pencil(self.subcomm, shape, lead)
+            else:
+                nxt = pen.pencil(lead)
+                tr = pen.transfer(nxt, dtype)
+                # single-rank redistribution: chain the stages through one buffer instead of
+                # copying (the reference builds a self-Alltoallw here, mpifft.py:324-331)
+                if tr.comm.Get_size() == 1 and tuple(nxt.subshape) == tuple(pen.subshape):
+                    U = self.xfftn[-1].forward.output_array
+                    if padding is False and np.dtype(dtype).kind == 'c':
+                        V = U             # complex stage on one rank: transform in place
+                self.transfer.append(tr)
+                pen = nxt
+            stage = FFT(pen.subshape, group, dtype, padding, backend=backend, transforms=transforms,
+                        U=U, V=V, **kw)
+            self.xfftn.append(stage)
+            out = stage.forward.output_array
+            if out.shape[lead] != shape[lead]:
+                dtype = out.dtype
+                shape[lead] = out.shape[lead]
+                pen = Pencil(pen.subcomm, shape, lead)
+        self.pencil[1] = pen
+        self._output_shape = tuple(shape)
 
     def _fuse_packs(self):
         """Let the serial transforms next to a redistribution write / read the exchange buffers

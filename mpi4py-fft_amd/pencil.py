@@ -11,6 +11,8 @@ buffer themselves (``packedA`` / ``packedB``); otherwise a HIP kernel packs and 
 unpacks -- skipped when the split axis is the outermost axis, whose sub-blocks already are
 contiguous.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -95,19 +97,28 @@ class Transfer:
         # set by PFFT when the neighbouring serial transforms write / read the exchange buffers
         # themselves (gfft_plan_set_split): that side's array IS the packed buffer
         self.packedA = self.packedB = False
-        self._relay = self._plan_relay()
+        # route of the exchange: 'direct' = one all-to-all on this sub-communicator, all a
+        # stand-alone Transfer (Pencil.transfer, DistArray.redistribute) ever uses -- like the
+        # reference's Alltoallw it involves the ranks of `comm` and nobody else.  The relayed
+        # all-link route is collective over the PARENT grid and therefore only switched on by an
+        # owner that runs its transfers in lockstep on every rank (PFFT, via plan_relay).
+        self._relay = None
+        self.exchange = 'direct'
 
-    def _plan_relay(self):
-        """Schedules of the multi-path exchange (relay.py) when the sub-communicator leaves most
-        of the parent's links idle; None = plain all-to-all.  Collective over the parent."""
+    def plan_relay(self, mode=None):
+        """Plan the multi-path exchange of relay.py for this transfer when the sub-communicator
+        leaves most of the parent's links idle.  `mode`: 'direct' | 'relay' | 'auto' | None (=
+        the GFFT_RELAY environment switch, default auto: time both routes at the first exchange).
+        COLLECTIVE over the parent communicator; every rank of the grid must call it for the same
+        transfers in the same order -- which is why only PFFT does."""
         parent = getattr(self.comm, 'relay_parent', None)
-        self.exchange = 'direct'          # route in use: 'direct' | 'relay' | None (to be measured)
+        self._relay, self.exchange = None, 'direct'
         if parent is None:
-            return None
-        mode = _relay.policy(self._p, parent.Get_size(), parent.backend)
+            return
+        mode = _relay.policy(self._p, parent.Get_size(), parent.backend, mode)
         if mode == 'off':
-            return None
-        self.exchange = 'relay' if mode == 'on' else None
+            return
+        self.exchange = 'relay' if mode == 'on' else None     # None: to be measured
         mult = 2 if self.dtype.kind == 'c' else 1
         members = tuple(parent._ranks.index(r) for r in self.comm._ranks)
         meta = parent.allgather_obj((members, [c * mult for c in self._countsA],
@@ -118,11 +129,11 @@ class Transfer:
         largest = max(sum(a) for _, a, _ in meta) * scalar
         if mode == 'measure' and largest < self.RELAY_MIN_BYTES:
             self.exchange = 'direct'
-            return None
+            return
         me = parent.Get_rank()
         fwd = _relay.Schedule([(m, a) for m, a, b in meta], me)
         bwd = _relay.Schedule([(m, b) for m, a, b in meta], me)
-        return parent, fwd, bwd
+        self._relay = (parent, fwd, bwd)
 
     # -- staging buffers in the real scalar type (all-to-all backends want real dtypes)
     def _real_view(self, t):
@@ -142,7 +153,8 @@ class Transfer:
     # overlap the wire time of slab k.  CHUNK_MIN_BYTES / CHUNKS are tunables.
     CHUNKS = 4
     CHUNK_MIN_BYTES = 64 << 20
-    RELAY_MIN_BYTES = 8 << 20       # per-rank exchange volume below which routes are not measured
+    # per-rank exchange volume below which routes are not measured (GFFT_RELAY_MIN_BYTES overrides)
+    RELAY_MIN_BYTES = int(os.environ.get('GFFT_RELAY_MIN_BYTES', 8 << 20))
 
     def _nchunks(self, shape_src, axis_src, axis_dst, nbytes):
         if self._p == 1 or 0 in (axis_src, axis_dst) or nbytes < self.CHUNK_MIN_BYTES:

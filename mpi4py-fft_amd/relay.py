@@ -29,14 +29,15 @@ import os
 PIECE_GRAIN = 32        # pieces start on multiples of this many real scalars (128 B / 256 B)
 
 
-def policy(p, W, backend):
-    """'off' | 'on' | 'measure'.  GFFT_RELAY = 0 | 1 | measure | auto (default): auto lets the
+def policy(p, W, backend, mode=None):
+    """'off' | 'on' | 'measure'.  `mode` (PFFT's ``exchange=`` keyword) or, when None, the
+    environment switch GFFT_RELAY: 0 / direct | 1 / relay | measure | auto (default).  auto lets the
     planner time both routes on the first exchange (as FFTW_MEASURE does for the serial plans)
     when the wire is RCCL and the predicted wire-time ratio f (see above) is at most 0.75."""
-    mode = os.environ.get('GFFT_RELAY', 'auto').lower()
-    if p <= 1 or W <= p or mode in ('0', 'off', 'no'):
+    mode = (os.environ.get('GFFT_RELAY', 'auto') if mode is None else str(mode)).lower()
+    if p <= 1 or W <= p or mode in ('0', 'off', 'no', 'direct'):
         return 'off'
-    if mode in ('1', 'on', 'yes', 'force'):
+    if mode in ('1', 'on', 'yes', 'force', 'relay'):
         return 'on'
     if mode == 'measure':
         return 'measure'
