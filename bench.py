@@ -299,7 +299,7 @@ def main():
     n = args.n
     shape = (n, n, n)
     # the plain route first (see the module docstring); `exchange='auto'` comes later, guarded
-    fft = PFFT(world, shape, dtype='D', exchange='direct')
+    fft = PFFT(world, shape, dtype='D', exchange='direct', wire='torch')
     u = fft.forward.input_array
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     ur = torch.view_as_real(u.tensor)
@@ -452,6 +452,7 @@ def main():
 
     # ---------------------------------------------------------------- N > 1: guarded phases
     state = {'phase': 'start'}
+    best = {'elapsed': elapsed}
 
     def bail():
         if rank == 0:
@@ -482,17 +483,34 @@ def main():
         if rank == 0:
             out['stages_ms'] = st
 
-        # measured route choice: the planner times the plain and the relayed all-link exchange on
-        # the transform's own buffers and keeps the faster one (as FFTW_MEASURE does for serial
-        # plans); the headline becomes this plan's number if it beats the plain route
-        if not args.no_tune:
-            state['phase'] = 'route measurement'
-            tuned = PFFT(world, shape, dtype='D')      # exchange: GFFT_RELAY, default 'auto'
+        # Alternatives to the plain route, each the product's own plan of the same transform, each
+        # checked by the round trip and timed with the same K steps; the headline becomes the
+        # fastest one.  (1) measured route choice: the planner times the plain and the relayed
+        # all-link exchange on the transform's own buffers and keeps the faster (as FFTW_MEASURE does
+        # for serial plans).  (2) the chunked redistribution overlapped with the serial transforms
+        # on libgfft's own RCCL communicators (pipeline.py).
+        variants = [] if args.no_tune else [('measured routes', dict(wire='torch')),
+                                           ('pipelined', dict(wire='auto', exchange='direct'))]
+        for label, kw in variants:
+            state['phase'] = label
+            try:
+                tuned = PFFT(world, shape, dtype='D', **kw)      # exchange: GFFT_RELAY, default 'auto'
+            except Exception as e:        # e.g. no RCCL library to bind: same on every rank
+                if rank == 0:
+                    out.setdefault('alternatives', []).append({'plan': label, 'error': repr(e)[:300]})
+                continue
+            routes = [t.exchange for t in tuned.transfer if t.comm.Get_size() > 1]
+            info = {'plan': label}
+            if tuned.pipeline is not None:
+                info['pipeline'] = tuned.pipeline.describe()
+            elif label == 'pipelined':
+                info['skipped'] = 'transform does not qualify for the pipelined path'
             tuned.forward.input_array.tensor.copy_(u0)
             err2 = round_trip_error(tuned)
             routes = [t.exchange for t in tuned.transfer if t.comm.Get_size() > 1]
-            info = {'exchange': exchange_report(tuned), 'round_trip_rel_err': err2}
-            if any(r != 'direct' for r in routes) and err2 <= 1e-10:
+            info.update({'exchange': exchange_report(tuned), 'round_trip_rel_err': err2})
+            differs = tuned.pipeline is not None or any(r != 'direct' for r in routes)
+            if differs and err2 <= 1e-10:
                 def tuned_step():
                     tuned.forward()
                     tuned.backward()
@@ -500,22 +518,30 @@ def main():
                     tuned_step()
                 el2 = timed_steps(world, sync, tuned_step, args.steps)
                 info['ms_per_step'] = round(el2 / args.steps * 1e3, 3)
-                if rank == 0 and el2 < elapsed:
-                    plain = {'ms_per_step': out['ms_per_step'], 'value': out['value'],
-                             'exchange': out['config']['exchange']}
-                    keep = {k: out[k] for k in ('roofline', 'hbm_copy_ceiling', 'stages_ms') if k in out}
+                info['value'] = round(flops / (el2 / args.steps) / 1e9, 1)
+                if rank == 0 and el2 < best['elapsed']:
+                    if 'plain_route' not in out:
+                        out['plain_route'] = {'ms_per_step': out['ms_per_step'], 'value': out['value'],
+                                              'exchange': out['config']['exchange']}
+                    keep = {k: out[k] for k in out if k not in headline(tuned, el2, err2)}
                     out.clear()
                     out.update(headline(tuned, el2, err2))
                     out.update(keep)
-                    out['plain_route'] = plain
-                state['phase'] = 'stage breakdown (tuned routes)'
-                st2 = {'forward': stages(tuned.forward), 'backward': stages(tuned.backward)}
-                if rank == 0:
-                    out['stages_ms_tuned'] = st2
+                    out['config']['plan'] = label
+                    if tuned.pipeline is not None:
+                        out['config']['pipeline'] = info['pipeline']
+                best['elapsed'] = min(best['elapsed'], el2)
+                if tuned.pipeline is None:
+                    state['phase'] = 'stage breakdown (%s)' % label
+                    st2 = {'forward': stages(tuned.forward), 'backward': stages(tuned.backward)}
+                    if rank == 0:
+                        out['stages_ms_' + label.replace(' ', '_')] = st2
             if rank == 0:
-                out['route_measurement'] = info
+                out.setdefault('alternatives', []).append(info)
             tuned.destroy()
             del tuned
+            import gc
+            gc.collect()
 
         # the same cube on the slab grid (N,1,1), whose single exchange spans all ranks and
         # therefore all xGMI links

@@ -93,6 +93,20 @@ int gfft_plan_set_truncation(gfft_plan plan, int64_t n_keep);
  * layout.  GFFT_ERR_UNSUPPORTED (plan unchanged) when the plan is not one register-kernel pass,
  * nblocks is not a power of two <= 8 dividing the length, or the transform is real. */
 int gfft_plan_set_split(gfft_plan plan, int side, int nblocks);
+/* One batched 1-D complex transform with explicit strides: the form fftw_planxfftn() hands to
+ * fftw_plan_guru_dft (fftw_planxfftn.c:25-57) -- `dim` is the transformed axis, `howmany` up to
+ * three batch dims, slowest first; lengths and strides in elements, as fftw_iodim64 -- for callers
+ * that run a stage of a distributed transform on sub-arrays and exchange buffers (the chunked,
+ * stream-overlapped redistribution of mpi4py-fft_amd/pipeline.py).  Extension for exchange
+ * buffers: the transformed axis may be stored as `in_blocks` / `out_blocks` equal blocks (a power
+ * of two, 1 = contiguous) whose starts lie `*_block_stride` elements apart -- block b of the axis
+ * is what rank b of the sub-communicator receives / sent.  kind: GFFT_C2C_FORWARD / _BACKWARD.
+ * gfft_execute's d_in / d_out are the addresses of element 0.  GFFT_ERR_UNSUPPORTED when the
+ * length has no single-pass register kernel or the block count does not fit its thread layout. */
+typedef struct { int64_t n, is, os; } gfft_iodim;
+int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_iodim *dim, int howmany_rank,
+                          const gfft_iodim *howmany, int in_blocks, int64_t in_block_stride, int out_blocks,
+                          int64_t out_block_stride);
 int gfft_plan_describe(gfft_plan plan, char *buf, size_t len);
 /* flops (5 n log2 n per line, half for real) and algorithmic bytes (one read + one write of
  * the array per 1-D pass) of one execute, and the number of kernel launches it issues */
@@ -136,6 +150,49 @@ int gfft_ps_project(void *d_du_hat, const void *d_u_hat, const void *d_k0, const
                     int64_t n0, int64_t n1, int64_t n2, double nu, int precision, void *stream);
 int gfft_ps_rk_stage(void *d_u, const void *d_u0, void *d_u1, const void *d_du, int64_t count, double cb,
                      double ca, int precision, void *stream);
+
+/* ---- the wire of a global redistribution: RCCL over xGMI -------------------------------------
+ * Replaces, for device buffers, what the reference gets from MPI on its Cartesian sub-communicators:
+ *   gfft_comm_create / gfft_comm_split  <- MPI_Cart_create + MPI_Cart_sub   mpi4py_fft/pencil.py:64-93
+ *   gfft_alltoallv / gfft_sendrecv      <- comm.Alltoallw(...)             mpi4py_fft/pencil.py:182-183,200-201
+ * One process per GPU; a communicator is bound to the device current at its creation.  RCCL is
+ * loaded at run time (an already loaded librccl is shared; GFFT_RCCL_LIB or gfft_rccl_load name a
+ * specific one), so these entries return GFFT_ERR_UNSUPPORTED on a host without RCCL and nothing
+ * else in the library depends on it.  The 128-byte unique id is produced on one rank and carried to
+ * the others by whatever the host already has (MPI_Bcast, a torch.distributed store, a file).
+ * All calls are collective where RCCL's are (create: all ranks; split: all ranks of the parent) and
+ * every exchange is enqueued on `stream`: the host owns the stream and orders it against its compute
+ * streams with events (gfft_event_record / gfft_stream_wait_event).  Error detail:
+ * gfft_exchange_last_error(). */
+typedef struct gfft_comm_s *gfft_comm;
+typedef struct {
+  void *ptr;        /* device address of the message */
+  int64_t bytes;
+  int peer;         /* rank in the communicator */
+} gfft_msg;
+#define GFFT_UNIQUE_ID_BYTES 128
+int gfft_rccl_load(const char *path);                   /* NULL: default search */
+int gfft_rccl_info(char *buf, size_t len);
+const char *gfft_exchange_last_error(void);
+int gfft_comm_get_unique_id(void *id128);
+int gfft_comm_create(gfft_comm *comm, const void *id128, int nranks, int rank);
+/* ranks passing the same color >= 0 form a group, ordered by key then parent rank; color < 0 joins
+ * no group (*sub = NULL).  Sub-communicator of grid axis i: color = the other coordinates, key =
+ * coordinate i (pencil.py:80-88). */
+int gfft_comm_split(gfft_comm parent, int color, int key, gfft_comm *sub);
+int gfft_comm_rank(gfft_comm comm, int *rank, int *size);
+int gfft_comm_destroy(gfft_comm comm);
+/* One grouped batch of point-to-point messages (ncclGroupStart .. ncclGroupEnd).  Messages
+ * between two ranks match in list order; messages to oneself are device copies. */
+int gfft_sendrecv(gfft_comm comm, int nsend, const gfft_msg *sends, int nrecv, const gfft_msg *recvs, void *stream);
+/* MPI_Alltoallv on device buffers: send_counts[i] items at item offset send_displs[i] of d_send go
+ * to rank i; recv_counts[j] items from rank j land at item offset recv_displs[j] of d_recv. */
+int gfft_alltoallv(gfft_comm comm, const void *d_send, const int64_t *send_counts, const int64_t *send_displs,
+                   void *d_recv, const int64_t *recv_counts, const int64_t *recv_displs, int itemsize, void *stream);
+int gfft_stream_create(void **stream);                  /* non-blocking HIP stream */
+int gfft_stream_destroy(void *stream);
+int gfft_stream_wait_event(void *stream, void *event);
+int gfft_event_create_untimed(void **event);            /* for ordering only (hipEventDisableTiming) */
 
 /* ---- raw device helpers for non-torch hosts (the Python host uses torch for these) ---- */
 int gfft_malloc(void **d_ptr, size_t bytes);

@@ -23,6 +23,14 @@ class GfftError(RuntimeError):
     pass
 
 
+class IoDim(ctypes.Structure):          # gfft_iodim
+    _fields_ = [('n', ctypes.c_int64), ('is_', ctypes.c_int64), ('os', ctypes.c_int64)]
+
+
+class Msg(ctypes.Structure):            # gfft_msg
+    _fields_ = [('ptr', ctypes.c_void_p), ('bytes', ctypes.c_int64), ('peer', ctypes.c_int)]
+
+
 def _declare(lib):
     c = ctypes
     i64p = c.POINTER(c.c_int64)
@@ -41,6 +49,8 @@ def _declare(lib):
         'gfft_plan_destroy': (c.c_int, [vp]),
         'gfft_plan_set_truncation': (c.c_int, [vp, c.c_int64]),
         'gfft_plan_set_split': (c.c_int, [vp, c.c_int, c.c_int]),
+        'gfft_plan_create_guru': (c.c_int, [c.POINTER(vp), c.c_int, c.c_int, c.POINTER(IoDim), c.c_int, c.POINTER(IoDim),
+                                            c.c_int, c.c_int64, c.c_int, c.c_int64]),
         'gfft_plan_describe': (c.c_int, [vp, c.c_char_p, c.c_size_t]),
         'gfft_plan_cost': (c.c_int, [vp, c.POINTER(c.c_double), c.POINTER(c.c_double), ip]),
         'gfft_pack': (c.c_int, [vp, vp, c.c_int, i64p, c.c_int, c.c_int, c.c_int, vp]),
@@ -66,6 +76,20 @@ def _declare(lib):
         'gfft_plan_profile': (c.c_int, [vp, c.POINTER(c.c_float), c.c_int, ip]),
         'gfft_plan_pass_info': (c.c_int, [vp, c.c_int, c.c_char_p, c.c_size_t, c.POINTER(c.c_double)]),
         'gfft_probe_copy': (c.c_int, [vp, vp, c.c_size_t, vp]),
+        'gfft_rccl_load': (c.c_int, [c.c_char_p]),
+        'gfft_rccl_info': (c.c_int, [c.c_char_p, c.c_size_t]),
+        'gfft_exchange_last_error': (c.c_char_p, []),
+        'gfft_comm_get_unique_id': (c.c_int, [vp]),
+        'gfft_comm_create': (c.c_int, [c.POINTER(vp), vp, c.c_int, c.c_int]),
+        'gfft_comm_split': (c.c_int, [vp, c.c_int, c.c_int, c.POINTER(vp)]),
+        'gfft_comm_rank': (c.c_int, [vp, ip, ip]),
+        'gfft_comm_destroy': (c.c_int, [vp]),
+        'gfft_sendrecv': (c.c_int, [vp, c.c_int, c.POINTER(Msg), c.c_int, c.POINTER(Msg), vp]),
+        'gfft_alltoallv': (c.c_int, [vp, vp, i64p, i64p, vp, i64p, i64p, c.c_int, vp]),
+        'gfft_stream_create': (c.c_int, [c.POINTER(vp)]),
+        'gfft_stream_destroy': (c.c_int, [vp]),
+        'gfft_stream_wait_event': (c.c_int, [vp, vp]),
+        'gfft_event_create_untimed': (c.c_int, [c.POINTER(vp)]),
         'gfft_probe_tile_copy': (c.c_int, [vp, vp, c.c_int64, c.c_int64, c.c_int64, c.c_int, vp]),
     }
     for name, (res, args) in sigs.items():
@@ -94,7 +118,15 @@ def lib():
 def check(rc):
     if rc != 0:
         l = lib()
-        raise GfftError('%s: %s' % (l.gfft_strerror(rc).decode(), l.gfft_last_error().decode()))
+        detail = l.gfft_last_error().decode() or l.gfft_exchange_last_error().decode()
+        raise GfftError('%s: %s' % (l.gfft_strerror(rc).decode(), detail))
+
+
+def check_wire(rc):
+    """status of an exchange-module call (its error text is kept separately from the planner's)"""
+    if rc != 0:
+        l = lib()
+        raise GfftError('%s: %s' % (l.gfft_strerror(rc).decode(), l.gfft_exchange_last_error().decode()))
 
 
 def _i64(seq):
@@ -148,6 +180,25 @@ class HipEngine:
         check(lib().gfft_plan_create_r2r(ctypes.byref(h), len(sizes), _i64(sizes), len(axes), ax, kd,
                                          int(precision)))
         return h
+
+    def plan_create_guru(self, precision, kind, dim, howmany, in_blocks=1, in_block_stride=0, out_blocks=1,
+                         out_block_stride=0):
+        """Strided batched 1-D plan (gfft_plan_create_guru); dim / howmany entries are (n, is, os).
+        None when the engine has no single-pass kernel for it."""
+        h = ctypes.c_void_p()
+        hm = (IoDim * max(1, len(howmany)))(*[IoDim(*[int(x) for x in d]) for d in howmany])
+        rc = lib().gfft_plan_create_guru(ctypes.byref(h), int(precision), int(kind), ctypes.byref(IoDim(*[int(x) for x in dim])),
+                                         len(howmany), hm, int(in_blocks), int(in_block_stride), int(out_blocks),
+                                         int(out_block_stride))
+        if rc == -2:
+            return None
+        check(rc)
+        return h
+
+    def execute_ptr(self, h, ptr_in, ptr_out, scale, stream=None):
+        """gfft_execute on raw device addresses (element 0 of the plan's input / output)."""
+        check(lib().gfft_execute(h, ctypes.c_void_p(ptr_in), ctypes.c_void_p(ptr_out), float(scale),
+                                 current_stream() if stream is None else stream))
 
     def plan_execute(self, h, tin, tout, scale):
         self.require_device(tin)

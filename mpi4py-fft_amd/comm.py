@@ -106,6 +106,83 @@ class Comm:
         raise NotImplementedError
 
 
+class NativeWire:
+    """An RCCL communicator owned by libgfft (C ABI: gfft_comm_create / gfft_comm_split /
+    gfft_sendrecv), the wire of the pipelined redistributions (pipeline.py).  Created
+    collectively: `create(comm)` carries RCCL's unique id from rank 0 to the others over `comm`
+    (whatever it is: a torch.distributed group, thread-ranks in tests) -- the bootstrap is the only
+    thing the host communicator is used for."""
+    _world = {}      # key of the bootstrap communicator -> NativeWire
+    _subs = {}       # (parent key, members) -> NativeWire
+
+    def __init__(self, handle, rank, size, key):
+        self.handle, self.rank, self.size, self.key = handle, rank, size, key
+
+    @classmethod
+    def create(cls, comm):
+        import ctypes
+        from . import _lib
+        key = comm.wire_key()
+        w = cls._world.get(key)
+        if w is None:
+            L = _lib.lib()
+            buf = ctypes.create_string_buffer(128)
+            if comm.Get_rank() == 0:
+                _lib.check_wire(L.gfft_comm_get_unique_id(buf))
+            ident = comm.bcast(buf.raw, root=0)
+            h = ctypes.c_void_p()
+            _lib.check_wire(L.gfft_comm_create(ctypes.byref(h), ctypes.c_char_p(ident), comm.Get_size(), comm.Get_rank()))
+            w = cls._world[key] = cls(h, comm.Get_rank(), comm.Get_size(), key)
+        return w
+
+    def split(self, color, key, members):
+        """ncclCommSplit: COLLECTIVE over this communicator.  `members` (parent ranks of my group,
+        in group-rank order) only names the cache slot."""
+        import ctypes
+        from . import _lib
+        slot = (self.key, tuple(members))
+        w = NativeWire._subs.get(slot)
+        if w is None:
+            h = ctypes.c_void_p()
+            _lib.check_wire(_lib.lib().gfft_comm_split(self.handle, int(color), int(key), ctypes.byref(h)))
+            r, n = ctypes.c_int(), ctypes.c_int()
+            _lib.check_wire(_lib.lib().gfft_comm_rank(h, ctypes.byref(r), ctypes.byref(n)))
+            assert n.value == len(members) and r.value == key, (n.value, r.value, members, key)
+            w = NativeWire._subs[slot] = NativeWire(h, r.value, n.value, slot)
+        return w
+
+    def sendrecv(self, sends, recvs, stream):
+        """One grouped batch: sends / recvs = [(device address, bytes, peer)]; `stream` a raw
+        hipStream_t (int / c_void_p)."""
+        import ctypes
+        from . import _lib
+        S = (_lib.Msg * max(1, len(sends)))(*[_lib.Msg(int(a), int(b), int(p)) for a, b, p in sends])
+        R = (_lib.Msg * max(1, len(recvs)))(*[_lib.Msg(int(a), int(b), int(p)) for a, b, p in recvs])
+        _lib.check_wire(_lib.lib().gfft_sendrecv(self.handle, len(sends), S, len(recvs), R, ctypes.c_void_p(stream)))
+
+    def alltoall_blocks(self, send_ptr, recv_ptr, block_bytes, stream):
+        """Equal-block all-to-all of contiguous regions: block j of the send region goes to rank j
+        and lands as block (my rank) ... of j's receive region."""
+        n = self.size
+        self.sendrecv([(send_ptr + j * block_bytes, block_bytes, j) for j in range(n)],
+                      [(recv_ptr + j * block_bytes, block_bytes, j) for j in range(n)], stream)
+
+
+def native_wires(subcomm):
+    """NativeWire (or None for single-rank axes) per entry of a Subcomm tuple.  COLLECTIVE over
+    the grid the tuple was cut from; every rank walks the axes in the same order."""
+    out = []
+    for c in subcomm:
+        parent = getattr(c, 'relay_parent', None)
+        if c.Get_size() == 1 or parent is None:
+            out.append(None)
+            continue
+        pw = NativeWire.create(parent)
+        members = tuple(parent._ranks.index(r) for r in c._ranks)
+        out.append(pw.split(min(members), c.Get_rank(), members))
+    return out
+
+
 class SelfComm(Comm):
     _count = itertools.count()
 
@@ -152,6 +229,9 @@ class TorchComm(Comm):
 
     def Get_rank(self):
         return self._ranks.index(self._world_rank)
+
+    def wire_key(self):
+        return ('torch', self._ranks)
 
     def __eq__(self, other):
         if isinstance(other, TorchComm):

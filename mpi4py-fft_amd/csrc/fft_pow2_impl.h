@@ -497,23 +497,30 @@ __device__ __forceinline__ cx<real> tile_load_pad(const PassDesc &d, const void 
   // zeroed by a select): a load inside a branch cannot be issued ahead of the previous one, and a
   // pass that waits for R loads one after the other is latency bound (measured on the backward
   // row pass of a padded 1024^3: 8.2 ms branching).
+  // ... and everything after the load is arithmetic on select-computed factors: a conditional
+  // `v *= 0.5` behind the load makes the compiler wait for THAT load inside the conditional, i.e.
+  // before it issues the next one (the backward strided pass of a padded 1024^3 took 7.4 ms that
+  // way against 6.7 ms unpadded, with a third of the data less to read).
   cx<real> v;
   if constexpr (MODE == MODE_C2R) {
     const cx<real> *p = reinterpret_cast<const cx<real> *>(in) + base;
     const bool mirror = e > (d.n >> 1);
     const int ee = mirror ? d.n - e : e;
     const bool ok = ee < d.tr_n;
+    const bool nyq = d.tr_even && ee == d.tr_n - 1;
     v = p[ok ? (int64_t)ee * d.in_es : 0];
-    if (d.tr_even && ee == d.tr_n - 1) { v.x *= (real)0.5; v.y = 0; }
-    if (!ok) v = {0, 0};
-    v.y *= mirror ? -sy : sy;
+    const real fx = ok ? (nyq ? (real)0.5 : (real)1) : (real)0;
+    const real fy = (ok && !nyq) ? (mirror ? -sy : sy) : (real)0;
+    v.x *= fx;
+    v.y *= fy;
   } else {
     const int h = d.tr_N >> 1;
     const bool lo = e <= h, hi = h > 0 && e >= d.n - h;
+    const bool half = d.tr_even && (e == h || e == d.n - h);
     v = reinterpret_cast<const cx<real> *>(in)[lo ? idx : (hi ? idx - shift : base)];
-    if (d.tr_even && (e == h || e == d.n - h)) { v.x *= (real)0.5; v.y *= (real)0.5; }
-    if (!(lo || hi)) v = {0, 0};
-    v.y *= sy;
+    const real f = (lo || hi) ? (half ? (real)0.5 : (real)1) : (real)0;
+    v.x *= f;
+    v.y *= f * sy;
   }
   return v;
 }
@@ -536,10 +543,82 @@ __device__ __forceinline__ void tile_store_trunc(const PassDesc &d, void *__rest
   }
 }
 
+// ---- real transforms of length 2N as one complex transform of length N (MODE_R2C_H / MODE_C2R_H) ----
+// The real line is read / written as the complex line z[j] = x[2j] + i x[2j+1] (16-byte loads in
+// fp64, half the butterflies of the full-length-with-zero-imaginary form), and the spectrum of x
+// follows from Z = DFT_N z by the Hermitian pass
+//     X[k] = (Z[k] + conj Z[N-k]) / 2  -  (i/2) w^k (Z[k] - conj Z[N-k]),   w = exp(-2 pi i / 2N),
+// k = 0..N (Z[N] = Z[0]); the backward direction inverts it,
+//     Z[k] = (X[k] + conj X[N-k])  +  i conj(w^k) (X[k] - conj X[N-k]).
+// Both need entry N-k next to entry k.  A thread holds entries e = t + q NT; the mirror entries
+// live in other threads, so the line passes through the LDS exchange buffer once more: every
+// thread writes its R entries to their slots (thread 0 also fills slot N: Z[0] again, or X[N]),
+// and reads slot N - e for each of them.  With split planes the real parts of the mirrors wait in
+// R registers while the imaginary plane goes through.
+// exp(-i pi q / R) for q < R, R in {4, 8, 16}, as compile-time constants: the Hermitian twiddle of
+// entry e = t + q NT is w^e = w^t exp(-i pi q / R) (NT = N / R, w = exp(-2 pi i / 2N)), so a thread
+// loads ONE table entry per line and derives the rest by a multiplication with a literal -- R table
+// loads per line cost R address / value register pairs that the scheduler hoists to the front.
+template <typename real> struct Pi16 {
+  static constexpr real C[9] = {(real)1.0, (real)0.98078528040323044912618223613424, (real)0.92387953251128675612818318939679,
+                                (real)0.83146961230254523707878837761791, (real)0.70710678118654752440084436210485,
+                                (real)0.55557023301960222474283081394853, (real)0.38268343236508977172845998403040,
+                                (real)0.19509032201612826784828486847702, (real)0.0};
+  static constexpr real cosk(int k) { return k <= 8 ? C[k] : -C[16 - k]; }       // cos(k pi / 16), 0 <= k <= 16
+  static constexpr real sink(int k) { return C[k <= 8 ? 8 - k : k - 8]; }        // sin(k pi / 16)
+};
+template <typename real, int R> __device__ __forceinline__ cx<real> mirror_twiddle(cx<real> wt, int q) {
+  static_assert(16 % R == 0, "mirror twiddles: R divides 16");
+  const int k = q * (16 / R);
+  const real c = Pi16<real>::cosk(k), s = -Pi16<real>::sink(k);
+  return {wt.x * c - wt.y * s, wt.x * s + wt.y * c};
+}
+
+template <typename real, int N, int R, bool SPLIT, typename F>
+__device__ __forceinline__ void mirror_pass(cx<real> *v, int t, void *col, cx<real> top, F &&combine) {
+  constexpr int NT = N / R;
+  constexpr bool PAD = is_pow2_c(N);
+  if constexpr (SPLIT) {
+    real *w = reinterpret_cast<real *>(col);
+    real px[R];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = v[q].x;
+    if (t == 0) w[pad_slot<PAD>(N)] = top.x;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; ++q) px[q] = w[pad_slot<PAD>(N - (t + q * NT))];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = v[q].y;
+    if (t == 0) w[pad_slot<PAD>(N)] = top.y;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const real py = w[pad_slot<PAD>(N - (t + q * NT))];
+      combine(q, cx<real>{px[q], py});
+    }
+  } else {
+    float2 *w = reinterpret_cast<float2 *>(col);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = make_float2(v[q].x, v[q].y);
+    if (t == 0) w[pad_slot<PAD>(N)] = make_float2(top.x, top.y);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const float2 p = w[pad_slot<PAD>(N - (t + q * NT))];
+      combine(q, cx<real>{(real)p.x, (real)p.y});
+    }
+  }
+}
+
 // FLAGS: 1 = non-temporal loads, 2 = non-temporal stores, 4 = skip the transform (access-pattern
 // probe), 8 = c2c only, 16 = fused truncation / padding adapters (d.tr_dir: 1 store, 2 load),
 // 32 = transposing store (strided kernels whose OUTPUT is contiguous along the transform axis:
-// the first pass of a four-step transform)
+// the first pass of a four-step transform), 64 = with 16: the adapter is the zero-padding LOAD
+// (backward direction) instead of the truncating STORE (a run-time direction switch inside the load
+// loop serialises the loads)
 template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int MODE, bool BIGTW, int... RADS>
 __global__ void __launch_bounds__(T *(N / R), MINW)
 fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
@@ -547,6 +626,10 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   constexpr int NT = N / R;
   constexpr int CS = Lds<N, COLS, T>::CS;
   constexpr int WORD = SPLIT ? sizeof(real) : 2 * sizeof(real);
+  // packed-real modes move complex pairs on both sides; the Hermitian pass is in the kernel body
+  constexpr bool HALF = MODE == MODE_R2C_H || MODE == MODE_C2R_H;
+  constexpr int IOMODE = HALF ? MODE_C2C : MODE;
+  static_assert(!HALF || (!COLS && !BIGTW && !(FLAGS & (16 | 32))), "packed-real modes: contiguous axis only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const cx<real> *tw = reinterpret_cast<const cx<real> *>(d.tw);
   const int tid = threadIdx.x;
@@ -563,7 +646,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   const unsigned chunks = ROWTILES ? (inner + T - 1) / T : 1;
   const unsigned ntiles = ROWTILES ? (batch / inner) * chunks : (batch + T - 1) / T;
   const real sy_in = d.conj_in ? (real)-1 : (real)1;
-  const real sx_out = (real)d.scale;
+  const real sx_out = (real)(MODE == MODE_R2C_H ? 0.5 * d.scale : d.scale);   // (the Hermitian pass leaves 2 X)
   const real sy_out = d.conj_out ? -sx_out : sx_out;
   const int64_t t_in = (int64_t)t * d.in_es, t_out = (int64_t)t * d.out_es;   // per thread
   // fused padding / truncation: distance between the two halves of the padded spectrum (uniform)
@@ -618,10 +701,10 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         if constexpr ((FLAGS & 16) != 0) {
-          v[q] = d.tr_dir == 2 ? tile_load_pad<real, MODE>(d, in, in0, idx, pad_shift_in, tl + q * NT, sy_in)
-                               : tile_load<real, MODE, false>(d, in, in0, idx, tl + q * NT, sy_in);
+          if constexpr ((FLAGS & 64) != 0) v[q] = tile_load_pad<real, IOMODE>(d, in, in0, idx, pad_shift_in, tl + q * NT, sy_in);
+          else v[q] = tile_load<real, IOMODE, false>(d, in, in0, idx, tl + q * NT, sy_in);
         } else {
-          v[q] = tile_load<real, MODE, (FLAGS & 1) != 0>(d, in, in0, idx, tl + q * NT, sy_in);
+          v[q] = tile_load<real, IOMODE, (FLAGS & 1) != 0>(d, in, in0, idx, tl + q * NT, sy_in);
         }
         int64_t step = q_in;
         if (++cnt == seg_in) {
@@ -639,14 +722,47 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     // (40 VGPRs at fp64 n=1024), costing a wave of occupancy per SIMD.
     const cx<real> *twl = tw;
     asm volatile("" : "+s"(twl));
+    [[maybe_unused]] const cx<real> *rtw = reinterpret_cast<const cx<real> *>(d.rtw);
+    if constexpr (HALF) asm volatile("" : "+s"(rtw));
+    if constexpr (MODE == MODE_C2R_H) {
+      // Hermitian half spectrum X[0..N] -> packed spectrum Z[0..N-1], conjugated for the
+      // inverse-by-conjugation butterflies.  Imaginary parts of X[0] and X[N] are ignored, as FFTW's
+      // c2r does.
+      cx<real> top = {0, 0};
+      if (tl == 0) {
+        if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[in0 + (int64_t)N * d.in_es].x;
+        v[0].y = 0;
+      }
+      const cx<real> wt = rtw[tl];
+      mirror_pass<real, N, R, SPLIT>(v, tl, col, top, [&](int q, cx<real> p) {
+        const cx<real> w = mirror_twiddle<real, R>(wt, q);         // (c, s) = exp(-2 pi i e / 2N)
+        const cx<real> a = {v[q].x + p.x, v[q].y - p.y};           // X + conj P
+        const cx<real> b = {v[q].x - p.x, v[q].y + p.y};           // X - conj P
+        const cx<real> wb = {w.x * b.x + w.y * b.y, w.x * b.y - w.y * b.x};   // conj(w) b
+        v[q] = {a.x - wb.y, -(a.y + wb.x)};                        // conj(a + i conj(w) b)
+      });
+    }
     // (the row index `tl` is laundered for the same reason: fp32 n=1024 R=32 104 bytes of scratch
     // -> none; fp64 n=1024 R=16 T=16 127 -> 107 VGPRs)
     if constexpr (!(FLAGS & 4)) Stage<real, N, R, SPLIT, 1, RADS...>::run(v, tl, col, twl);
-    if constexpr ((FLAGS & 16) != 0 && MODE == MODE_C2C) {
+    [[maybe_unused]] cx<real> z0 = v[0];
+    if constexpr (MODE == MODE_R2C_H) {
+      // packed spectrum Z[0..N-1] -> Hermitian half spectrum X[0..N-1] in place (twice the values:
+      // the factor 1/2 rides on the store scale); X[N] = Re Z[0] - Im Z[0] is stored by thread 0
+      const cx<real> wt = rtw[tl];
+      mirror_pass<real, N, R, SPLIT>(v, tl, col, v[0], [&](int q, cx<real> p) {
+        const cx<real> w = mirror_twiddle<real, R>(wt, q);
+        const cx<real> a = {v[q].x + p.x, v[q].y - p.y};           // Z + conj P
+        const cx<real> b = {v[q].x - p.x, v[q].y + p.y};           // Z - conj P
+        const cx<real> wb = cmul(w, b);
+        v[q] = {a.x + wb.y, a.y - wb.x};                           // a - i w b
+      });
+    }
+    if constexpr ((FLAGS & 16) != 0 && !(FLAGS & 64) && MODE == MODE_C2C) {
       // complex truncation with even N: entries h = N/2 and n - h of the padded spectrum both land
       // on truncated entry h (libfft.py:281-284).  They live in different threads: pass the upper
       // one through LDS.  (uniform branch: every thread of the workgroup takes it or none does)
-      if (d.tr_dir == 1 && d.tr_even) {
+      if (d.tr_even) {
         cx<real> *fold = reinterpret_cast<cx<real> *>(smem);
         const int h = d.tr_N >> 1;
         __syncthreads();
@@ -713,10 +829,10 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         if constexpr ((FLAGS & 16) != 0) {
-          if (d.tr_dir == 1) tile_store_trunc<real, MODE>(d, out, idx, pad_shift_out, tl + q * NT, v[q], sx_out, sy_out);
-          else tile_store<real, MODE, false, false>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
+          if constexpr (!(FLAGS & 64)) tile_store_trunc<real, IOMODE>(d, out, idx, pad_shift_out, tl + q * NT, v[q], sx_out, sy_out);
+          else tile_store<real, IOMODE, false, false>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
         } else {
-          tile_store<real, MODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
+          tile_store<real, IOMODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
         }
         int64_t step = q_out;
         if (++cnt == seg_out) {
@@ -724,6 +840,10 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
           step += d.out_jump;
         }
         idx += step;
+      }
+      if constexpr (MODE == MODE_R2C_H) {
+        if (tl == 0)
+          reinterpret_cast<cx<real> *>(out)[out0 + (int64_t)N * d.out_es] = {(z0.x - z0.y) * 2 * sx_out, 0};
       }
     }
   }
@@ -736,7 +856,7 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   constexpr int NT = N / R;
   constexpr int threads = T * NT;
   static_assert(threads >= 64 && threads <= 1024, "workgroup size");
-  constexpr size_t lds_x = (sizeof...(RADS) > 1 || (FLAGS & 32)) ? (size_t)T * Lds<N, COLS, T>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
+  constexpr size_t lds_x = (sizeof...(RADS) > 1 || (FLAGS & 32) || MODE == MODE_R2C_H || MODE == MODE_C2R_H) ? (size_t)T * Lds<N, COLS, T>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
   constexpr size_t lds_f = (FLAGS & 16) ? (size_t)T * 2 * sizeof(real) : 0;
   constexpr size_t lds = lds_x > lds_f ? lds_x : lds_f;
   static_assert(lds <= 160 * 1024, "LDS budget");
@@ -783,8 +903,8 @@ hipError_t launch_pow2_inst(const PassDesc &d, const void *in, void *out, hipStr
     }
     if (d.tr_dir == 1 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2C, false, RADS...>(d, in, out, s);
     if (d.tr_dir == 1 && d.mode == MODE_R2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_R2C, false, RADS...>(d, in, out, s);
-    if (d.tr_dir == 2 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2C, false, RADS...>(d, in, out, s);
-    if (d.tr_dir == 2 && d.mode == MODE_C2R) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2R, false, RADS...>(d, in, out, s);
+    if (d.tr_dir == 2 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16 | 64, MODE_C2C, false, RADS...>(d, in, out, s);
+    if (d.tr_dir == 2 && d.mode == MODE_C2R) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16 | 64, MODE_C2R, false, RADS...>(d, in, out, s);
     if (d.tr_dir) return hipErrorInvalidValue;
     switch (d.mode) {
       case MODE_C2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, false, RADS...>(d, in, out, s);

@@ -1,0 +1,55 @@
+// fp32 packed-real row kernels (see fft_real_f64.hip): r2c / c2r of even length 2N along a
+// contiguous axis as one complex64 transform of length N plus the Hermitian pass in registers.
+// fp32 exchanges whole complex values through LDS, so the mirror entries are combined as they are
+// read (no extra registers) and R = 16 plans stay under 128 VGPRs.
+#include "fft_pow2_impl.h"
+
+namespace gfft {
+
+// (R = 16 plans are held to 128 VGPRs = 4 waves per SIMD: unconstrained, the backward kernels
+// keep all mirror entries and twiddles in flight at once and take ~170)
+#define H32(MODE, N, R, T, ...) \
+  launch_pow2_one<float, N, R, T, false, false, 1, 0, MODE, false, __VA_ARGS__>(d, in, out, s)
+
+template <int MODE>
+static hipError_t launch_half_f32(const PassDesc &d, int variant, const void *in, void *out, hipStream_t s) {
+  switch (d.n) {
+    case 16: return H32(MODE, 16, 4, 16, 4, 4);
+    case 32: return H32(MODE, 32, 8, 16, 8, 4);
+    case 64: return H32(MODE, 64, 8, 8, 8, 8);
+    case 128: return H32(MODE, 128, 8, 4, 8, 8, 2);
+    case 256: return H32(MODE, 256, 16, 4, 16, 16);
+    // measured on (1024,1024,1024) / (512,1024,2048) / (256,1024,4096) f32 (tools/real_probe.py):
+    // forward likes R = 16 everywhere; backward R = 16 takes ~170 VGPRs and only wins from N = 1024
+    case 512:
+      switch (variant) {
+        default:
+          if (MODE == MODE_C2R_H) return H32(MODE, 512, 8, 4, 8, 8, 8);
+          return H32(MODE, 512, 16, 8, 16, 8, 4);
+        case 2: return H32(MODE, 512, 8, 8, 8, 8, 8);
+        case 3: return H32(MODE, 512, 8, 1, 8, 8, 8);
+      }
+    case 1024:
+      switch (variant) {
+        default: return H32(MODE, 1024, 16, 1, 16, 16, 4);
+        case 2: return H32(MODE, 1024, 16, 4, 16, 16, 4);
+        case 3: return H32(MODE, 1024, 8, 4, 8, 8, 8, 2);
+      }
+    case 2048:
+      switch (variant) {
+        default: return H32(MODE, 2048, 16, 1, 16, 16, 8);
+        case 2: return H32(MODE, 2048, 16, 2, 16, 16, 8);
+        case 3: return H32(MODE, 2048, 8, 2, 8, 8, 8, 4);
+      }
+    case 4096: return H32(MODE, 4096, 16, 1, 16, 16, 16);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_real_half_f32(const PassDesc &d, int variant, const void *in, void *out, hipStream_t s) {
+  if (d.mode == MODE_R2C_H) return launch_half_f32<MODE_R2C_H>(d, variant, in, out, s);
+  if (d.mode == MODE_C2R_H) return launch_half_f32<MODE_C2R_H>(d, variant, in, out, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace gfft

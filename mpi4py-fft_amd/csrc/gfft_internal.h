@@ -21,7 +21,10 @@ template <typename T> __device__ __forceinline__ cx<T> cswap(cx<T> a) { return {
 // Column b of the batch decomposes as b = (o * mid + m) * inner + i; element e of that column
 // sits at  base + o*os + m*ms + i*is + e*es  (strides in units of the buffer's element type:
 // real scalars on the real side of r2c/c2r, complex otherwise).
-enum PassMode { MODE_C2C = 0, MODE_R2C = 1, MODE_C2R = 2, MODE_R2R = 3 };
+// MODE_R2C_H / MODE_C2R_H: real transforms of even length 2 n along a CONTIGUOUS axis as one complex
+// transform of length n on the packed line z[j] = x[2j] + i x[2j+1] plus a Hermitian pass in
+// registers (fft_pow2_impl.h); the real side is addressed as complex pairs (strides in pairs).
+enum PassMode { MODE_C2C = 0, MODE_R2C = 1, MODE_C2R = 2, MODE_R2R = 3, MODE_R2C_H = 4, MODE_C2R_H = 5 };
 
 struct PassDesc {
   int n;          // logical transform length
@@ -49,6 +52,7 @@ struct PassDesc {
   int r2r_n, r2r_pos0, r2r_idx0;
   double scale;           // applied on store
   const void *tw;         // cx<real>[n]: exp(-2 pi i k / n)
+  const void *rtw;        // MODE_R2C_H / MODE_C2R_H: cx<real>[n]: exp(-2 pi i k / (2 n)), k < n
   // optional four-step twiddle: output element k of a column with mid index m is multiplied
   // by W_big^(m*k), W_big = exp(-2 pi i / big_n), m*k < big_n <= 2^24;
   // factored as hi[(m*k) >> tw_L] * lo[(m*k) & (2^tw_L - 1)]
@@ -96,6 +100,10 @@ bool pow2_r2r_supported(int n);
 hipError_t launch_pow2_r2r_f64(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
 hipError_t launch_pow2_r2r_f32(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
 int pow2_grid_cap();
+// packed-real row kernels (fft_real_*.hip): d.n = complex length = half the real length
+bool real_half_supported(int n_complex);
+hipError_t launch_real_half_f64(const PassDesc &d, int variant, const void *in, void *out, hipStream_t s);
+hipError_t launch_real_half_f32(const PassDesc &d, int variant, const void *in, void *out, hipStream_t s);
 // lengths 3^b * 2^k handled by the same register-resident kernel with R = 12 (fft_mix3_*.hip)
 bool mix3_supported(int n);
 hipError_t launch_mix3_f64(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);

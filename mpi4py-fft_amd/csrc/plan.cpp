@@ -67,6 +67,7 @@ struct Options {
   int xcd_swizzle = -1;      // XCD-contiguous tile order in the pow2 kernels: 0 off, 1 on, -1 auto
   int profile = 0;           // record HIP events around every pass (bench.py roofline leg)
   int fused3 = 1;            // reorder + padded-pitch workspace for 3-D all-axes plans
+  int real_half = 1;         // contiguous real lines as half-length complex transforms (fft_real_*.hip)
   int64_t fused3_min_bytes = 32 << 20;
   Options() {
     if (const char *s = getenv("GFFT_GRID_CAP")) grid_cap = atoi(s);
@@ -74,6 +75,7 @@ struct Options {
     if (const char *s = getenv("GFFT_VARIANT_COLS")) variant_cols = atoi(s);
     if (const char *s = getenv("GFFT_FORCE_GENERIC")) force_generic = atoi(s);
     if (const char *s = getenv("GFFT_FUSED3")) fused3 = atoi(s);
+    if (const char *s = getenv("GFFT_REAL_HALF")) real_half = atoi(s);
     if (const char *s = getenv("GFFT_XCD_SWIZZLE")) xcd_swizzle = atoi(s);
   }
 };
@@ -177,6 +179,10 @@ struct Pass {
   bool logical_first = false;        // first kernel of a transformed axis (profiling/report)
   PointDesc pt{};                    // PK_EMBED / PK_MULB / PK_EXTRACT geometry
   double extra_scale = 1.0;          // e.g. 1/M of Bluestein's inverse
+  // packed-real passes keep the full-length form of the same line (MODE_R2C / MODE_C2R with the
+  // zero-imaginary / mirror adapters) for what only that form can fuse: truncation / padding
+  bool has_full = false;
+  PassDesc full{};
 };
 
 bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -259,6 +265,26 @@ PassDesc natural_desc(const Line &L) {
   d.out_es = L.inner;
   d.scale = 1.0;
   return d;
+}
+
+// Real lines along a contiguous axis, even length: the packed-real form (MODE_R2C_H / MODE_C2R_H).
+bool real_half_ok(const Line &L, int prec) {
+  (void)prec;
+  return opts().real_half && !opts().force_generic && (L.mode == MODE_R2C || L.mode == MODE_C2R) &&
+         L.inner == 1 && L.n % 2 == 0 && real_half_supported((int)(L.n / 2)) && L.outer < ((int64_t)1 << 31);
+}
+
+// natural_desc(L) restated for the packed-real form: d.n = complex length, real side in pairs
+void half_desc(PassDesc *d, const Line &L) {
+  const int64_t m = L.n / 2;
+  d->n = (int)m;
+  d->mode = L.mode == MODE_R2C ? MODE_R2C_H : MODE_C2R_H;
+  d->conj_in = 0;
+  d->conj_out = L.mode == MODE_C2R ? 1 : 0;     // inverse by conjugation: the pre-pass conjugates
+  d->in_os = L.mode == MODE_R2C ? m : m + 1;
+  d->out_os = L.mode == MODE_R2C ? m + 1 : m;
+  d->in_es = d->out_es = 1;
+  d->in_is = d->out_is = 1;
 }
 
 // ---- four-step for long composite lengths: n = n1 * n2 (complex) ---------------------------
@@ -650,6 +676,24 @@ int plan_line(gfft_plan_s *pl, const Line &L, bool top) {
   p.dst = L.dst;
   p.logical_first = true;
   const int gmax = generic_max_n(prec);
+  if (real_half_ok(L, prec)) {
+    // contiguous real lines of even length: one complex transform of HALF the length on the line
+    // read / written as complex pairs, Hermitian pass in registers (fft_real_*.hip)
+    if (regk_ok(n, prec)) {
+      p.has_full = true;
+      p.full = p.d;
+      int rc = get_twiddles(n, prec, &p.full.tw);
+      if (rc) return rc;
+    }
+    half_desc(&p.d, L);
+    p.regk = true;
+    p.cols = false;
+    int rc = get_twiddles(n / 2, prec, &p.d.tw);
+    if (!rc) rc = get_twiddles(n, prec, &p.d.rtw);
+    if (rc) return rc;
+    pl->passes.push_back(p);
+    return GFFT_OK;
+  }
   if (regk_ok(n, prec)) {
     p.regk = true;
     p.cols = L.inner > 1;
@@ -768,6 +812,15 @@ int plan_fused3(gfft_plan_s *pl) {
     p.d.in_es = 1;
     p.d.out_es = 1;
     p.src = src; p.dst = dst;
+    if (mode != MODE_C2C && opts().real_half && n2 % 2 == 0 && real_half_supported((int)(n2 / 2))) {
+      // packed-real form: complex length n2/2, the real side (the user's natural array) in pairs
+      p.d.n = (int)(n2 / 2);
+      p.d.mode = mode == MODE_R2C ? MODE_R2C_H : MODE_C2R_H;
+      p.d.conj_in = 0;
+      p.d.conj_out = mode == MODE_C2R ? 1 : 0;
+      if (mode == MODE_R2C) { p.d.in_os /= 2; p.d.in_is /= 2; }
+      else { p.d.out_os /= 2; p.d.out_is /= 2; }
+    }
     return p;
   };
   // axis 1: batch (o = i0, i = c)
@@ -805,11 +858,14 @@ int plan_fused3(gfft_plan_s *pl) {
   for (Pass &p : seq) {
     int rc = get_twiddles(p.d.n, prec, &p.d.tw);
     if (rc) return rc;
+    const bool half = p.d.mode == MODE_R2C_H || p.d.mode == MODE_C2R_H;
+    if (half && (rc = get_twiddles(2 * (int64_t)p.d.n, prec, &p.d.rtw))) return rc;
     const double lines = (double)p.d.batch;
-    const double n = p.d.n;
+    const double n = half ? 2.0 * p.d.n : p.d.n;          // logical length of the line
+    const bool r2c = p.d.mode == MODE_R2C || p.d.mode == MODE_R2C_H, c2r = p.d.mode == MODE_C2R || p.d.mode == MODE_C2R_H;
     pl->flops += (p.d.mode == MODE_C2C ? 1.0 : 0.5) * 5.0 * n * std::log2(n) * lines;
-    const double ein = p.d.mode == MODE_R2C ? prec : esz, eout = p.d.mode == MODE_C2R ? prec : esz;
-    const double nin = p.d.mode == MODE_C2R ? (double)nc : n, nout = p.d.mode == MODE_R2C ? (double)nc : n;
+    const double ein = r2c ? prec : esz, eout = c2r ? prec : esz;
+    const double nin = c2r ? (double)nc : n, nout = r2c ? (double)nc : n;
     pl->bytes += lines * (nin * ein + nout * eout);
     pl->passes.push_back(p);
   }
@@ -830,6 +886,9 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   const int64_t esz_out = ((d.mode == MODE_C2R || d.mode == MODE_R2R) ? 1 : 2) * (int64_t)pl->precision;
   d.swizzle = pl->xcd_swizzle >= 0 ? pl->xcd_swizzle
                                    : (p.cols && ((d.out_es * esz_out) % 128 != 0) ? 1 : 0);
+  if (d.mode == MODE_R2C_H || d.mode == MODE_C2R_H)
+    return pl->precision == 8 ? launch_real_half_f64(d, pl->variant_rows, in, out, s)
+                              : launch_real_half_f32(d, pl->variant_rows, in, out, s);
   if (p.regk && d.mode == MODE_R2R && pow2_r2r_supported(d.n))
     return pl->precision == 8 ? launch_pow2_r2r_f64(d, p.cols, in, out, s) : launch_pow2_r2r_f32(d, p.cols, in, out, s);
   if (p.regk && mix3_supported(d.n)) {
@@ -897,6 +956,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "force_generic")) opts().force_generic = value;
   else if (!strcmp(key, "copy_nt")) gfft::g_copy_nt = value;
   else if (!strcmp(key, "fused3")) opts().fused3 = value;
+  else if (!strcmp(key, "real_half")) opts().real_half = value;
   else if (!strcmp(key, "profile")) opts().profile = value;
   else if (!strcmp(key, "xcd_swizzle")) opts().xcd_swizzle = value;
   else if (!strcmp(key, "fused3_min_mib")) opts().fused3_min_bytes = (int64_t)value << 20;
@@ -1121,6 +1181,12 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
   const bool percol = !p.regk && (p.d.n == 3 || p.d.n == 5 || p.d.n == 7 || p.d.n == 11 || p.d.n == 13) &&
                       p.d.mode == MODE_C2C && !p.d.tw_hi && p.d.in_is == 1 && p.d.out_is == 1 && p.d.inner >= 64;
   snprintf(buf, len, "%s n=%d", p.regk ? (p.cols ? "pow2-cols" : "pow2-rows") : (percol ? "percol" : "generic"), p.d.n);
+  if (bytes && (p.d.mode == MODE_R2C_H || p.d.mode == MODE_C2R_H)) {
+    // n complex = 2n reals on one side, n + 1 complex on the other
+    *bytes = (double)p.d.batch * (2.0 * p.d.n * pl->precision + (p.d.n + 1.0) * 2.0 * pl->precision);
+    snprintf(buf, len, "real-rows n=%d", 2 * p.d.n);
+    return GFFT_OK;
+  }
   if (bytes) {
     const double esz = 2.0 * pl->precision;
     const double nc = p.d.mode == MODE_C2C ? p.d.n : p.d.n / 2 + 1;
@@ -1142,6 +1208,12 @@ int gfft_plan_set_truncation(gfft_plan pl, int64_t n_keep) {
   if (pl->passes.size() != 1 || pl->axes.size() != 1 || pl->fused3)
     return fail(GFFT_ERR_UNSUPPORTED, "truncation fuses into single-pass plans only");
   Pass &p = pl->passes[0];
+  if (p.d.mode == MODE_R2C_H || p.d.mode == MODE_C2R_H) {
+    // the truncation / padding adapters belong to the full-length form of a real line
+    if (!p.has_full) return fail(GFFT_ERR_UNSUPPORTED, "truncation: no single-pass full-length form of this real line");
+    p.d = p.full;
+    p.has_full = false;
+  }
   if (p.kind != PK_FFT || !p.regk || p.d.mid != 1 || p.d.tw_hi)
     return fail(GFFT_ERR_UNSUPPORTED, "truncation fuses into register-kernel passes only");
   const int axis = pl->axes[0];
@@ -1202,6 +1274,68 @@ int gfft_plan_set_split(gfft_plan pl, int side, int nblocks) {
   return GFFT_OK;
 }
 
+int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_iodim *dim, int howmany_rank,
+                          const gfft_iodim *howmany, int in_blocks, int64_t in_block_stride, int out_blocks,
+                          int64_t out_block_stride) {
+  if (!plan || !dim || (howmany_rank > 0 && !howmany)) return fail(GFFT_ERR_INVALID, "null argument");
+  *plan = nullptr;
+  if (precision != GFFT_F32 && precision != GFFT_F64) return fail(GFFT_ERR_INVALID, "precision must be 4 or 8");
+  if (kind != GFFT_C2C_FORWARD && kind != GFFT_C2C_BACKWARD) return fail(GFFT_ERR_UNSUPPORTED, "guru plans are complex-to-complex");
+  if (howmany_rank < 0 || howmany_rank > 3) return fail(GFFT_ERR_UNSUPPORTED, "at most three batch dims");
+  if (dim->n < 1) return fail(GFFT_ERR_INVALID, "bad transform length");
+  int rc = check_device();
+  if (rc) return rc;
+  if (!regk_ok(dim->n, precision)) return fail(GFFT_ERR_UNSUPPORTED, "no single-pass register kernel for this length");
+  // batch dims -> (outer, mid, inner): the last listed dim is the one adjacent columns run along
+  gfft_iodim o{1, 0, 0}, m{1, 0, 0}, i{1, 0, 0};
+  if (howmany_rank == 1) i = howmany[0];
+  if (howmany_rank == 2) { o = howmany[0]; i = howmany[1]; }
+  if (howmany_rank == 3) { o = howmany[0]; m = howmany[1]; i = howmany[2]; }
+  if (o.n < 1 || m.n < 1 || i.n < 1) return fail(GFFT_ERR_INVALID, "bad batch length");
+  const double batch = (double)o.n * (double)m.n * (double)i.n;
+  if (batch >= 2147483648.0) return fail(GFFT_ERR_UNSUPPORTED, "batch exceeds 2^31");
+  const int64_t n = dim->n;
+  auto blocks_ok = [&](int nb) {
+    if (nb < 1 || (nb & (nb - 1))) return false;
+    const int max_blocks = is_pow2(n) ? (n >= 32 ? 8 : 4) : 4;    // whole thread slots per block (see gfft_plan_set_split)
+    return nb <= max_blocks && n % nb == 0;
+  };
+  if (!blocks_ok(in_blocks) || !blocks_ok(out_blocks)) return fail(GFFT_ERR_UNSUPPORTED, "block count not supported for this length");
+  gfft_plan_s *pl = new gfft_plan_s;
+  pl->ndims = 0;
+  pl->kind = kind;
+  pl->precision = precision;
+  pl->variant_rows = opts().variant_rows;
+  pl->variant_cols = opts().variant_cols;
+  pl->xcd_swizzle = opts().xcd_swizzle;
+  Pass p;
+  p.regk = true;
+  p.cols = !(dim->is == 1 && dim->os == 1);
+  p.logical_first = true;
+  p.carries_scale = true;
+  PassDesc &d = p.d;
+  const bool inverse = kind == GFFT_C2C_BACKWARD;
+  d.n = (int)n;
+  d.mode = MODE_C2C;
+  d.conj_in = d.conj_out = inverse ? 1 : 0;
+  d.batch = o.n * m.n * i.n;
+  d.mid = m.n;
+  d.inner = i.n;
+  d.in_os = o.is; d.in_ms = m.is; d.in_is = i.is; d.in_es = dim->is;
+  d.out_os = o.os; d.out_ms = m.os; d.out_is = i.os; d.out_es = dim->os;
+  d.scale = 1.0;
+  auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+  if (in_blocks > 1) { d.in_lgp = lg2(in_blocks); d.in_jump = in_block_stride - (n / in_blocks) * dim->is; }
+  if (out_blocks > 1) { d.out_lgp = lg2(out_blocks); d.out_jump = out_block_stride - (n / out_blocks) * dim->os; }
+  rc = get_twiddles(n, precision, &d.tw);
+  if (rc) { delete pl; return rc; }
+  pl->passes.push_back(p);
+  if (n > 1) pl->flops = 5.0 * (double)n * std::log2((double)n) * batch;
+  pl->bytes = batch * (double)n * 4.0 * precision;
+  *plan = pl;
+  return GFFT_OK;
+}
+
 int gfft_plan_destroy(gfft_plan pl) {
   if (!pl) return GFFT_OK;
   if (pl->scratch) (void)hipFree(pl->scratch);
@@ -1229,7 +1363,9 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
     }
     snprintf(line, sizeof line, "  n=%d batch=%lld (mid=%lld inner=%lld) es_in=%lld es_out=%lld kernel=%s%s%s  %s -> %s\n",
              p.d.n, (long long)p.d.batch, (long long)p.d.mid, (long long)p.d.inner, (long long)p.d.in_es,
-             (long long)p.d.out_es, p.regk ? (p.cols ? "regs-cols" : "regs-rows") : "generic",
+             (long long)p.d.out_es,
+             (p.d.mode == MODE_R2C_H || p.d.mode == MODE_C2R_H) ? "regs-rows packed-real (n = complex length)"
+             : p.regk ? (p.cols ? "regs-cols" : "regs-rows") : "generic",
              p.d.tw_hi ? " [four-step 1/2, fused twiddle]" : "", p.carries_scale ? " [scale]" : "",
              bufn[p.src], bufn[p.dst]);
     s += line;

@@ -26,13 +26,15 @@ from . import comm as _comm
 class Transform:
     """A parallel transform, forward or backward: serial transforms interleaved with global
     redistributions (mpifft.py:8-79)."""
-    def __init__(self, xfftn, transfer, pencil, fused=None):
+    def __init__(self, xfftn, transfer, pencil, fused=None, pipe=None):
         assert len(xfftn) == len(transfer) + 1 and len(pencil) == 2
         self._xfftn = tuple(xfftn)
         self._transfer = tuple(transfer)
         self._pencil = tuple(pencil)
         # single-rank shortcut: one all-axes plan from input_array to output_array (see PFFT)
         self._fused = fused
+        # (pipeline.Pipeline, is_forward): chunked execution overlapped with the exchanges
+        self._pipe = pipe
 
     @property
     def input_array(self):
@@ -68,6 +70,13 @@ class Transform:
         # kernel writes a device array of the planned shape/dtype directly.
         if output_array is not None and self._direct(output_array, self.output_array):
             dst = output_array
+        if self._pipe is not None:
+            pipe, is_forward = self._pipe
+            pipe.run(is_forward, None if src is None else src.tensor, None if dst is None else dst.tensor,
+                     kw.get('normalize', is_forward))
+            if output_array is not None and dst is None:
+                output_array[...] = self.output_array
+            return self.output_array if output_array is None else output_array
         io = {}
         if src is not None:
             io['src'] = src
@@ -159,6 +168,9 @@ class PFFT:
         sub-communicator), 'relay' (two rounds over all xGMI links of the grid, relay.py) or
         'auto' (time both at the first call and keep the faster).  Default: the GFFT_RELAY
         environment switch, else 'auto'.
+    wire : 'native' = chunked redistributions overlapped with the serial transforms on libgfft's
+        own RCCL communicators (pipeline.py); 'torch' = the staged path on torch.distributed's
+        collectives.  Default: GFFT_WIRE, else 'auto' (native when the grid runs on RCCL).
     fuse : single-GPU transforms run as one all-axes plan (default True)
     fuse_pack : serial transforms write / read the exchange buffers directly (default True)
     """
@@ -166,6 +178,7 @@ class PFFT:
                  collapse=False, backend='fftw', transforms=None, darray=None, **kw):
         # keywords of this engine (not in the reference): see the class docstring
         exchange = kw.pop('exchange', None)
+        wire = kw.pop('wire', None)
         fuse = kw.pop('fuse', True)
         fuse_pack = kw.pop('fuse_pack', os.environ.get('GFFT_FUSE_PACK', '1') != '0')
         slab = kw.pop('slab', False)
@@ -208,15 +221,39 @@ class PFFT:
             # the route of every exchange (relay.py): collective over the grid, same order everywhere
             for t in self.transfer:
                 t.plan_relay(exchange)
+        self.pipeline = None
+        if not local and padding is False and transforms is None:
+            self.pipeline = self._plan_pipeline(wire)
 
         self.forward = Transform(
             [o.forward for o in self.xfftn],
             [o.forward for o in self.transfer],
-            self.pencil, fused_fwd)
+            self.pencil, fused_fwd, None if self.pipeline is None else (self.pipeline, True))
         self.backward = Transform(
             [o.backward for o in self.xfftn[::-1]],
             [o.backward for o in self.transfer[::-1]],
-            self.pencil[::-1], fused_bck)
+            self.pencil[::-1], fused_bck, None if self.pipeline is None else (self.pipeline, False))
+
+    def _plan_pipeline(self, wire):
+        """The chunked, stream-overlapped form of this transform on libgfft's own RCCL communicators
+        (pipeline.py), or None: `wire` = 'native' asks for it, 'torch' keeps the staged path on
+        torch.distributed's collectives, None reads GFFT_WIRE (default 'auto': native when the
+        grid's wire is RCCL).  Collective over the grid (communicator split)."""
+        mode = (os.environ.get('GFFT_WIRE', 'auto') if wire is None else str(wire)).lower()
+        if mode in ('torch', 'staged', '0', 'off'):
+            return None
+        parents = [getattr(c, 'relay_parent', None) for c in self.subcomm]
+        parent = next((p for p in parents if p is not None), None)
+        if parent is None or (mode == 'auto' and parent.backend != 'nccl'):
+            return None
+        from . import pipeline
+        try:
+            wires = _comm.native_wires(self.subcomm)
+        except Exception:
+            if mode == 'native':
+                raise
+            return None
+        return pipeline.Pipeline.build(self, wires)
 
     # ---- planning steps (what mpifft.py:202-347 decides, one decision per helper) ---------------
     @staticmethod
@@ -403,6 +440,8 @@ class PFFT:
             trans.destroy()
         for x in self.xfftn:
             x.destroy()
+        if getattr(self, 'pipeline', None) is not None:
+            self.pipeline.destroy()
         if self._fused_plans:
             for p in self._fused_plans:
                 p.destroy()

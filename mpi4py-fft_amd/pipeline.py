@@ -1,0 +1,281 @@
+"""Chunked, stream-overlapped execution of a distributed transform: FFT(k+1) on the compute stream
+while exchange(k) is on the wire.
+
+The reference runs a parallel transform as a strict sequence -- serial transform, Alltoallw,
+serial transform, ... (mpifft.py:68-73) -- and so does the staged path of this package
+(mpifft.Transform).  On xGMI the exchanges dominate the multi-GPU transform, and the serial
+transforms on either side of one only touch disjoint slabs of the array; so here every
+redistribution is cut into K chunks along the array axis that takes no part in it (the free axis:
+neither the axis being gathered nor the one being scattered), and
+
+    stage A writes chunk k of the send buffer  ->  chunk k goes on the wire  ->  stage B reads chunk k
+
+run as a pipeline: the serial transforms on the caller's (compute) stream, the exchanges on a
+communication stream this module owns, chained by events -- no host synchronisation.  The wire is
+libgfft's own RCCL communicator (comm.NativeWire: grouped ncclSend / ncclRecv, C ABI gfft_sendrecv).
+
+Buffers are chunk-major exchange buffers  [chunk][block = peer][C order of the chunk's sub-box],
+so every chunk of every peer is one contiguous message, and the transform kernels address them
+directly (gfft_plan_create_guru: explicit strides + block stride along the transformed axis):
+neither pack nor unpack kernels run, exactly as in the fused staged path (PFFT._fuse_packs).
+
+Applies to 3-D complex-to-complex transforms whose stages are single-axis register-kernel lengths
+and whose redistributions split evenly over a power-of-two number of ranks <= 8 (the BASELINE
+configurations); anything else keeps the staged path.  Results are bit-identical to it (same
+kernels, same arithmetic; tests/test_gpu_pipeline.py).
+"""
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+def _cstrides(shape):
+    st, acc = [], 1
+    for n in reversed(shape):
+        st.insert(0, acc)
+        acc *= int(n)
+    return st
+
+
+class Layout:
+    """Where element (i_0, .., i_{d-1}) of a stage's local array lives, in elements: natural C
+    order, or an exchange buffer -- axis `axis` cut into `p` blocks, optionally chunk-major in `K`
+    chunks along the free axis `f`."""
+    def __init__(self, shape, axis=None, p=1, f=None, K=1):
+        self.shape = tuple(int(n) for n in shape)
+        self.axis, self.p, self.f, self.K = axis, int(p), f, int(K)
+        sub = list(self.shape)
+        if self.p > 1:
+            assert sub[axis] % self.p == 0
+            sub[axis] //= self.p
+        if self.K > 1:
+            assert sub[f] % self.K == 0
+            sub[f] //= self.K
+        self.sub = tuple(sub)
+        self.stride = _cstrides(sub)
+        self.block = int(np.prod(sub, dtype=np.int64))       # elements per (chunk, peer) message
+        self.chunk = self.block * self.p                      # elements per chunk region
+        self.width = sub[f] if self.K > 1 else None           # entries of the free axis per chunk
+
+
+class _Stage:
+    """One serial transform of the chain in one direction: guru plan + how to walk its chunks."""
+    def __init__(self, shape, axis, lay_in, lay_out, kind, precision):
+        self.axis, self.lay_in, self.lay_out = axis, lay_in, lay_out
+        nd = len(shape)
+        # iterate over the chunks of the side that has them (input side first: data arrives in
+        # chunks; a first stage iterates over the chunks it has to deliver)
+        if lay_in.K > 1:
+            self.iter_lay, self.iter_side = lay_in, 'in'
+        elif lay_out.K > 1:
+            self.iter_lay, self.iter_side = lay_out, 'out'
+        else:
+            self.iter_lay, self.iter_side = None, None
+        self.nchunks = self.iter_lay.K if self.iter_lay else 1
+        fi = self.iter_lay.f if self.iter_lay else None
+        other = lay_out if self.iter_side == 'in' else lay_in      # the side walked in full
+        dims = []
+        for d in range(nd):
+            if d == axis:
+                continue
+            if d == fi:
+                dims.append((self.iter_lay.width, lay_in.stride[d], lay_out.stride[d]))
+            elif other.K > 1 and d == other.f:
+                # the other side is chunk-major along d: (chunk, entry within the chunk)
+                w = other.width
+                if other is lay_out:
+                    dims.append((other.K, w * lay_in.stride[d], other.chunk))
+                    dims.append((w, lay_in.stride[d], lay_out.stride[d]))
+                else:
+                    dims.append((other.K, other.chunk, w * lay_out.stride[d]))
+                    dims.append((w, lay_in.stride[d], lay_out.stride[d]))
+            else:
+                dims.append((shape[d], lay_in.stride[d], lay_out.stride[d]))
+        dims = [x for x in dims if x[0] > 1] or [(1, 0, 0)]
+        self.plan = None
+        if len(dims) <= 3:
+            self.plan = _lib.engine().plan_create_guru(
+                precision, kind, (shape[axis], lay_in.stride[axis], lay_out.stride[axis]), dims,
+                lay_in.p, lay_in.block, lay_out.p, lay_out.block)
+        # element offsets of chunk c on either side
+        if self.iter_side == 'in':
+            self.step_in, self.step_out = lay_in.chunk, lay_in.width * lay_out.stride[fi]
+        elif self.iter_side == 'out':
+            self.step_in, self.step_out = lay_out.width * lay_in.stride[fi], lay_out.chunk
+        else:
+            self.step_in = self.step_out = 0
+
+    def destroy(self):
+        if self.plan is not None:
+            _lib.engine().plan_destroy(self.plan)
+            self.plan = None
+
+
+class Pipeline:
+    """Both directions of one PFFT.  `build` returns None when the transform does not qualify."""
+    CHUNKS = int(os.environ.get('GFFT_PIPE_CHUNKS', 4))
+    MIN_CHUNK_BYTES = int(os.environ.get('GFFT_PIPE_MIN_CHUNK_BYTES', 8 << 20))
+    MIN_WIDTH = 16
+
+    @classmethod
+    def build(cls, pfft, wires):
+        import torch
+        stages, transfers = pfft.xfftn, pfft.transfer
+        if not transfers or not torch.cuda.is_available():
+            return None
+        dtype = np.dtype(stages[0].forward.input_array.dtype)
+        if dtype.kind != 'c' or len(stages[0].forward.input_array.shape) != 3:
+            return None
+        for x in stages:
+            if len(x.axes) != 1 or x._padded or np.dtype(x.forward.input_array.dtype) != dtype \
+                    or tuple(x.forward.input_array.shape) != tuple(x.forward.output_array.shape):
+                return None
+        nd = 3
+        isz = dtype.itemsize
+        # per transfer: ranks, wire, free axis, chunks
+        plan = []
+        by_ranks = {tuple(c._ranks): w for c, w in zip(pfft.subcomm, wires) if w is not None}
+        for i, t in enumerate(transfers):
+            p = t.comm.Get_size()
+            if p == 1:
+                plan.append(dict(p=1))
+                continue
+            a, b = t.axisA, t.axisB
+            wire = by_ranks.get(tuple(t.comm._ranks))
+            if wire is None or wire.size != p or p & (p - 1) or p > 8:
+                return None
+            if t.subshapeA[a] % p or t.subshapeB[b] % p:
+                return None
+            free = [d for d in range(nd) if d not in (a, b)]
+            f = free[0]
+            nf = t.subshapeA[f]
+            K = 1
+            nbytes = int(np.prod(t.subshapeA, dtype=np.int64)) * isz
+            for k in range(min(cls.CHUNKS, nf), 1, -1):
+                if nf % k == 0 and nf // k >= cls.MIN_WIDTH and nbytes // k >= cls.MIN_CHUNK_BYTES:
+                    K = k
+                    break
+            plan.append(dict(p=p, wire=wire, f=f, K=K, a=a, b=b))
+        if all(e['p'] == 1 for e in plan):
+            return None
+        self = cls()
+        self.pfft = pfft
+        self.dtype, self.isz = dtype, isz
+        self.precision = _lib.precision_of(dtype)
+        self.tplan = plan
+        L = len(stages)
+        # storage between the stages: stage i's planned output array and stage i+1's planned input
+        # array (the staged path's exchange buffers), replaced where they alias something that the
+        # pipelined layout would overwrite
+        self.out_buf = [x.forward.output_array.tensor for x in stages]
+        self.in_buf = [x.forward.input_array.tensor for x in stages]
+        for i in range(L):
+            if i < L - 1 and plan[i]['p'] > 1 and self.out_buf[i].data_ptr() == self.in_buf[i].data_ptr():
+                self.out_buf[i] = torch.empty_like(self.in_buf[i])       # in-place stage: own send buffer
+        # layouts
+        lay_in, lay_out = [], []
+        for i, x in enumerate(stages):
+            shape, ax = tuple(x.forward.input_array.shape), x.axes[0]
+            if i > 0 and plan[i - 1]['p'] > 1:
+                e = plan[i - 1]
+                lay_in.append(Layout(shape, ax, e['p'], e['f'], e['K']))
+            else:
+                lay_in.append(Layout(shape))
+            if i < L - 1 and plan[i]['p'] > 1:
+                e = plan[i]
+                lay_out.append(Layout(shape, ax, e['p'], e['f'], e['K']))
+            else:
+                lay_out.append(Layout(shape))
+        self.fwd = [_Stage(tuple(x.forward.input_array.shape), x.axes[0], lay_in[i], lay_out[i], -1, self.precision)
+                    for i, x in enumerate(stages)]
+        self.bwd = [_Stage(tuple(x.forward.input_array.shape), x.axes[0], lay_out[i], lay_in[i], +1, self.precision)
+                    for i, x in enumerate(stages)]
+        if any(s.plan is None for s in self.fwd + self.bwd):
+            self.destroy()
+            return None
+        self.M = [x.M for x in stages]
+        self.comm_stream = torch.cuda.Stream()
+        self._events = {}
+        return self
+
+    def destroy(self):
+        for s in getattr(self, 'fwd', []) + getattr(self, 'bwd', []):
+            s.destroy()
+
+    # ---------------------------------------------------------------------------------------
+    def _event(self, key):
+        import torch
+        e = self._events.get(key)
+        if e is None:
+            e = self._events[key] = torch.cuda.Event()
+        return e
+
+    def describe(self):
+        return [dict(ranks=e['p'], free_axis=e.get('f'), chunks=e.get('K', 1)) for e in self.tplan]
+
+    def run(self, forward, src=None, dst=None, normalize=None):
+        """One transform.  `src` / `dst`: tensors of the planned input / output layout to read /
+        write instead of the planned arrays."""
+        import torch
+        eng = _lib.engine()
+        L = len(self.fwd)
+        compute = torch.cuda.current_stream()
+        cs = self.comm_stream
+        cs_raw = cs.cuda_stream
+        isz = self.isz
+        if normalize is None:
+            normalize = forward
+        order = list(range(L)) if forward else list(range(L - 1, -1, -1))
+        stages = self.fwd if forward else self.bwd
+        tag = 'f' if forward else 'b'
+        for pos, i in enumerate(order):
+            st = stages[i]
+            # buffers of this stage in this direction
+            if forward:
+                tin = (src if (i == 0 and src is not None) else self.in_buf[i])
+                tout = (dst if (i == L - 1 and dst is not None) else self.out_buf[i])
+                t_next = self.tplan[i] if i < L - 1 else None          # transfer after this stage
+                t_prev = self.tplan[i - 1] if i > 0 else None
+            else:
+                tin = (src if (i == L - 1 and src is not None) else self.out_buf[i])
+                tout = (dst if (i == 0 and dst is not None) else self.in_buf[i])
+                t_next = self.tplan[i - 1] if i > 0 else None
+                t_prev = self.tplan[i] if i < L - 1 else None
+            pin, pout = tin.data_ptr(), tout.data_ptr()
+            scale = self.M[i] if normalize else 1.0
+            arrives = t_prev is not None and t_prev['p'] > 1
+            send_whole = t_next is not None and t_next['p'] > 1 and st.iter_side != 'out'
+            for c in range(st.nchunks):
+                if arrives and st.iter_side == 'in':
+                    compute.wait_event(self._event((tag, 'x', pos - 1, c)))      # chunk c has arrived
+                elif arrives and c == 0:
+                    for cc in range(st.lay_in.K):                                # walks its output: needs it all
+                        compute.wait_event(self._event((tag, 'x', pos - 1, cc)))
+                eng.execute_ptr(st.plan, pin + c * st.step_in * isz, pout + c * st.step_out * isz, scale)
+                if st.iter_side == 'out':
+                    # chunk c of the send buffer is complete: put it on the wire
+                    self._exchange(tag, pos, c, t_next, st.lay_out, pout, forward, i, compute, cs, cs_raw)
+            if send_whole:
+                # this stage filled every chunk of its send buffer (it walked its INPUT chunks):
+                # all chunks go on the wire now, the next stage picks them up one by one
+                for c in range(st.lay_out.K):
+                    self._exchange(tag, pos, c, t_next, st.lay_out, pout, forward, i, compute, cs, cs_raw,
+                                   record=(c == 0))
+        return dst if dst is not None else (self.out_buf[L - 1] if forward else self.in_buf[0])
+
+    def _exchange(self, tag, pos, c, t, lay, send_ptr, forward, i, compute, cs, cs_raw, record=True):
+        """Chunk c of the redistribution after stage position `pos`: wait (on the communication
+        stream) for the compute stream's work so far, all-to-all the chunk, signal its arrival."""
+        if record:
+            ev = self._event((tag, 'k', pos, c))
+            ev.record(compute)
+            cs.wait_event(ev)
+        L = len(self.fwd)
+        j = i + 1 if forward else i - 1                       # the receiving stage
+        recv = (self.in_buf[j] if forward else self.out_buf[j]).data_ptr()
+        isz = self.isz
+        off = c * lay.chunk * isz
+        t['wire'].alltoall_blocks(send_ptr + off, recv + off, lay.block * isz, cs_raw)
+        self._event((tag, 'x', pos, c)).record(cs)

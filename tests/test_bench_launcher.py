@@ -50,8 +50,9 @@ def test_bench_self_launch_four_ranks_measures_routes_and_slab():
                extra_env={'GFFT_RELAY': 'measure', 'GFFT_RELAY_MIN_BYTES': '0'})
     _check_line(out, 4, 32)
     assert out['config']['grid'] == [2, 2, 1]
-    rm = out['route_measurement']
-    assert rm['round_trip_rel_err'] <= 1e-10
+    rm = [a for a in out['alternatives'] if a['plan'] == 'measured routes'][0]
+    assert any(a['plan'] == 'pipelined' for a in out['alternatives'])
+    assert rm["round_trip_rel_err"] <= 1e-10
     assert all(len(e['measured_s']) == 2 and e['route'] in ('direct', 'relay') for e in rm['exchange'])
     assert out['slab_grid']['grid'] == [4, 1, 1] and out['slab_grid']['gflops'] > 0
 

@@ -1,0 +1,136 @@
+"""The chunked, stream-overlapped redistribution (mpi4py-fft_amd/pipeline.py) on libgfft's own
+communicators (C ABI gfft_comm_* / gfft_sendrecv), on ONE GPU: thread-ranks stand in for processes
+and tests/fake_rccl stands in for RCCL, which refuses two ranks on a device.  Everything above the
+dozen ncclXxx entry points is the product path: communicator split, message lists, streams and
+events, guru plans addressing chunk-major exchange buffers."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests import cases, thread_comm
+from oracle import pfft_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope='module', autouse=True)
+def fake_rccl():
+    src = os.path.join(HERE, 'fake_rccl', 'fake_rccl.cpp')
+    so = os.path.join(HERE, 'fake_rccl', 'libfake_rccl.so')
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '-O2', '-std=c++17', '-fPIC', '-shared', '-x', 'hip',
+                               '--offload-arch=gfx950', src, '-o', so])
+    from mpi4py_fft_amd import _lib
+    _lib.check_wire(_lib.lib().gfft_rccl_load(so.encode()))
+    yield
+    _lib.lib().gfft_rccl_load(None)          # back to the real library for whoever comes next
+
+
+def test_native_alltoallv_and_split_through_the_c_abi():
+    """gfft_comm_create / gfft_comm_split / gfft_alltoallv with uneven counts on 4 thread-ranks."""
+    import torch
+    from mpi4py_fft_amd import _lib, comm
+
+    def body(c):
+        L = _lib.lib()
+        w = comm.NativeWire.create(c)
+        r, P = c.Get_rank(), c.Get_size()
+        assert (w.rank, w.size) == (r, P)
+        # rank r sends (r + j + 1) doubles to rank j, value 100 r + j
+        scounts = [r + j + 1 for j in range(P)]
+        rcounts = [j + r + 1 for j in range(P)]
+        send = torch.cat([torch.full((n,), 100.0 * r + j, dtype=torch.float64) for j, n in enumerate(scounts)]).cuda()
+        recv = torch.zeros(sum(rcounts), dtype=torch.float64, device='cuda')
+        i64 = lambda v: (ctypes.c_int64 * len(v))(*v)
+        sd = [sum(scounts[:j]) for j in range(P)]
+        rd = [sum(rcounts[:j]) for j in range(P)]
+        _lib.check_wire(L.gfft_alltoallv(w.handle, send.data_ptr(), i64(scounts), i64(sd), recv.data_ptr(),
+                                         i64(rcounts), i64(rd), 8, _lib.current_stream()))
+        torch.cuda.synchronize()
+        want = torch.cat([torch.full((n,), 100.0 * j + r, dtype=torch.float64) for j, n in enumerate(rcounts)])
+        assert torch.equal(recv.cpu(), want)
+        # split into rows of a 2 x 2 grid: color = row, key = column
+        sub = w.split(r // 2, r % 2, (2 * (r // 2), 2 * (r // 2) + 1))
+        assert (sub.rank, sub.size) == (r % 2, 2)
+        a = torch.full((6,), float(r), device='cuda')
+        b = torch.empty(6, device='cuda')
+        sub.alltoall_blocks(a.data_ptr(), b.data_ptr(), 12, _lib.current_stream().value or 0)
+        torch.cuda.synchronize()
+        row = [2 * (r // 2), 2 * (r // 2) + 1]
+        assert b.cpu().tolist() == [float(row[0])] * 3 + [float(row[1])] * 3
+        return True
+    assert all(thread_comm.run(4, body))
+
+
+@pytest.mark.parametrize('P,shape,kw', [
+    (2, (64, 64, 64), {}),
+    (4, (64, 64, 64), {}),
+    (8, (64, 64, 64), {}),
+    (8, (128, 64, 256), {}),
+    (4, (64, 128, 64), dict(grid=(-1,))),          # slab: one redistribution over all ranks
+    (8, (64, 64, 128), dict(grid=(-1,))),
+    (4, (64, 64, 64), dict(axes=(1, 2, 0))),
+])
+@pytest.mark.parametrize('dt', ['D', 'F'])
+def test_pipelined_transform_is_bit_identical_to_the_staged_one(P, shape, kw, dt, monkeypatch):
+    from mpi4py_fft_amd import PFFT, newDistArray, pipeline
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_CHUNK_BYTES', 0)
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_WIDTH', 4)
+    G = O.rng_array(shape, dt, 11)
+
+    def body(comm):
+        k = {a: (list(b) if isinstance(b, list) else b) for a, b in kw.items()}
+        staged = PFFT(comm, shape, dtype=dt, wire='torch', exchange='direct', **k)
+        piped = PFFT(comm, shape, dtype=dt, wire='native', exchange='direct', **k)
+        assert staged.pipeline is None and piped.pipeline is not None
+        info = piped.pipeline.describe()
+        u = newDistArray(staged, False)
+        u[...] = G[staged.local_slice(False)]
+        a = np.asarray(staged.forward(u)).copy()
+        b = np.asarray(piped.forward(u)).copy()
+        out = newDistArray(piped, True)
+        piped.forward(u, out)                          # caller's arrays read / written directly
+        c = np.asarray(out).copy()
+        ab = np.asarray(staged.backward()).copy()
+        bb = np.asarray(piped.backward()).copy()
+        bn = np.asarray(piped.backward(out, normalize=True)).copy()
+        keep = np.asarray(u).copy()
+        staged.destroy()
+        piped.destroy()
+        return a, b, c, ab, bb, bn, keep, info
+    res = cases.run_ranks(P, body)
+    ref = O.OPFFT(P, shape, dtype=dt, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+    want = ref.forward(ref.scatter(G))
+    for r, (a, b, c, ab, bb, bn, keep, info) in enumerate(res):
+        assert any(e['chunks'] > 1 for e in info), info
+        assert np.array_equal(a, b) and np.array_equal(a, c), (P, shape, kw, r)
+        assert np.array_equal(ab, bb)
+        tol = cases.tol_for(dt)
+        assert np.abs(a - want[r]).max() <= tol * np.abs(want[r]).max()
+        assert np.allclose(bn * G.size, bb, rtol=1e-5 if dt == 'F' else 1e-12, atol=0)
+    # the golden fixture of the reference itself through the pipelined path
+    if P == 8 and shape == (64, 64, 64) and dt == 'D':
+        monkeypatch.setenv('GFFT_WIRE', 'native')
+        cases.check_pfft_golden('c2c_16x16x16_p8')
+
+
+def test_transforms_that_do_not_qualify_keep_the_staged_path(monkeypatch):
+    from mpi4py_fft_amd import PFFT
+
+    def body(comm):
+        out = []
+        for shape, dt, kw in (((64, 64, 64), 'd', {}), ((48, 64, 60), 'D', {}),
+                              ((64, 64, 64), 'D', dict(padding=[1.5, 1.5, 1.5])), ((32, 32), 'D', {})):
+            f = PFFT(comm, shape, dtype=dt, wire='native', **kw)
+            out.append(f.pipeline is None)
+            f.destroy()
+        return out
+    monkeypatch.setenv('GFFT_WIRE', 'native')
+    assert thread_comm.run(4, body)[0] == [True, True, True, True]
+    cases.check_pfft_vs_oracle(4, (33, 20, 18), 'd')
+    cases.check_pfft_vs_oracle(4, (48, 40, 64), 'D')

@@ -14,8 +14,11 @@ from mpi4py_fft_amd import comm as C
 
 
 class _World:
+    _serial = itertools.count()
+
     def __init__(self, size):
         self.size = size
+        self.serial = next(_World._serial)
         self.lock = threading.Lock()
         self.groups = {}
 
@@ -40,6 +43,11 @@ class ThreadComm(C.Comm):
 
     def Get_rank(self):
         return self._members.index(self._me)
+
+    def wire_key(self):
+        return ('thread', self._world.serial, self._members, self._me)
+
+    backend = 'thread'
 
     def __eq__(self, other):
         if isinstance(other, ThreadComm):
