@@ -19,9 +19,17 @@
  * `int`, fftw_planxfftn.c:11-22; 1024^3 is its edge).  Arrays are C-contiguous (row-major), the
  * only layout the reference plans for (fftw_planxfftn.c:25-30).  Caller is single-threaded per
  * plan.  No host fallback exists: without a HIP device every compute entry point returns
- * GFFT_ERR_NO_DEVICE.  A plan allocates its scratch at its first gfft_execute; after that,
- * gfft_execute and the pointwise entries only enqueue kernels (no allocation, no synchronisation),
- * so a stream running them can be captured into a HIP graph.
+ * GFFT_ERR_NO_DEVICE.
+ *
+ * Scratch and re-entrancy: plans that need a workspace (3-D all-axes plans, multi-axis c2r, four-step
+ * and Bluestein lengths) carve it from ONE buffer per (calling thread, stream), shared by every
+ * plan that thread executes on that stream and grown -- with a synchronisation of that stream --
+ * when a larger request arrives (gfft_scratch_release frees them).  Consequences: (1) a thread may
+ * run any sequence of plans on a stream; (2) two executions issued by one thread that may overlap
+ * in time must be on different streams; (3) the first
+ * gfft_execute of the largest plan on a stream allocates, so run each plan once on the stream
+ * before capturing it into a HIP graph -- after that gfft_execute and the pointwise entries only
+ * enqueue kernels (no allocation, no synchronisation).
  */
 #ifndef GFFT_H
 #define GFFT_H
@@ -75,10 +83,13 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
  * input and output are real arrays of shape `sizes`; in-place execution is allowed. */
 int gfft_plan_create_r2r(gfft_plan *plan, int ndims, const int64_t *sizes, int naxes, const int *axes,
                          const int *kinds, int precision);
-/* out = scale * DFT(in).  d_in == d_out is allowed for C2C.  C2C out-of-place preserves the
- * input; C2R with naxes > 1 overwrites it (as FFTW does).  */
+/* out = scale * DFT(in).  d_in == d_out is allowed for C2C and real-to-real plans.  Every
+ * out-of-place execution PRESERVES its input -- part of the contract: multi-axis C2R (where FFTW
+ * destroys the input) routes its complex passes through the workspace, and the Python host relies
+ * on it when it reads a caller's array in place (Transform.__call__). */
 int gfft_execute(gfft_plan plan, const void *d_in, void *d_out, double scale, void *stream);
 int gfft_plan_destroy(gfft_plan plan);
+int gfft_scratch_release(void);           /* frees the shared per-stream workspaces */
 /* Fuse FFTBase._truncation_forward / _padding_backward (libfft.py:263-311) into a single-axis plan:
  * afterwards gfft_execute writes (forward kinds) / reads (backward kinds) the TRUNCATED array,
  * n_keep entries along the axis (N on a complex axis, N/2+1 on the real half-axis), with the

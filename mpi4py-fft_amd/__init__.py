@@ -8,7 +8,7 @@ __version__ = '0.1.0'
 
 from . import _lib
 from . import comm
-from .array import DeviceArray, asdevice, empty, zeros
+from .array import DeviceArray, asdevice, empty, zeros, host_empty
 from .distarray import DistArray, newDistArray, Function
 from .mpifft import PFFT
 from .pencil import Pencil, Subcomm, Transfer

@@ -47,6 +47,7 @@ def _declare(lib):
         'gfft_plan_create_r2r': (c.c_int, [c.POINTER(vp), c.c_int, i64p, c.c_int, ip, ip, c.c_int]),
         'gfft_execute': (c.c_int, [vp, vp, vp, c.c_double, vp]),
         'gfft_plan_destroy': (c.c_int, [vp]),
+        'gfft_scratch_release': (c.c_int, []),
         'gfft_plan_set_truncation': (c.c_int, [vp, c.c_int64]),
         'gfft_plan_set_split': (c.c_int, [vp, c.c_int, c.c_int]),
         'gfft_plan_create_guru': (c.c_int, [c.POINTER(vp), c.c_int, c.c_int, c.POINTER(IoDim), c.c_int, c.POINTER(IoDim),

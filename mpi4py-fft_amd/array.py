@@ -17,6 +17,92 @@ _NP2T = {'f': torch.float32, 'd': torch.float64, 'F': torch.complex64, 'D': torc
          'i': torch.int32, 'l': torch.int64, 'b': torch.int8, 'B': torch.uint8}
 
 
+# ---- host <-> device staging ----------------------------------------------------------------------
+# The reference hands FFTW page-aligned host arrays (fftw/utilities.pyx:54-104, `aligned`); the
+# counterpart on this side of PCIe is page-LOCKED host memory.  `u[...] = host_array` and
+# `np.asarray(u)` of large arrays go through two pinned bounce buffers, filled by a multi-threaded
+# host copy while the previous chunk is on the wire (a pageable `tensor.to(device)` is staged by the
+# runtime through small internal buffers, one thread, no overlap); `host_empty` gives the caller a
+# numpy array that IS pinned, which then moves at the PCIe rate without any staging.
+PIN_CHUNK_BYTES = 128 << 20
+PIN_MIN_BYTES = 16 << 20
+_pinned = {}
+
+
+def _bounce(device):
+    key = str(device)
+    b = _pinned.get(key)
+    if b is None:
+        b = _pinned[key] = dict(buf=[torch.empty(PIN_CHUNK_BYTES, dtype=torch.uint8, pin_memory=True) for _ in range(2)],
+                                ev=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False])
+    return b
+
+
+def _bytes_view(t):
+    return (torch.view_as_real(t) if t.is_complex() else t).reshape(-1).view(torch.uint8)
+
+
+def h2d(dst, host):
+    """dst (contiguous device tensor) <- host (C-contiguous numpy array of the same dtype / size)."""
+    src = torch.from_numpy(host.reshape(-1).view(np.uint8))
+    n = src.numel()
+    if n < PIN_MIN_BYTES or not dst.is_cuda or src.is_pinned():
+        _bytes_view(dst).copy_(src)
+        return
+    b = _bounce(dst.device)
+    d = _bytes_view(dst)
+    for k, off in enumerate(range(0, n, PIN_CHUNK_BYTES)):
+        m = min(PIN_CHUNK_BYTES, n - off)
+        i = k & 1
+        if b['used'][i]:
+            b['ev'][i].synchronize()                 # the chunk sent two rounds ago has left the buffer
+        b['buf'][i][:m].copy_(src[off:off + m])      # host copy (torch splits it over its threads)
+        d[off:off + m].copy_(b['buf'][i][:m], non_blocking=True)
+        b['ev'][i].record()
+        b['used'][i] = True
+
+
+def d2h(src):
+    """numpy copy of a contiguous device tensor (raw bytes; the caller views them)."""
+    s = _bytes_view(src)
+    n = s.numel()
+    out = np.empty(n, dtype=np.uint8)
+    if n < PIN_MIN_BYTES or not src.is_cuda:
+        torch.from_numpy(out).copy_(s)
+        return out
+    b = _bounce(src.device)
+    o = torch.from_numpy(out)
+    pending = None
+    for k, off in enumerate(range(0, n, PIN_CHUNK_BYTES)):
+        m = min(PIN_CHUNK_BYTES, n - off)
+        i = k & 1
+        if b['used'][i]:
+            b['ev'][i].synchronize()
+        b['buf'][i][:m].copy_(s[off:off + m], non_blocking=True)
+        b['ev'][i].record()
+        b['used'][i] = True
+        if pending is not None:                      # drain the previous chunk while this one flies
+            j, poff, pm = pending
+            b['ev'][j].synchronize()
+            o[poff:poff + pm].copy_(b['buf'][j][:pm])
+        pending = (i, off, m)
+    if pending is not None:
+        j, poff, pm = pending
+        b['ev'][j].synchronize()
+        o[poff:poff + pm].copy_(b['buf'][j][:pm])
+    return out
+
+
+def host_empty(shape, dtype=float):
+    """A numpy array in page-locked host memory: assigning it to a device array, or copying a device
+    array into it (``u.get(out=h)``), runs at the PCIe rate with no staging copy."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    pin = torch.cuda.is_available()
+    raw = torch.empty(max(n, 1), dtype=torch.uint8, pin_memory=pin)
+    return raw.numpy()[:n].view(dtype).reshape(shape)
+
+
 def default_device():
     if torch.cuda.is_available():
         return torch.device('cuda', torch.cuda.current_device())
@@ -77,10 +163,21 @@ class DeviceArray:
         return '%s(shape=%s, dtype=%s, device=%s)' % (type(self).__name__, self._shape, self._dtype, self._t.device)
 
     # ---- host interop
-    def get(self):
-        """Copy to a new host numpy array."""
+    def get(self, out=None):
+        """Copy to a host numpy array (a new one, or `out` -- e.g. from `host_empty`)."""
         t = self._t.detach()
-        return t.cpu().numpy() if t.is_cuda else t.numpy().copy()
+        if not t.is_cuda:
+            a = t.numpy().copy()
+        elif out is not None:
+            assert out.shape == self._shape and out.dtype == self._dtype and out.flags.c_contiguous
+            torch.from_numpy(out.reshape(-1).view(np.uint8)).copy_(_bytes_view(t.contiguous()))
+            return out
+        else:
+            a = d2h(t.contiguous()).view(self._dtype).reshape(self._shape)
+        if out is not None:
+            out[...] = a
+            return out
+        return a
 
     def __array__(self, dtype=None, copy=None):
         a = self.get()              # always fresh memory, so `copy=True` is honoured
@@ -98,15 +195,30 @@ class DeviceArray:
             a = a.astype(self._dtype)
         return torch.from_numpy(np.ascontiguousarray(a)).to(self._t.device, non_blocking=False)
 
+    def _load_host(self, value):
+        """Whole-array assignment from a host array through the pinned staging path; False if
+        `value` is not a host array of this shape."""
+        if isinstance(value, (DeviceArray, torch.Tensor)) or np.isscalar(value) or not self._t.is_cuda:
+            return False
+        a = np.asarray(value)
+        if a.shape != self._shape or not self._t.is_contiguous():
+            return False
+        a = np.ascontiguousarray(a if a.dtype == self._dtype else a.astype(self._dtype))
+        h2d(self._t, a)
+        return True
+
     def set(self, value):
         self[...] = value
         return self
 
     def __setitem__(self, key, value):
+        whole = key is Ellipsis or (isinstance(key, slice) and key == slice(None))
+        if whole and self._load_host(value):
+            return
         v = self._as_tensor(value)
         if isinstance(key, DeviceArray):
             key = key._t
-        if key is Ellipsis or (isinstance(key, slice) and key == slice(None)):
+        if whole:
             if isinstance(v, torch.Tensor):
                 self._t.copy_(v if v.dtype == self._t.dtype else v.to(self._t.dtype))
             else:

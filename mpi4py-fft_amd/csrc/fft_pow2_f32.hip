@@ -26,6 +26,16 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 2048: return P32(2048, 16, 1, false, false, 1, 16, 16, 8);
       case 4096: return P32(4096, 16, 1, false, false, 1, 16, 16, 16);
     }
+  } else if (d.tw_hi && d.out_es == 1 && d.mode == MODE_C2C && !d.tr_dir && d.n >= 512 && variant != 9) {
+    // first pass of a four-step transform: four-step twiddle, then a transposing store through LDS so
+    // that each output line is written in whole rows (as in fft_pow2_f64.hip; measured on 128 x 2^20
+    // c64 under rocprofv3: this pass took 934 us with the plain store, the second pass 501 us)
+    switch (d.n) {
+      case 512: return P32F(512, 16, 32, true, true, 1, 32, 16, 8, 4);
+      case 1024: return P32F(1024, 16, 16, true, true, 1, 32, 16, 16, 4);
+      case 2048: return P32F(2048, 16, 8, true, true, 4, 32, 16, 16, 8);
+      case 4096: return P32F(4096, 16, 4, true, true, 4, 32, 16, 16, 16);
+    }
   } else if (d.mode == MODE_C2C && d.tr_dir && !d.tw_hi && (d.n == 512 || (variant == 7 && d.tr_dir == 2 && d.n >= 1024))) {
     // complex strided passes with fused truncation (store side) / zero padding (load side) on the
     // 256-byte tiles of the plain passes below.  n = 512 compiles clean (100 / 82 VGPRs); from

@@ -21,6 +21,7 @@
 #include <tuple>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace gfft;
@@ -216,6 +217,62 @@ constexpr int GENERIC_MAX_PRIME = 61;
 
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// ---- scratch shared by all plans ---------------------------------------------------------------
+// One buffer per (host thread, stream), grown to the largest request seen there: the passes of one
+// gfft_execute are enqueued back to back by one thread and a stream runs them in order, so every
+// plan that thread executes on that stream can share the buffer (the forward and the backward plan
+// of a 1024^3 PFFT each need a 16 GiB padded workspace; owning one each doubled that).  Other
+// threads -- whose launches could interleave with this one's on the same stream -- and other
+// streams get their own.  Growing synchronises the stream once (earlier launches may still be
+// using the old buffer).
+struct ScratchPool {
+  std::mutex m;
+  std::map<std::pair<std::thread::id, hipStream_t>, std::pair<void *, size_t>> bufs;
+  int get(hipStream_t s, size_t bytes, void **out) {
+    std::lock_guard<std::mutex> lock(m);
+    const auto me = std::this_thread::get_id();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone) {
+      // No allocation inside a capture: the graph uses the buffer this thread's warm-up execution
+      // grew (on whatever stream that ran), so replays must not overlap other executions of this
+      // thread -- the stream a graph is replayed on orders them.
+      for (auto &kv : bufs)
+        if (kv.first.first == me && kv.second.second >= bytes) { *out = kv.second.first; return GFFT_OK; }
+      return fail(GFFT_ERR_INVALID, "stream capture: execute the plan once before capturing it (its workspace is allocated at the first execution)");
+    }
+    auto &b = bufs[{me, s}];
+    if (bytes > b.second) {
+      if (b.first) {
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipFree(b.first));
+        b = {nullptr, 0};
+      }
+      void *p = nullptr;
+      hipError_t e = hipMalloc(&p, bytes);
+      if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(GFFT_ERR_NOMEM, "scratch allocation failed"); }
+      HIP_TRY(e);
+      b = {p, bytes};
+    }
+    *out = b.first;
+    return GFFT_OK;
+  }
+  int release() {
+    std::lock_guard<std::mutex> lock(m);
+    for (auto &kv : bufs)
+      if (kv.second.first) {
+        (void)hipStreamSynchronize(kv.first.second);
+        (void)hipFree(kv.second.first);
+      }
+    bufs.clear();
+    return GFFT_OK;
+  }
+};
+ScratchPool &scratch_pool() {
+  static ScratchPool p;
+  return p;
+}
+
 }  // namespace
 
 struct gfft_plan_s {
@@ -224,8 +281,6 @@ struct gfft_plan_s {
   std::vector<int> axes;
   std::vector<Pass> passes;
   size_t region_bytes[BUF_COUNT] = {0, 0, 0, 0, 0};   // WS / FS / AUX sizes
-  void *scratch = nullptr;
-  size_t scratch_bytes = 0;
   double flops = 0, bytes = 0;
   int variant_rows = 0, variant_cols = 0, xcd_swizzle = 0;
   bool fused3 = false;
@@ -879,13 +934,16 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   if (p.kind == PK_MULB) return launch_mulb(p.pt, pl->precision, out, s);
   if (p.kind == PK_EXTRACT) return launch_extract(p.pt, pl->precision, in, out, scale * p.extra_scale, s);
   PassDesc d = d0;
-  // auto: only where a strided pass writes rows that do not start on 128-byte lines (odd-width
-  // half spectra): neighbouring chunks then meet in one L2 and their partial lines merge
+  // auto: only where a strided pass reads or writes rows that do not start on 128-byte lines
+  // (odd-width half spectra): neighbouring chunks then meet in one L2 and their partial lines merge
+  // (FETCH_SIZE of the backward first pass of a 1024^3 r2c, which READS the 513-wide array and was
+  // left unswizzled at first: 1.44 x the algorithmic bytes, profiles/r02_real_*)
   // (measured 1024^3 r2c: 5.4 -> 5.0 ms fp64, 3.6 -> 2.6 ms fp32; neutral-to-slightly-negative on
   // aligned arrays, so it stays off there)
   const int64_t esz_out = ((d.mode == MODE_C2R || d.mode == MODE_R2R) ? 1 : 2) * (int64_t)pl->precision;
+  const int64_t esz_in = ((d.mode == MODE_R2C || d.mode == MODE_R2R) ? 1 : 2) * (int64_t)pl->precision;
   d.swizzle = pl->xcd_swizzle >= 0 ? pl->xcd_swizzle
-                                   : (p.cols && ((d.out_es * esz_out) % 128 != 0) ? 1 : 0);
+                                   : (p.cols && (((d.out_es * esz_out) % 128 != 0) || ((d.in_es * esz_in) % 128 != 0)) ? 1 : 0);
   if (d.mode == MODE_R2C_H || d.mode == MODE_C2R_H)
     return pl->precision == 8 ? launch_real_half_f64(d, pl->variant_rows, in, out, s)
                               : launch_real_half_f32(d, pl->variant_rows, in, out, s);
@@ -1102,24 +1160,20 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
   if ((pl->kind == GFFT_R2C || pl->kind == GFFT_C2R) && d_in == d_out)
     return fail(GFFT_ERR_INVALID, "in-place real transforms are not supported");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  // scratch regions (one allocation, made on first use)
+  // scratch regions: carved from the stream's shared buffer (scratch_pool)
   size_t off[BUF_COUNT] = {0, 0, 0, 0, 0}, total = 0;
   for (int b = BUF_WS; b < BUF_COUNT; ++b) {
     off[b] = total;
     total += align256(pl->region_bytes[b]);
   }
-  if (total > pl->scratch_bytes) {
-    if (pl->scratch) HIP_TRY(hipFree(pl->scratch));
-    pl->scratch = nullptr;
-    pl->scratch_bytes = 0;
-    hipError_t e = hipMalloc(&pl->scratch, total);
-    if (e == hipErrorOutOfMemory) return fail(GFFT_ERR_NOMEM, "scratch allocation failed");
-    HIP_TRY(e);
-    pl->scratch_bytes = total;
+  void *scratch = nullptr;
+  if (total) {
+    int rc = scratch_pool().get(s, total, &scratch);
+    if (rc) return rc;
   }
   void *bufs[BUF_COUNT] = {const_cast<void *>(d_in), d_out, nullptr, nullptr, nullptr};
   for (int b = BUF_WS; b < BUF_COUNT; ++b)
-    if (pl->region_bytes[b]) bufs[b] = static_cast<char *>(pl->scratch) + off[b];
+    if (pl->region_bytes[b]) bufs[b] = static_cast<char *>(scratch) + off[b];
 
   std::vector<hipEvent_t> *ev = nullptr;
   auto mark = [&]() -> hipError_t {
@@ -1336,9 +1390,11 @@ int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_i
   return GFFT_OK;
 }
 
+/* free the shared scratch buffers (they are otherwise kept for the life of the process) */
+int gfft_scratch_release(void) { return scratch_pool().release(); }
+
 int gfft_plan_destroy(gfft_plan pl) {
   if (!pl) return GFFT_OK;
-  if (pl->scratch) (void)hipFree(pl->scratch);
   delete pl;
   return GFFT_OK;
 }

@@ -87,7 +87,8 @@ class FFT(FFTBase):
     Parameters as the reference (libfft.py:376-377).  ``backend`` is accepted for signature
     compatibility: 'fftw' (the reference's default name) and 'gfft' both select the one engine
     this package has; any other name raises.  ``transforms`` may map axes to
-    ``(fftw.fftn, fftw.ifftn)`` / ``(fftw.rfftn, fftw.irfftn)``; real-to-real planners raise.
+    ``(fftw.fftn, fftw.ifftn)`` / ``(fftw.rfftn, fftw.irfftn)`` or to real-to-real planner pairs
+    (``fftw.dctn / idctn / dstn / idstn``, usually through ``functools.partial(..., type=k)``).
     FFTW-only keywords (planner_effort, threads, overwrite_input) are accepted and ignored.
 
     ``U`` / ``V``: optionally reuse existing device arrays as the work arrays (PFFT chains the

@@ -388,3 +388,30 @@ def test_split_layout_refusals():
     assert p4.set_split(1, 2) is False                   # four-step
     for q in (r, p2, p3, p4):
         q.destroy()
+
+
+def test_pinned_staging_round_trip(monkeypatch):
+    """u[...] = host / np.asarray(u) through the two pinned bounce buffers (several chunks, odd
+    tail), and through a caller-owned pinned array (host_empty): bytes arrive unchanged."""
+    from mpi4py_fft_amd import array, empty, host_empty
+    monkeypatch.setattr(array, 'PIN_CHUNK_BYTES', 1 << 20)
+    monkeypatch.setattr(array, 'PIN_MIN_BYTES', 1 << 16)
+    array._pinned.clear()
+    rng = np.random.default_rng(3)
+    for shape, dt in (((3, 257, 1031), 'D'), ((5, 333, 129), 'f'), ((64, 64), 'd')):
+        h = rng.standard_normal(shape).astype(dt)
+        if dt == 'D':
+            h = h + 1j * rng.standard_normal(shape)
+        u = empty(shape, dt)
+        u[...] = h
+        assert np.array_equal(np.asarray(u), h)
+        assert np.array_equal(u.tensor.cpu().numpy(), h)
+        p = host_empty(shape, dt)
+        p[...] = h
+        v = empty(shape, dt)
+        v[...] = p
+        q = host_empty(shape, dt)
+        assert v.get(out=q) is q and np.array_equal(q, h)
+        u[...] = h.astype('F' if dt == 'D' else 'd')          # dtype conversion on the way in
+        assert np.allclose(np.asarray(u), h, rtol=1e-6)
+    array._pinned.clear()
