@@ -55,7 +55,17 @@ class Transform:
     def __call__(self, input_array=None, output_array=None, **kw):
         """Compute the transform.  Without arguments it works on the planned arrays and returns
         the planned output array (aliasing is part of the contract, mpifft.py:75-79).
-        ``normalize=True/False`` overrides the default (forward normalised, backward not)."""
+        ``normalize=True/False`` overrides the default (forward normalised, backward not).
+
+        Difference from the reference: a device array of the planned shape and dtype passed as
+        ``input_array`` is READ IN PLACE, not copied into the planned input array
+        (mpifft.py:65-66 copies); ``self.input_array`` therefore keeps its previous contents, and
+        a later argument-less call transforms those, not the array passed here.  Host (numpy)
+        arrays are copied in as in the reference.  Likewise a device ``output_array`` of the
+        planned layout is written directly and the planned output array is left untouched.  On
+        several ranks the stage arrays between redistributions (``xfftn[i].forward.output_array``)
+        hold exchange-buffer layouts, not natural ones (``Transfer.packedA / packedB``,
+        ``PFFT.pipeline``)."""
         src = dst = None
         if input_array is not None:
             # The reference copies the caller's array into the planned input array
