@@ -490,7 +490,8 @@ def main():
         # for serial plans).  (2) the chunked redistribution overlapped with the serial transforms
         # on libgfft's own RCCL communicators (pipeline.py).
         variants = [] if args.no_tune else [('measured routes', dict(wire='torch')),
-                                           ('pipelined', dict(wire='auto', exchange='direct'))]
+                                           ('pipelined', dict(wire='auto', exchange='direct')),
+                                           ('pipelined routed', dict(wire='auto', exchange='relay'))]
         for label, kw in variants:
             state['phase'] = label
             try:
@@ -503,13 +504,15 @@ def main():
             info = {'plan': label}
             if tuned.pipeline is not None:
                 info['pipeline'] = tuned.pipeline.describe()
-            elif label == 'pipelined':
+            elif label.startswith('pipelined'):
                 info['skipped'] = 'transform does not qualify for the pipelined path'
             tuned.forward.input_array.tensor.copy_(u0)
             err2 = round_trip_error(tuned)
             routes = [t.exchange for t in tuned.transfer if t.comm.Get_size() > 1]
             info.update({'exchange': exchange_report(tuned), 'round_trip_rel_err': err2})
             differs = tuned.pipeline is not None or any(r != 'direct' for r in routes)
+            if label == 'pipelined routed' and not any(e['route'] == 'relay' for e in info.get('pipeline', [])):
+                differs = False           # nothing to route on this grid: same plan as 'pipelined'
             if differs and err2 <= 1e-10:
                 def tuned_step():
                     tuned.forward()

@@ -233,7 +233,7 @@ class PFFT:
                 t.plan_relay(exchange)
         self.pipeline = None
         if not local and padding is False and transforms is None:
-            self.pipeline = self._plan_pipeline(wire)
+            self.pipeline = self._plan_pipeline(wire, exchange)
 
         self.forward = Transform(
             [o.forward for o in self.xfftn],
@@ -244,7 +244,7 @@ class PFFT:
             [o.backward for o in self.transfer[::-1]],
             self.pencil[::-1], fused_bck, None if self.pipeline is None else (self.pipeline, False))
 
-    def _plan_pipeline(self, wire):
+    def _plan_pipeline(self, wire, exchange=None):
         """The chunked, stream-overlapped form of this transform on libgfft's own RCCL communicators
         (pipeline.py), or None: `wire` = 'native' asks for it, 'torch' keeps the staged path on
         torch.distributed's collectives, None reads GFFT_WIRE (default 'auto': native when the
@@ -263,7 +263,7 @@ class PFFT:
             if mode == 'native':
                 raise
             return None
-        return pipeline.Pipeline.build(self, wires)
+        return pipeline.Pipeline.build(self, wires, exchange)
 
     # ---- planning steps (what mpifft.py:202-347 decides, one decision per helper) ---------------
     @staticmethod

@@ -120,7 +120,7 @@ class Pipeline:
     MIN_WIDTH = 16
 
     @classmethod
-    def build(cls, pfft, wires):
+    def build(cls, pfft, wires, exchange=None):
         import torch
         stages, transfers = pfft.xfftn, pfft.transfer
         if not transfers or not torch.cuda.is_available():
@@ -157,7 +157,7 @@ class Pipeline:
                 if nf % k == 0 and nf // k >= cls.MIN_WIDTH and nbytes // k >= cls.MIN_CHUNK_BYTES:
                     K = k
                     break
-            plan.append(dict(p=p, wire=wire, f=f, K=K, a=a, b=b))
+            plan.append(dict(p=p, wire=wire, f=f, K=K, a=a, b=b, comm=t.comm))
         if all(e['p'] == 1 for e in plan):
             return None
         self = cls()
@@ -198,7 +198,45 @@ class Pipeline:
         self.M = [x.M for x in stages]
         self.comm_stream = torch.cuda.Stream()
         self._events = {}
+        if str(exchange).lower() in ('relay', '1', 'on'):
+            self._plan_relays(pfft, lay_out)
         return self
+
+    def _plan_relays(self, pfft, lay_out):
+        """Routed exchanges (relay.py) on the native wire: a redistribution inside a small
+        sub-communicator is carried over ALL links of the grid in two rounds, and round 2 of chunk
+        k shares one grouped batch with round 1 of chunk k+1.  The grid is regular, so every rank
+        derives every rank's message lists from the grid shape alone (no communication)."""
+        import torch
+        from . import relay as _relay
+        from . import comm as _comm
+        dims = [c.Get_size() for c in pfft.subcomm]
+        parent = next((c.relay_parent for c in pfft.subcomm if getattr(c, 'relay_parent', None) is not None), None)
+        if parent is None:
+            return
+        W = parent.Get_size()
+        me = parent.Get_rank()
+        pwire = None
+        scalar = self.isz // 2
+        for i, e in enumerate(self.tplan):
+            if e['p'] == 1 or _relay.policy(e['p'], W, 'nccl', 'auto') == 'off':
+                continue
+            g = next(k for k, c in enumerate(pfft.subcomm) if c.Get_size() > 1 and tuple(c._ranks) == tuple(e['comm']._ranks))
+            if pwire is None:
+                pwire = _comm.NativeWire.create(parent)
+            per_peer = lay_out[i].block * 2                      # real scalars per (chunk, peer) message
+            meta = []
+            for a in range(W):
+                coords = list(np.unravel_index(a, dims))
+                members = []
+                for v in range(dims[g]):
+                    coords[g] = v
+                    members.append(int(np.ravel_multi_index(coords, dims)))
+                meta.append((tuple(members), [per_peer] * dims[g]))
+            sched = _relay.Schedule(meta, me)
+            nbytes = max(1, sched.relay_size) * scalar
+            e['relay'] = dict(wire=pwire, sched=sched, scalar=scalar,
+                              buf=torch.empty(2 * nbytes, dtype=torch.uint8, device='cuda'), bytes=nbytes)
 
     def destroy(self):
         for s in getattr(self, 'fwd', []) + getattr(self, 'bwd', []):
@@ -213,7 +251,8 @@ class Pipeline:
         return e
 
     def describe(self):
-        return [dict(ranks=e['p'], free_axis=e.get('f'), chunks=e.get('K', 1)) for e in self.tplan]
+        return [dict(ranks=e['p'], free_axis=e.get('f'), chunks=e.get('K', 1),
+                     route='relay' if e.get('relay') else 'direct') for e in self.tplan]
 
     def run(self, forward, src=None, dst=None, normalize=None):
         """One transform.  `src` / `dst`: tensors of the planned input / output layout to read /
@@ -272,10 +311,37 @@ class Pipeline:
             ev = self._event((tag, 'k', pos, c))
             ev.record(compute)
             cs.wait_event(ev)
-        L = len(self.fwd)
         j = i + 1 if forward else i - 1                       # the receiving stage
         recv = (self.in_buf[j] if forward else self.out_buf[j]).data_ptr()
         isz = self.isz
         off = c * lay.chunk * isz
-        t['wire'].alltoall_blocks(send_ptr + off, recv + off, lay.block * isz, cs_raw)
-        self._event((tag, 'x', pos, c)).record(cs)
+        rl = t.get('relay')
+        if rl is None:
+            t['wire'].alltoall_blocks(send_ptr + off, recv + off, lay.block * isz, cs_raw)
+            self._event((tag, 'x', pos, c)).record(cs)
+            return
+        # routed: batch c carries round 1 of chunk c and round 2 of chunk c - 1; the batch after the
+        # last chunk carries the last round 2
+        sc, sched, K = rl['scalar'], rl['sched'], lay.K
+
+        def msgs(lst, chunk):
+            base = {'send': send_ptr + chunk * lay.chunk * isz, 'recv': recv + chunk * lay.chunk * isz,
+                    'relay': rl['buf'].data_ptr() + (chunk & 1) * rl['bytes']}
+            return [(base[b] + o * sc, n * sc, peer) for b, o, n, peer in lst]
+        sends, recvs = [], []
+        if c >= 1:
+            sends += msgs(sched.r2_send, c - 1)
+            recvs += msgs(sched.r2_recv, c - 1)
+        sends += msgs(sched.r1_send, c)
+        recvs += msgs(sched.r1_recv, c)
+        if sched.self_copy is not None:
+            so, ro, n = sched.self_copy
+            me = rl['wire'].rank
+            sends.append((send_ptr + off + so * sc, n * sc, me))
+            recvs.append((recv + off + ro * sc, n * sc, me))
+        rl['wire'].sendrecv(sends, recvs, cs_raw)
+        if c >= 1:
+            self._event((tag, 'x', pos, c - 1)).record(cs)
+        if c == K - 1:
+            rl['wire'].sendrecv(msgs(sched.r2_send, c), msgs(sched.r2_recv, c), cs_raw)
+            self._event((tag, 'x', pos, c)).record(cs)

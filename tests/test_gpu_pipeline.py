@@ -134,3 +134,34 @@ def test_transforms_that_do_not_qualify_keep_the_staged_path(monkeypatch):
     assert thread_comm.run(4, body)[0] == [True, True, True, True]
     cases.check_pfft_vs_oracle(4, (33, 20, 18), 'd')
     cases.check_pfft_vs_oracle(4, (48, 40, 64), 'D')
+
+
+@pytest.mark.parametrize('P,shape', [(4, (64, 64, 64)), (8, (64, 64, 64)), (8, (128, 64, 256))])
+@pytest.mark.parametrize('chunks', [1, 4])
+def test_pipelined_routed_exchange_is_bit_identical(P, shape, chunks, monkeypatch):
+    """exchange='relay' on the native wire: every redistribution inside a small sub-communicator
+    travels over all links of the grid in two rounds, round 2 of chunk k batched with round 1 of
+    chunk k+1 (pipeline.Pipeline._plan_relays); same bits as the staged direct path."""
+    from mpi4py_fft_amd import PFFT, newDistArray, pipeline
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_CHUNK_BYTES', 0)
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_WIDTH', 4)
+    monkeypatch.setattr(pipeline.Pipeline, 'CHUNKS', chunks)
+    G = O.rng_array(shape, 'D', 5)
+
+    def body(comm):
+        staged = PFFT(comm, shape, dtype='D', wire='torch', exchange='direct')
+        piped = PFFT(comm, shape, dtype='D', wire='native', exchange='relay')
+        info = piped.pipeline.describe()
+        u = newDistArray(staged, False)
+        u[...] = G[staged.local_slice(False)]
+        a = np.asarray(staged.forward(u)).copy()
+        b = np.asarray(piped.forward(u)).copy()
+        ab = np.asarray(staged.backward()).copy()
+        bb = np.asarray(piped.backward()).copy()
+        b2 = np.asarray(piped.forward(u)).copy()          # buffers and events are reusable
+        staged.destroy()
+        piped.destroy()
+        return a, b, ab, bb, b2, info
+    for a, b, ab, bb, b2, info in cases.run_ranks(P, body):
+        assert [e['route'] for e in info if e['ranks'] > 1] == ['relay'] * sum(1 for e in info if e['ranks'] > 1), info
+        assert np.array_equal(a, b) and np.array_equal(ab, bb) and np.array_equal(a, b2)
