@@ -555,22 +555,42 @@ __device__ __forceinline__ void tile_store_trunc(const PassDesc &d, void *__rest
 // thread writes its R entries to their slots (thread 0 also fills slot N: Z[0] again, or X[N]),
 // and reads slot N - e for each of them.  With split planes the real parts of the mirrors wait in
 // R registers while the imaginary plane goes through.
-// exp(-i pi q / R) for q < R, R in {4, 8, 16}, as compile-time constants: the Hermitian twiddle of
-// entry e = t + q NT is w^e = w^t exp(-i pi q / R) (NT = N / R, w = exp(-2 pi i / 2N)), so a thread
-// loads ONE table entry per line and derives the rest by a multiplication with a literal -- R table
-// loads per line cost R address / value register pairs that the scheduler hoists to the front.
-template <typename real> struct Pi16 {
-  static constexpr real C[9] = {(real)1.0, (real)0.98078528040323044912618223613424, (real)0.92387953251128675612818318939679,
-                                (real)0.83146961230254523707878837761791, (real)0.70710678118654752440084436210485,
-                                (real)0.55557023301960222474283081394853, (real)0.38268343236508977172845998403040,
-                                (real)0.19509032201612826784828486847702, (real)0.0};
-  static constexpr real cosk(int k) { return k <= 8 ? C[k] : -C[16 - k]; }       // cos(k pi / 16), 0 <= k <= 16
-  static constexpr real sink(int k) { return C[k <= 8 ? 8 - k : k - 8]; }        // sin(k pi / 16)
+// exp(-i pi q / R) for q < R as compile-time constants: the Hermitian twiddle of entry e = t + q NT
+// is w^e = w^t exp(-i pi q / R) (NT = N / R, w = exp(-2 pi i / 2N)), so a thread loads ONE table entry
+// per line and derives the rest by a multiplication with a literal -- R table loads per line cost R
+// address / value register pairs that the scheduler hoists to the front.  The literals come from a
+// constexpr Taylor evaluation in long double (R = 4 ... 24: powers of two, 12, 20, 24).
+namespace ct {
+constexpr long double PI = 3.14159265358979323846264338327950288L;
+constexpr long double sin_small(long double x) {      // |x| <= pi/4
+  long double term = x, sum = x;
+  for (int k = 1; k < 16; ++k) { term *= -x * x / ((2 * k) * (2 * k + 1)); sum += term; }
+  return sum;
+}
+constexpr long double cos_small(long double x) {
+  long double term = 1, sum = 1;
+  for (int k = 1; k < 16; ++k) { term *= -x * x / ((2 * k - 1) * (2 * k)); sum += term; }
+  return sum;
+}
+constexpr long double cos_0pi(long double x) {        // 0 <= x <= pi
+  return x <= PI / 4 ? cos_small(x) : (x <= 3 * PI / 4 ? -sin_small(x - PI / 2) : -cos_small(PI - x));
+}
+constexpr long double sin_0pi(long double x) {
+  return x <= PI / 4 ? sin_small(x) : (x <= 3 * PI / 4 ? cos_small(x - PI / 2) : sin_small(PI - x));
+}
+}  // namespace ct
+template <typename real, int R> struct MirrorTab {
+  real c[R], s[R];
+  constexpr MirrorTab() : c(), s() {
+    for (int q = 0; q < R; ++q) {
+      c[q] = (real)ct::cos_0pi(ct::PI * q / R);
+      s[q] = (real)-ct::sin_0pi(ct::PI * q / R);
+    }
+  }
 };
 template <typename real, int R> __device__ __forceinline__ cx<real> mirror_twiddle(cx<real> wt, int q) {
-  static_assert(16 % R == 0, "mirror twiddles: R divides 16");
-  const int k = q * (16 / R);
-  const real c = Pi16<real>::cosk(k), s = -Pi16<real>::sink(k);
+  constexpr MirrorTab<real, R> tab{};
+  const real c = tab.c[q], s = tab.s[q];
   return {wt.x * c - wt.y * s, wt.x * s + wt.y * c};
 }
 
@@ -629,7 +649,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   // packed-real modes move complex pairs on both sides; the Hermitian pass is in the kernel body
   constexpr bool HALF = MODE == MODE_R2C_H || MODE == MODE_C2R_H;
   constexpr int IOMODE = HALF ? MODE_C2C : MODE;
-  static_assert(!HALF || (!COLS && !BIGTW && !(FLAGS & (16 | 32))), "packed-real modes: contiguous axis only");
+  static_assert(!HALF || (!COLS && !BIGTW && !(FLAGS & 32)), "packed-real modes: contiguous axis only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const cx<real> *tw = reinterpret_cast<const cx<real> *>(d.tw);
   const int tid = threadIdx.x;
@@ -701,7 +721,15 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         if constexpr ((FLAGS & 16) != 0) {
-          if constexpr ((FLAGS & 64) != 0) v[q] = tile_load_pad<real, IOMODE>(d, in, in0, idx, pad_shift_in, tl + q * NT, sy_in);
+          if constexpr (HALF && (FLAGS & 64) != 0) {
+            // zero-padded half spectrum (libfft.py:298-311): entries >= tr_n are zero, the last kept
+            // entry of an even truncated length is a real Nyquist value taken at half weight
+            const int e = tl + q * NT;
+            const bool ok = e < d.tr_n, nyq = d.tr_even && e == d.tr_n - 1;
+            v[q] = reinterpret_cast<const cx<real> *>(in)[ok ? idx : in0];
+            v[q].x *= ok ? (nyq ? (real)0.5 : (real)1) : (real)0;
+            v[q].y *= (ok && !nyq) ? (real)1 : (real)0;
+          } else if constexpr ((FLAGS & 64) != 0) v[q] = tile_load_pad<real, IOMODE>(d, in, in0, idx, pad_shift_in, tl + q * NT, sy_in);
           else v[q] = tile_load<real, IOMODE, false>(d, in, in0, idx, tl + q * NT, sy_in);
         } else {
           v[q] = tile_load<real, IOMODE, (FLAGS & 1) != 0>(d, in, in0, idx, tl + q * NT, sy_in);
@@ -730,7 +758,9 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
       // c2r does.
       cx<real> top = {0, 0};
       if (tl == 0) {
-        if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[in0 + (int64_t)N * d.in_es].x;
+        if constexpr (!(FLAGS & 64)) {
+          if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[in0 + (int64_t)N * d.in_es].x;
+        }
         v[0].y = 0;
       }
       const cx<real> wt = rtw[tl];
@@ -758,7 +788,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
         v[q] = {a.x + wb.y, a.y - wb.x};                           // a - i w b
       });
     }
-    if constexpr ((FLAGS & 16) != 0 && !(FLAGS & 64) && MODE == MODE_C2C) {
+    if constexpr ((FLAGS & 16) != 0 && !(FLAGS & 64) && MODE == MODE_C2C && !HALF) {
       // complex truncation with even N: entries h = N/2 and n - h of the padded spectrum both land
       // on truncated entry h (libfft.py:281-284).  They live in different threads: pass the upper
       // one through LDS.  (uniform branch: every thread of the workgroup takes it or none does)
@@ -829,7 +859,15 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         if constexpr ((FLAGS & 16) != 0) {
-          if constexpr (!(FLAGS & 64)) tile_store_trunc<real, IOMODE>(d, out, idx, pad_shift_out, tl + q * NT, v[q], sx_out, sy_out);
+          if constexpr (HALF && !(FLAGS & 64)) {
+            // truncated half spectrum (libfft.py:286-296): keep entries < tr_n; the last one of an
+            // even truncated length becomes a real Nyquist value of twice the weight
+            const int e = tl + q * NT;
+            if (e < d.tr_n) {
+              const bool nyq = d.tr_even && e == d.tr_n - 1;
+              reinterpret_cast<cx<real> *>(out)[idx] = {v[q].x * (nyq ? 2 * sx_out : sx_out), nyq ? (real)0 : v[q].y * sy_out};
+            }
+          } else if constexpr (!(FLAGS & 64)) tile_store_trunc<real, IOMODE>(d, out, idx, pad_shift_out, tl + q * NT, v[q], sx_out, sy_out);
           else tile_store<real, IOMODE, false, false>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
         } else {
           tile_store<real, IOMODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
@@ -841,7 +879,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
         }
         idx += step;
       }
-      if constexpr (MODE == MODE_R2C_H) {
+      if constexpr (MODE == MODE_R2C_H && !(FLAGS & 16)) {
         if (tl == 0)
           reinterpret_cast<cx<real> *>(out)[out0 + (int64_t)N * d.out_es] = {(z0.x - z0.y) * 2 * sx_out, 0};
       }
@@ -882,6 +920,20 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, dd, in, out);
   return hipGetLastError();
+}
+
+// packed-real row plans (fft_real_*.hip): plain, with the truncating store (forward, 3/2-rule) or
+// with the zero-padding load (backward), by d.tr_dir
+template <typename real, int MODE, int N, int R, int T, bool SPLIT, int... RADS>
+hipError_t half_launch(const PassDesc &d, const void *in, void *out, hipStream_t s) {
+  static_assert(MODE == MODE_R2C_H || MODE == MODE_C2R_H, "packed-real modes");
+  if (d.tr_dir == 0) return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 0, MODE, false, RADS...>(d, in, out, s);
+  if constexpr (MODE == MODE_R2C_H) {
+    if (d.tr_dir == 1) return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 16, MODE, false, RADS...>(d, in, out, s);
+  } else {
+    if (d.tr_dir == 2) return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 16 | 64, MODE, false, RADS...>(d, in, out, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 // runtime (mode, four-step twiddle) -> instantiation

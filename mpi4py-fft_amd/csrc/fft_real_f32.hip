@@ -8,8 +8,8 @@ namespace gfft {
 
 // (R = 16 plans are held to 128 VGPRs = 4 waves per SIMD: unconstrained, the backward kernels
 // keep all mirror entries and twiddles in flight at once and take ~170)
-#define H32(MODE, N, R, T, ...) \
-  launch_pow2_one<float, N, R, T, false, false, 1, 0, MODE, false, __VA_ARGS__>(d, in, out, s)
+// (plain, truncating-store and zero-padding-load instantiations of one plan: half_launch picks by d.tr_dir)
+#define H32(MODE, N, R, T, ...) half_launch<float, MODE, N, R, T, false, __VA_ARGS__>(d, in, out, s)
 
 template <int MODE>
 static hipError_t launch_half_f32(const PassDesc &d, int variant, const void *in, void *out, hipStream_t s) {

@@ -8,8 +8,8 @@
 
 namespace gfft {
 
-#define H64(MODE, N, R, T, ...) \
-  launch_pow2_one<double, N, R, T, false, true, 1, 0, MODE, false, __VA_ARGS__>(d, in, out, s)
+// (plain, truncating-store and zero-padding-load instantiations of one plan: half_launch picks by d.tr_dir)
+#define H64(MODE, N, R, T, ...) half_launch<double, MODE, N, R, T, true, __VA_ARGS__>(d, in, out, s)
 
 template <int MODE>
 static hipError_t launch_half_f64(const PassDesc &d, int variant, const void *in, void *out, hipStream_t s) {

@@ -104,6 +104,10 @@ int pow2_grid_cap();
 bool real_half_supported(int n_complex);
 hipError_t launch_real_half_f64(const PassDesc &d, int variant, const void *in, void *out, hipStream_t s);
 hipError_t launch_real_half_f32(const PassDesc &d, int variant, const void *in, void *out, hipStream_t s);
+// ... for complex lengths 3^b 2^k / 5^c 2^k (fft_real_mix_*.hip, generated)
+bool real_half_mix_supported(int n_complex);
+hipError_t launch_real_half_mix_f64(const PassDesc &d, const void *in, void *out, hipStream_t s);
+hipError_t launch_real_half_mix_f32(const PassDesc &d, const void *in, void *out, hipStream_t s);
 // lengths 3^b * 2^k handled by the same register-resident kernel with R = 12 (fft_mix3_*.hip)
 bool mix3_supported(int n);
 hipError_t launch_mix3_f64(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);

@@ -326,7 +326,8 @@ PassDesc natural_desc(const Line &L) {
 bool real_half_ok(const Line &L, int prec) {
   (void)prec;
   return opts().real_half && !opts().force_generic && (L.mode == MODE_R2C || L.mode == MODE_C2R) &&
-         L.inner == 1 && L.n % 2 == 0 && real_half_supported((int)(L.n / 2)) && L.outer < ((int64_t)1 << 31);
+         L.inner == 1 && L.n % 2 == 0 && L.n / 2 <= 4096 &&
+         (real_half_supported((int)(L.n / 2)) || real_half_mix_supported((int)(L.n / 2))) && L.outer < ((int64_t)1 << 31);
 }
 
 // natural_desc(L) restated for the packed-real form: d.n = complex length, real side in pairs
@@ -867,7 +868,8 @@ int plan_fused3(gfft_plan_s *pl) {
     p.d.in_es = 1;
     p.d.out_es = 1;
     p.src = src; p.dst = dst;
-    if (mode != MODE_C2C && opts().real_half && n2 % 2 == 0 && real_half_supported((int)(n2 / 2))) {
+    if (mode != MODE_C2C && opts().real_half && n2 % 2 == 0 &&
+        (real_half_supported((int)(n2 / 2)) || real_half_mix_supported((int)(n2 / 2)))) {
       // packed-real form: complex length n2/2, the real side (the user's natural array) in pairs
       p.d.n = (int)(n2 / 2);
       p.d.mode = mode == MODE_R2C ? MODE_R2C_H : MODE_C2R_H;
@@ -944,9 +946,11 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   const int64_t esz_in = ((d.mode == MODE_R2C || d.mode == MODE_R2R) ? 1 : 2) * (int64_t)pl->precision;
   d.swizzle = pl->xcd_swizzle >= 0 ? pl->xcd_swizzle
                                    : (p.cols && (((d.out_es * esz_out) % 128 != 0) || ((d.in_es * esz_in) % 128 != 0)) ? 1 : 0);
-  if (d.mode == MODE_R2C_H || d.mode == MODE_C2R_H)
+  if ((d.mode == MODE_R2C_H || d.mode == MODE_C2R_H) && real_half_supported(d.n))
     return pl->precision == 8 ? launch_real_half_f64(d, pl->variant_rows, in, out, s)
                               : launch_real_half_f32(d, pl->variant_rows, in, out, s);
+  if (d.mode == MODE_R2C_H || d.mode == MODE_C2R_H)
+    return pl->precision == 8 ? launch_real_half_mix_f64(d, in, out, s) : launch_real_half_mix_f32(d, in, out, s);
   if (p.regk && d.mode == MODE_R2R && pow2_r2r_supported(d.n))
     return pl->precision == 8 ? launch_pow2_r2r_f64(d, p.cols, in, out, s) : launch_pow2_r2r_f32(d, p.cols, in, out, s);
   if (p.regk && mix3_supported(d.n)) {
@@ -1263,10 +1267,18 @@ int gfft_plan_set_truncation(gfft_plan pl, int64_t n_keep) {
     return fail(GFFT_ERR_UNSUPPORTED, "truncation fuses into single-pass plans only");
   Pass &p = pl->passes[0];
   if (p.d.mode == MODE_R2C_H || p.d.mode == MODE_C2R_H) {
-    // the truncation / padding adapters belong to the full-length form of a real line
-    if (!p.has_full) return fail(GFFT_ERR_UNSUPPORTED, "truncation: no single-pass full-length form of this real line");
-    p.d = p.full;
-    p.has_full = false;
+    // packed-real rows: the truncating store / zero-padding load act on the half spectrum
+    // (entries 0 .. n_keep-1 of the p.d.n + 1; strides are in complex entries, inner == 1)
+    const int64_t full_h = (int64_t)p.d.n + 1;
+    if (n_keep < 1 || n_keep > full_h) return fail(GFFT_ERR_INVALID, "bad truncated length");
+    if (n_keep == full_h) return GFFT_OK;        // nothing to cut: the plain plan is the answer
+    const bool fwd_h = p.d.mode == MODE_R2C_H;
+    const double lines_h = (double)p.d.batch, esz_h = 2.0 * pl->precision;
+    if (fwd_h) { p.d.tr_dir = 1; p.d.out_os = n_keep; } else { p.d.tr_dir = 2; p.d.in_os = n_keep; }
+    pl->bytes += lines_h * ((double)n_keep - (double)full_h) * esz_h;
+    p.d.tr_n = p.d.tr_N = (int)n_keep;
+    p.d.tr_even = (n_keep % 2 == 0) ? 1 : 0;
+    return GFFT_OK;
   }
   if (p.kind != PK_FFT || !p.regk || p.d.mid != 1 || p.d.tw_hi)
     return fail(GFFT_ERR_UNSUPPORTED, "truncation fuses into register-kernel passes only");

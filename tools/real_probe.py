@@ -69,3 +69,7 @@ else:
     case((256, 1024, 4096), 'f')
     case((128, 1024, 8192), 'f')
     case((4096, 256), 'd')
+    case((768, 768, 768), 'd')
+    case((512, 768, 1536), 'f')
+    case((1000, 1000, 1000), 'd')
+    case((512, 1024, 3072), 'f')
