@@ -690,18 +690,19 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     // hoisted it sits in -- or spills from -- 2 VGPRs per use for the whole kernel.
     int tl = t;
     asm volatile("" : "+v"(tl));
-    bool valid;
+    bool valid, valid_st;
     unsigned o, m, i;
     if constexpr (ROWTILES) {
       const unsigned row = tile / chunks, j = tile - row * chunks;
       i = j * T + c;
-      valid = i < inner;
-      if (!valid) i = 0;
+      valid = i < (d.inner_ld ? (unsigned)d.inner_ld : inner);          // columns that are read
+      valid_st = i < (d.inner_st ? (unsigned)d.inner_st : inner);       // columns that are written
+      if (!(valid || valid_st)) i = 0;
       o = row / mid;
       m = row - o * mid;
     } else {
       const unsigned b = tile * T + c;
-      valid = b < batch;
+      valid = valid_st = b < batch;
       const unsigned bb = valid ? b : 0;
       const unsigned bm = bb / inner;
       i = bb - bm * inner;
@@ -813,14 +814,34 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
       // its R values to thread (c' = tid / NT, t' = tid % NT), same slots e = t' + q*NT -- and
       // store with lanes along e: whole 64-lane rows of one output line.
       static_assert(COLS && SPLIT && BIGTW && MODE == MODE_C2C, "transposing store: first four-step pass");
-#pragma unroll
-      for (int q = 0; q < R; ++q) {
-        if constexpr (BIGTW) {
-          const unsigned x = m * (unsigned)(tl + q * NT);
+      if constexpr (BIGTW) {
+        // four-step twiddle W^(m e), e = t + q NT: two table look-ups per THREAD -- W^(m t) and
+        // W^(m NT) -- and the powers of the second by squaring (q is a compile-time index, so entry q
+        // costs at most log2 R multiplications); one look-up pair per ELEMENT tripled the load
+        // instructions of this pass (data + 2 gathers)
+        const auto big = [&](unsigned x) {
           const cx<real> a = reinterpret_cast<const cx<real> *>(d.tw_hi)[x >> d.tw_L];
           const cx<real> b = reinterpret_cast<const cx<real> *>(d.tw_lo)[x & ((1u << d.tw_L) - 1)];
-          v[q] = cmul(v[q], cmul(a, b));
+          return cmul(a, b);
+        };
+        constexpr int LG = R >= 32 ? 5 : (R >= 16 ? 4 : (R >= 8 ? 3 : 2));
+        static_assert((1 << LG) >= R, "powers of the step twiddle");
+        const cx<real> w0 = big(m * (unsigned)tl);
+        cx<real> sp[LG];
+        sp[0] = big(m * (unsigned)NT);
+#pragma unroll
+        for (int k = 1; k < LG; ++k) sp[k] = cmul(sp[k - 1], sp[k - 1]);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          cx<real> w = w0;
+#pragma unroll
+          for (int k = 0; k < LG; ++k)
+            if ((q >> k) & 1) w = cmul(w, sp[k]);
+          v[q] = cmul(v[q], w);
         }
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
         v[q].x *= sx_out;
         v[q].y *= sy_out;
       }
@@ -853,7 +874,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
           idx += q_out;
         }
       }
-    } else if (valid) {
+    } else if (valid_st) {
       int64_t idx = out0 + t_out;
       int cnt = 0;
 #pragma unroll
@@ -880,8 +901,11 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
         idx += step;
       }
       if constexpr (MODE == MODE_R2C_H && !(FLAGS & 16)) {
-        if (tl == 0)
-          reinterpret_cast<cx<real> *>(out)[out0 + (int64_t)N * d.out_es] = {(z0.x - z0.y) * 2 * sx_out, 0};
+        // X[N] from thread 0, followed by d.out_pad zeros from its neighbours: one coalesced store
+        // that completes the row's last 128-byte line when the output rows are pitched
+        if (tl <= d.out_pad)
+          reinterpret_cast<cx<real> *>(out)[out0 + (int64_t)(N + tl) * d.out_es] =
+              {tl == 0 ? (z0.x - z0.y) * 2 * sx_out : (real)0, 0};
       }
     }
   }

@@ -36,6 +36,14 @@ struct PassDesc {
   int tr_dir, tr_n, tr_N, tr_even;
   int64_t batch;  // number of columns = outer * mid * inner
   int64_t mid, inner;
+  // strided (COLS) passes over rows with padding columns: of the `inner` adjacent columns only the
+  // first inner_ld are read (the rest enter as zeros) and only the first inner_st are written
+  // (0 = all).  Lets the passes inside a pitched workspace run on whole 128-byte lines -- a ragged
+  // last tile of ONE column (513-wide half spectra) costs 16-byte partial-line writes that measured
+  // 0.5 ms per 1024^3 pass, profiles/r02b_ragged_probe.txt -- while the caller's natural arrays are
+  // touched only where they have data.
+  int64_t inner_ld, inner_st;
+  int out_pad;    // MODE_R2C_H: zero entries written after X[N] (fills the output row's last line)
   int64_t in_os, in_ms, in_is, in_es;
   int64_t out_os, out_ms, out_is, out_es;
   // packed-layout adapters (gfft_plan_set_split): the transform axis is cut into 2^lgp equal

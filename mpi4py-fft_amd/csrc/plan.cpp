@@ -184,6 +184,7 @@ struct Pass {
   // zero-imaginary / mirror adapters) for what only that form can fuse: truncation / padding
   bool has_full = false;
   PassDesc full{};
+  int64_t data_inner = 0;            // columns of d.inner that carry data (0 = all): byte accounting
 };
 
 bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -824,6 +825,9 @@ int plan_fused3(gfft_plan_s *pl) {
   int64_t P = (nc + seg - 1) / seg * seg;
   if ((P * esz) % 2048 == 0) P += 256 / esz;
   need(pl, BUF_WS, (size_t)(n0 * n1 * P * esz));
+  // columns the in-workspace passes run over: nc rounded up to whole 128-byte lines (the padding
+  // columns hold zeros written by the pass that fills W), see PassDesc::inner_ld / inner_st
+  const int64_t Pu = (nc + seg - 1) / seg * seg;
 
   auto base = [&](int n, int mode) {
     Pass p;
@@ -877,6 +881,7 @@ int plan_fused3(gfft_plan_s *pl) {
       p.d.conj_out = mode == MODE_C2R ? 1 : 0;
       if (mode == MODE_R2C) { p.d.in_os /= 2; p.d.in_is /= 2; }
       else { p.d.out_os /= 2; p.d.out_is /= 2; }
+      if (mode == MODE_R2C && out_ws) p.d.out_pad = (int)(Pu - nc);
     }
     return p;
   };
@@ -884,8 +889,14 @@ int plan_fused3(gfft_plan_s *pl) {
   auto axis1 = [&](bool in_ws, bool out_ws, int src, int dst) {
     Pass p = base((int)n1, MODE_C2C);
     p.cols = true;
-    p.d.batch = n0 * nc;
-    p.d.inner = nc;
+    // tiles cover the line-rounded width; the natural side is masked to its nc columns
+    p.d.batch = n0 * Pu;
+    p.d.inner = Pu;
+    p.data_inner = nc;
+    if (Pu != nc) {
+      if (!in_ws) p.d.inner_ld = nc;
+      if (!out_ws) p.d.inner_st = nc;
+    }
     p.d.in_os = in_ws ? w_i0 : n1 * nc;   p.d.in_es = in_ws ? w_i1 : nc;
     p.d.out_os = out_ws ? w_i0 : n1 * nc; p.d.out_es = out_ws ? w_i1 : nc;
     p.src = src; p.dst = dst;
@@ -895,8 +906,9 @@ int plan_fused3(gfft_plan_s *pl) {
   auto axis0 = [&](int src, int dst) {
     Pass p = base((int)n0, MODE_C2C);
     p.cols = true;
-    p.d.batch = n1 * nc;
-    p.d.inner = nc;
+    p.d.batch = n1 * Pu;
+    p.d.inner = Pu;
+    p.data_inner = nc;
     p.d.in_os = w_i1;  p.d.in_es = w_i0;
     p.d.out_os = w_i1; p.d.out_es = w_i0;
     p.src = src; p.dst = dst;
@@ -917,7 +929,8 @@ int plan_fused3(gfft_plan_s *pl) {
     if (rc) return rc;
     const bool half = p.d.mode == MODE_R2C_H || p.d.mode == MODE_C2R_H;
     if (half && (rc = get_twiddles(2 * (int64_t)p.d.n, prec, &p.d.rtw))) return rc;
-    const double lines = (double)p.d.batch;
+    // (strided passes tile the line-rounded width Pu; the work model counts the nc data columns)
+    const double lines = p.cols ? (double)p.d.batch / (double)Pu * (double)nc : (double)p.d.batch;
     const double n = half ? 2.0 * p.d.n : p.d.n;          // logical length of the line
     const bool r2c = p.d.mode == MODE_R2C || p.d.mode == MODE_R2C_H, c2r = p.d.mode == MODE_C2R || p.d.mode == MODE_C2R_H;
     pl->flops += (p.d.mode == MODE_C2C ? 1.0 : 0.5) * 5.0 * n * std::log2(n) * lines;
@@ -1251,6 +1264,7 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
     const double ein = p.d.mode == MODE_R2C ? p.d.n * (double)pl->precision : nc * esz;
     const double eout = p.d.mode == MODE_C2R ? p.d.n * (double)pl->precision : nc * esz;
     *bytes = (double)p.d.batch * (ein + eout);
+    if (p.data_inner) *bytes *= (double)p.data_inner / (double)p.d.inner;
     if (p.d.mode == MODE_R2R) *bytes = (double)p.d.batch * 2.0 * p.d.r2r_n * (double)pl->precision;
   }
   return GFFT_OK;
