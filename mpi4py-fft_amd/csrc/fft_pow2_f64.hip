@@ -107,6 +107,8 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
           case 6: return P64F(1024, 8, 8, true, 1, 7, 8, 8, 8, 2);      // ... with nt loads/stores
           case 10: return P64F(1024, 16, 16, true, 4, 4, 16, 16, 4);    // access pattern only, T=16
           case 12: return P64F(1024, 16, 16, true, 4, 8, 8, 8, 8, 2);
+          case 13: return P64F(1024, 16, 16, true, 4, 8 | 2, 16, 16, 4);   // non-temporal stores
+          case 14: return P64F(1024, 16, 16, true, 4, 8 | 3, 16, 16, 4);   // non-temporal loads and stores
         }
       case 2048: return P64F(2048, 16, 8, true, 4, 8, 16, 16, 8);
       case 4096: return P64F(4096, 16, 4, true, 4, 8, 16, 16, 16);

@@ -231,6 +231,12 @@ class PFFT:
             # the route of every exchange (relay.py): collective over the grid, same order everywhere
             for t in self.transfer:
                 t.plan_relay(exchange)
+            # 'auto': the routes are timed NOW, on the planned exchange buffers (their contents do
+            # not matter), as FFTW_MEASURE times candidate plans inside the planner -- not inside the
+            # caller's first forward()
+            for i, t in enumerate(self.transfer):
+                if t.exchange is None:
+                    t.forward(self.xfftn[i].forward.output_array, self.xfftn[i + 1].forward.input_array)
         self.pipeline = None
         if not local and padding is False and transforms is None:
             self.pipeline = self._plan_pipeline(wire, exchange)

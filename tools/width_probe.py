@@ -39,6 +39,13 @@ def case(shape, dt, axis, swz=None):
 
 
 print(torch.cuda.get_device_name(0))
+if os.environ.get('WIDTH_PROBE_VARIANTS'):
+    for v in [int(x) for x in os.environ['WIDTH_PROBE_VARIANTS'].split(',')]:
+        _lib.set_option('variant_cols', v)
+        print('variant_cols', v)
+        for w in (512, 513):
+            case((1024, 1024, w), 'D', 1, 1)
+    sys.exit(0)
 for w in (512, 513, 520, 528, 544):
     for swz in (0, 1):
         case((1024, 1024, w), 'D', 1, swz)
