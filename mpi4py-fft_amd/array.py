@@ -19,14 +19,18 @@ _NP2T = {'f': torch.float32, 'd': torch.float64, 'F': torch.complex64, 'D': torc
 
 # ---- host <-> device staging ----------------------------------------------------------------------
 # The reference hands FFTW page-aligned host arrays (fftw/utilities.pyx:54-104, `aligned`); the
-# counterpart on this side of PCIe is page-LOCKED host memory.  `u[...] = host_array` and
-# `np.asarray(u)` of large arrays go through two pinned bounce buffers, filled by a multi-threaded
-# host copy while the previous chunk is on the wire (a pageable `tensor.to(device)` is staged by the
-# runtime through small internal buffers, one thread, no overlap); `host_empty` gives the caller a
-# numpy array that IS pinned, which then moves at the PCIe rate without any staging.
-PIN_CHUNK_BYTES = 128 << 20
-PIN_MIN_BYTES = 16 << 20
+# counterpart on this side of PCIe is page-LOCKED host memory.  Measured on the MI355X boxes
+# (tools/staging_probe.py, 4 GiB): host -> device from ordinary (pageable) numpy memory already runs
+# at the link rate (56.6 GB/s: the runtime DMAs it directly), so `u[...] = host` is a plain copy;
+# device -> pageable host is the slow direction (7-8 GB/s).  `np.asarray(u)` therefore lands chunks in
+# two pinned bounce buffers at the link rate and drains them into the result with several host
+# threads while the next chunk is on the wire; `host_empty` gives the caller a numpy array that IS
+# pinned, which moves at 57 GB/s both ways with no staging (`u.get(out=h)`).
+PIN_CHUNK_BYTES = 64 << 20
+PIN_MIN_BYTES = 32 << 20
+HOST_COPY_THREADS = 16
 _pinned = {}
+_pool = None
 
 
 def _bounce(device):
@@ -34,7 +38,7 @@ def _bounce(device):
     b = _pinned.get(key)
     if b is None:
         b = _pinned[key] = dict(buf=[torch.empty(PIN_CHUNK_BYTES, dtype=torch.uint8, pin_memory=True) for _ in range(2)],
-                                ev=[torch.cuda.Event(), torch.cuda.Event()], used=[False, False])
+                                ev=[torch.cuda.Event(), torch.cuda.Event()])
     return b
 
 
@@ -42,24 +46,25 @@ def _bytes_view(t):
     return (torch.view_as_real(t) if t.is_complex() else t).reshape(-1).view(torch.uint8)
 
 
+def _host_copy(dst, src):
+    """dst[:] = src for 1-D uint8 numpy arrays, split over a few threads (numpy copies release the
+    GIL; one thread moves 6-9 GB/s, far below the link)."""
+    global _pool
+    n = dst.shape[0]
+    k = min(HOST_COPY_THREADS, max(1, n >> 22))
+    if k == 1:
+        dst[:] = src
+        return
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(HOST_COPY_THREADS)
+    step = -(-n // k)
+    list(_pool.map(lambda o: dst.__setitem__(slice(o, o + step), src[o:o + step]), range(0, n, step)))
+
+
 def h2d(dst, host):
     """dst (contiguous device tensor) <- host (C-contiguous numpy array of the same dtype / size)."""
-    src = torch.from_numpy(host.reshape(-1).view(np.uint8))
-    n = src.numel()
-    if n < PIN_MIN_BYTES or not dst.is_cuda or src.is_pinned():
-        _bytes_view(dst).copy_(src)
-        return
-    b = _bounce(dst.device)
-    d = _bytes_view(dst)
-    for k, off in enumerate(range(0, n, PIN_CHUNK_BYTES)):
-        m = min(PIN_CHUNK_BYTES, n - off)
-        i = k & 1
-        if b['used'][i]:
-            b['ev'][i].synchronize()                 # the chunk sent two rounds ago has left the buffer
-        b['buf'][i][:m].copy_(src[off:off + m])      # host copy (torch splits it over its threads)
-        d[off:off + m].copy_(b['buf'][i][:m], non_blocking=True)
-        b['ev'][i].record()
-        b['used'][i] = True
+    _bytes_view(dst).copy_(torch.from_numpy(host.reshape(-1).view(np.uint8)))
 
 
 def d2h(src):
@@ -71,25 +76,21 @@ def d2h(src):
         torch.from_numpy(out).copy_(s)
         return out
     b = _bounce(src.device)
-    o = torch.from_numpy(out)
+    chunk = b['buf'][0].numel()
     pending = None
-    for k, off in enumerate(range(0, n, PIN_CHUNK_BYTES)):
-        m = min(PIN_CHUNK_BYTES, n - off)
+    for k, off in enumerate(range(0, n, chunk)):
+        m = min(chunk, n - off)
         i = k & 1
-        if b['used'][i]:
-            b['ev'][i].synchronize()
-        b['buf'][i][:m].copy_(s[off:off + m], non_blocking=True)
+        b['buf'][i][:m].copy_(s[off:off + m], non_blocking=True)      # buffer i was drained two rounds ago
         b['ev'][i].record()
-        b['used'][i] = True
         if pending is not None:                      # drain the previous chunk while this one flies
             j, poff, pm = pending
             b['ev'][j].synchronize()
-            o[poff:poff + pm].copy_(b['buf'][j][:pm])
+            _host_copy(out[poff:poff + pm], b['buf'][j][:pm].numpy())
         pending = (i, off, m)
-    if pending is not None:
-        j, poff, pm = pending
-        b['ev'][j].synchronize()
-        o[poff:poff + pm].copy_(b['buf'][j][:pm])
+    j, poff, pm = pending
+    b['ev'][j].synchronize()
+    _host_copy(out[poff:poff + pm], b['buf'][j][:pm].numpy())
     return out
 
 

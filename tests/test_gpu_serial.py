@@ -391,11 +391,13 @@ def test_split_layout_refusals():
 
 
 def test_pinned_staging_round_trip(monkeypatch):
-    """u[...] = host / np.asarray(u) through the two pinned bounce buffers (several chunks, odd
-    tail), and through a caller-owned pinned array (host_empty): bytes arrive unchanged."""
+    """np.asarray(u) through the two pinned bounce buffers and the threaded host copy (several
+    chunks, odd tail), u[...] = host, and a caller-owned pinned array (host_empty): bytes arrive
+    unchanged."""
     from mpi4py_fft_amd import array, empty, host_empty
     monkeypatch.setattr(array, 'PIN_CHUNK_BYTES', 1 << 20)
     monkeypatch.setattr(array, 'PIN_MIN_BYTES', 1 << 16)
+    monkeypatch.setattr(array, 'HOST_COPY_THREADS', 3)
     array._pinned.clear()
     rng = np.random.default_rng(3)
     for shape, dt in (((3, 257, 1031), 'D'), ((5, 333, 129), 'f'), ((64, 64), 'd')):
