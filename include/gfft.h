@@ -101,8 +101,11 @@ int gfft_plan_set_truncation(gfft_plan plan, int64_t n_keep);
  * in the layout of the all-to-all SEND buffer for `nblocks` equal blocks of the transformed axis
  * -- what gfft_pack would produce from the natural output; side 0: it reads its input directly
  * from the RECEIVE buffer -- what gfft_unpack would consume.  nblocks = 1 restores the natural
- * layout.  GFFT_ERR_UNSUPPORTED (plan unchanged) when the plan is not one register-kernel pass,
- * nblocks is not a power of two <= 8 dividing the length, or the transform is real. */
+ * layout.  GFFT_ERR_UNSUPPORTED (plan unchanged) when the plan is not one register-kernel pass or
+ * nblocks is not a power of two <= 8 dividing the length.  Real transforms: the half-spectrum side
+ * of an r2c (side 1) / c2r (side 0) plan along the contiguous last axis takes any nblocks <= 8 --
+ * n/2 + 1 entries never split evenly, so the blocks follow the reference's block rule
+ * (pencil.py:5-9) exactly as gfft_pack cuts them; other real plans return GFFT_ERR_UNSUPPORTED. */
 int gfft_plan_set_split(gfft_plan plan, int side, int nblocks);
 /* One batched 1-D complex transform with explicit strides: the form fftw_planxfftn() hands to
  * fftw_plan_guru_dft (fftw_planxfftn.c:25-57) -- `dim` is the transformed axis, `howmany` up to

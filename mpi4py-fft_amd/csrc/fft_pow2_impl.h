@@ -633,12 +633,28 @@ __device__ __forceinline__ void mirror_pass(cx<real> *v, int t, void *col, cx<re
   }
 }
 
+// Uneven all-to-all blocks on the half-spectrum side of a packed-real row pass (FLAGS & 128, see
+// PassDesc::ub_*): element offset of entry e of row `row`.  The block of e comes from a chain of at
+// most seven compares against scalar boundaries; no divisions, no table look-ups.
+__device__ __forceinline__ int64_t uneven_offset(const PassDesc &d, unsigned row, int e) {
+  int start = 0, width = d.ub_start[1];
+#pragma unroll
+  for (int b = 1; b < 8; ++b) {
+    if (b < d.ub_p && e >= d.ub_start[b]) {
+      start = d.ub_start[b];
+      width = d.ub_start[b + 1] - d.ub_start[b];
+    }
+  }
+  return d.ub_rows * (int64_t)start + (int64_t)row * width + (e - start);
+}
+
 // FLAGS: 1 = non-temporal loads, 2 = non-temporal stores, 4 = skip the transform (access-pattern
 // probe), 8 = c2c only, 16 = fused truncation / padding adapters (d.tr_dir: 1 store, 2 load),
 // 32 = transposing store (strided kernels whose OUTPUT is contiguous along the transform axis:
 // the first pass of a four-step transform), 64 = with 16: the adapter is the zero-padding LOAD
 // (backward direction) instead of the truncating STORE (a run-time direction switch inside the load
-// loop serialises the loads)
+// loop serialises the loads), 128 = packed-real rows whose half-spectrum side is an all-to-all buffer
+// of uneven blocks
 template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int MODE, bool BIGTW, int... RADS>
 __global__ void __launch_bounds__(T *(N / R), MINW)
 fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
@@ -711,6 +727,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     }
     const int64_t in0 = (int64_t)o * d.in_os + (int64_t)m * d.in_ms + (int64_t)i * d.in_is;
     const int64_t out0 = (int64_t)o * d.out_os + (int64_t)m * d.out_ms + (int64_t)i * d.out_is;
+    [[maybe_unused]] const unsigned row_ub = o * inner + i;     // FLAGS & 128: row of the exchange buffer
     cx<real> v[R];
     // Split layouts: thread slots e = t + q*NT advance by NT, and a block of the cut axis holds
     // (R >> lgp) * NT entries, so block boundaries fall between the same q for every thread: a
@@ -732,6 +749,8 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
             v[q].y *= (ok && !nyq) ? (real)1 : (real)0;
           } else if constexpr ((FLAGS & 64) != 0) v[q] = tile_load_pad<real, IOMODE>(d, in, in0, idx, pad_shift_in, tl + q * NT, sy_in);
           else v[q] = tile_load<real, IOMODE, false>(d, in, in0, idx, tl + q * NT, sy_in);
+        } else if constexpr (MODE == MODE_C2R_H && (FLAGS & 128) != 0) {
+          v[q] = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, tl + q * NT)];
         } else {
           v[q] = tile_load<real, IOMODE, (FLAGS & 1) != 0>(d, in, in0, idx, tl + q * NT, sy_in);
         }
@@ -759,7 +778,9 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
       // c2r does.
       cx<real> top = {0, 0};
       if (tl == 0) {
-        if constexpr (!(FLAGS & 64)) {
+        if constexpr ((FLAGS & 128) != 0) {
+          if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, N)].x;
+        } else if constexpr (!(FLAGS & 64)) {
           if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[in0 + (int64_t)N * d.in_es].x;
         }
         v[0].y = 0;
@@ -890,6 +911,8 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
             }
           } else if constexpr (!(FLAGS & 64)) tile_store_trunc<real, IOMODE>(d, out, idx, pad_shift_out, tl + q * NT, v[q], sx_out, sy_out);
           else tile_store<real, IOMODE, false, false>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
+        } else if constexpr (MODE == MODE_R2C_H && (FLAGS & 128) != 0) {
+          reinterpret_cast<cx<real> *>(out)[uneven_offset(d, row_ub, tl + q * NT)] = {v[q].x * sx_out, v[q].y * sy_out};
         } else {
           tile_store<real, IOMODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
         }
@@ -900,7 +923,10 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
         }
         idx += step;
       }
-      if constexpr (MODE == MODE_R2C_H && !(FLAGS & 16)) {
+      if constexpr (MODE == MODE_R2C_H && (FLAGS & 128) != 0) {
+        if (tl == 0)
+          reinterpret_cast<cx<real> *>(out)[uneven_offset(d, row_ub, N)] = {(z0.x - z0.y) * 2 * sx_out, 0};
+      } else if constexpr (MODE == MODE_R2C_H && !(FLAGS & 16)) {
         // X[N] from thread 0, followed by d.out_pad zeros from its neighbours: one coalesced store
         // that completes the row's last 128-byte line when the output rows are pitched
         if (tl <= d.out_pad)
@@ -951,6 +977,9 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
 template <typename real, int MODE, int N, int R, int T, bool SPLIT, int... RADS>
 hipError_t half_launch(const PassDesc &d, const void *in, void *out, hipStream_t s) {
   static_assert(MODE == MODE_R2C_H || MODE == MODE_C2R_H, "packed-real modes");
+  if (d.ub_p > 1 && d.tr_dir == 0)
+    return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 128, MODE, false, RADS...>(d, in, out, s);
+  if (d.ub_p > 1) return hipErrorInvalidValue;
   if (d.tr_dir == 0) return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 0, MODE, false, RADS...>(d, in, out, s);
   if constexpr (MODE == MODE_R2C_H) {
     if (d.tr_dir == 1) return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 16, MODE, false, RADS...>(d, in, out, s);

@@ -44,6 +44,14 @@ struct PassDesc {
   // touched only where they have data.
   int64_t inner_ld, inner_st;
   int out_pad;    // MODE_R2C_H: zero entries written after X[N] (fills the output row's last line)
+  // Packed-real rows writing (r2c) / reading (c2r) an all-to-all buffer whose blocks are UNEVEN: the
+  // N + 1 entries of the half spectrum dealt to ub_p ranks by the reference's block rule
+  // (pencil.py:5-9), block b = entries [ub_start[b], ub_start[b+1]).  Entry e of row o (of ub_rows
+  // rows in the buffer) lives at  ub_rows * start_b + o * w_b + (e - start_b):  the layout gfft_pack
+  // produces for the cut axis being the last one.  0 = not in use.
+  int ub_p;
+  int ub_start[9];
+  int64_t ub_rows;
   int64_t in_os, in_ms, in_is, in_es;
   int64_t out_os, out_ms, out_is, out_es;
   // packed-layout adapters (gfft_plan_set_split): the transform axis is cut into 2^lgp equal

@@ -1331,6 +1331,23 @@ int gfft_plan_set_split(gfft_plan pl, int side, int nblocks) {
   if (pl->passes.size() != 1 || pl->axes.size() != 1 || pl->fused3)
     return fail(GFFT_ERR_UNSUPPORTED, "split layouts fuse into single-pass plans only");
   Pass &p = pl->passes[0];
+  if ((p.d.mode == MODE_R2C_H && side == 1) || (p.d.mode == MODE_C2R_H && side == 0)) {
+    // packed-real rows: the half-spectrum side as an all-to-all buffer of UNEVEN blocks (the
+    // n/2 + 1 entries never divide evenly; pencil.py:5-9 deals the remainder to the first ranks)
+    if (p.d.tr_dir || p.d.mid != 1 || p.d.inner != 1) return fail(GFFT_ERR_UNSUPPORTED, "split layout: plain packed-real rows only");
+    const int nh = p.d.n + 1;
+    if (nblocks < 1 || nblocks > 8 || nblocks > nh) return fail(GFFT_ERR_UNSUPPORTED, "split layout: at most 8 blocks");
+    if (nblocks == 1) {
+      p.d.ub_p = 0;
+      return GFFT_OK;
+    }
+    const int q = nh / nblocks, r = nh % nblocks;
+    p.d.ub_p = nblocks;
+    for (int b = 0; b <= nblocks; ++b) p.d.ub_start[b] = b * q + (b < r ? b : r);
+    for (int b = nblocks + 1; b < 9; ++b) p.d.ub_start[b] = nh;
+    p.d.ub_rows = p.d.batch;
+    return GFFT_OK;
+  }
   if (p.kind != PK_FFT || !p.regk || p.d.mid != 1 || p.d.tw_hi || p.d.tr_dir || p.d.mode != MODE_C2C)
     return fail(GFFT_ERR_UNSUPPORTED, "split layouts fuse into complex register-kernel passes only");
   const int64_t n = p.d.n, inner = p.d.inner, outer = p.d.batch / p.d.inner;

@@ -56,11 +56,14 @@ def test_c5_uneven_hermitian_split_at_grid_4x2(shape):
     def geometry(comm):
         fft = PFFT(comm, shape, dtype='f', grid=[4, 2, 1])
         t = fft.transfer[0]
-        out = (t.comm.Get_size(), t.subshapeB[2], fft.forward.output_array.shape)
+        out = (t.comm.Get_size(), t.subshapeB[2], fft.forward.output_array.shape, t.packedA, t.packedB)
         fft.destroy()
         return out
     geo = thread_comm.run(8, geometry)
     assert [g[0] for g in geo] == [2] * 8
+    # the r2c kernel writes the uneven 513 | 512-style blocks of the exchange buffer itself whenever
+    # the real length has a packed-real plan (gfft_plan_set_split on MODE_R2C_H): no pack kernel
+    assert all(g[3] == (shape[2] in (64, 128)) for g in geo), [g[3] for g in geo]
     big, small = nh - nh // 2, nh // 2
     assert [g[1] for g in geo] == [big, small] * 4      # rank r sits in grid column r % 2
     assert geo[7][2] == (shape[0], shape[1] // 4, small)

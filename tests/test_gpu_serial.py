@@ -376,8 +376,12 @@ def test_split_layout_plans(shape, axis, dt):
 def test_split_layout_refusals():
     from mpi4py_fft_amd import fftw, asdevice, zeros
     a = asdevice(O.rng_array((8, 16, 32), 'd', 1))
-    r = fftw.rfftn(a, axes=(2,))
-    assert r.set_split(1, 2) is False                    # real transform
+    r = fftw.rfftn(a, axes=(1,))
+    assert r.set_split(1, 2) is False                    # real transform along a strided axis
+    r2 = fftw.rfftn(a, axes=(2,))
+    assert r2.set_split(0, 2) is False                   # the REAL side of a packed-real row plan
+    assert r2.set_split(1, 9) is False                   # more than 8 blocks
+    r2.destroy()
     c = asdevice(O.rng_array((8, 16, 32), 'D', 1))
     p2 = fftw.fftn(c, axes=(1, 2))
     assert p2.set_split(1, 2) is False                   # two passes
@@ -417,3 +421,38 @@ def test_pinned_staging_round_trip(monkeypatch):
         u[...] = h.astype('F' if dt == 'D' else 'd')          # dtype conversion on the way in
         assert np.allclose(np.asarray(u), h, rtol=1e-6)
     array._pinned.clear()
+
+
+@pytest.mark.parametrize('dt', ['d', 'f'])
+@pytest.mark.parametrize('n', [32, 64, 1024, 96, 40])
+def test_packed_real_rows_address_uneven_exchange_blocks(n, dt):
+    """gfft_plan_set_split on packed-real row plans: the r2c kernel writes, and the c2r kernel reads,
+    the half spectrum (n/2 + 1 entries, never an even split) as the all-to-all buffer gfft_pack
+    produces for p = 2 ... 8 ranks -- bit for bit."""
+    from mpi4py_fft_amd import fftw, asdevice, zeros, _lib
+    shape = (6, 5, n)
+    nh = n // 2 + 1
+    cdt = 'D' if dt == 'd' else 'F'
+    a = asdevice(O.rng_array(shape, dt, 21))
+    nat = fftw.rfftn(a, axes=(2,))
+    want = nat.execute_scaled(a, nat.output_array, 0.25)
+    eng = _lib.engine()
+    for p in (2, 3, 4, 5, 7, 8):
+        packed_want = zeros((6, 5, nh), cdt)
+        eng.pack(want.tensor, packed_want.tensor, (6, 5, nh), 2, p, np.dtype(cdt).itemsize)
+        plan = fftw.rfftn(a, axes=(2,), output_array=zeros((6, 5, nh), cdt))
+        assert plan.set_split(1, p)
+        got = plan.execute_scaled(a, plan.output_array, 0.25)
+        assert np.array_equal(np.asarray(got), np.asarray(packed_want)), (n, dt, p, 'r2c store')
+        plan.destroy()
+        # c2r reading the same buffer gives what it gives on the natural half spectrum
+        back_nat = fftw.irfftn(want, s=(n,), axes=(2,), output_array=zeros(shape, dt))
+        ref = np.asarray(back_nat.execute_scaled(want, back_nat.output_array, 1.0)).copy()
+        back = fftw.irfftn(packed_want, s=(n,), axes=(2,), output_array=zeros(shape, dt))
+        assert back.set_split(0, p)
+        got = np.asarray(back.execute_scaled(packed_want, back.output_array, 1.0))
+        # (two instantiations of the kernel: the compiler may contract multiply-adds differently)
+        assert np.abs(got - ref).max() <= (1e-13 if dt == 'd' else 1e-5) * np.abs(ref).max(), (n, dt, p, 'c2r load')
+        back.destroy()
+        back_nat.destroy()
+    nat.destroy()
