@@ -491,7 +491,8 @@ def main():
         # on libgfft's own RCCL communicators (pipeline.py).
         variants = [] if args.no_tune else [('measured routes', dict(wire='torch')),
                                            ('pipelined', dict(wire='auto', exchange='direct')),
-                                           ('pipelined routed', dict(wire='auto', exchange='relay'))]
+                                           ('pipelined routed', dict(wire='auto', exchange='relay')),
+                                           ('pipelined on torch.distributed', dict(wire='overlap', exchange='direct'))]
         for label, kw in variants:
             state['phase'] = label
             try:

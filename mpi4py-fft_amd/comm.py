@@ -167,6 +167,38 @@ class NativeWire:
         self.sendrecv([(send_ptr + j * block_bytes, block_bytes, j) for j in range(n)],
                       [(recv_ptr + j * block_bytes, block_bytes, j) for j in range(n)], stream)
 
+    # ---- what pipeline.Pipeline calls (same on TorchWire) --------------------------------------
+    owns_stream = True      # exchanges are enqueued on a stream the caller passes and orders itself
+
+    def exchange_chunk(self, send, send_off, recv, recv_off, block_bytes, stream):
+        """Equal-block all-to-all between byte ranges of two device tensors (uint8 views)."""
+        self.alltoall_blocks(send.data_ptr() + send_off, recv.data_ptr() + recv_off, block_bytes, stream)
+        return None
+
+
+class TorchWire:
+    """The same chunk exchange on a torch.distributed process group (backend nccl = RCCL, or gloo on
+    development boxes): `dist.all_to_all_single` on the chunk's region, asynchronous -- the backend runs it
+    on its own stream after the work already queued on the current stream, and the returned handle's
+    wait() makes the current stream wait for it (no host synchronisation on nccl).  Lets the chunked
+    pipeline of pipeline.py run where libgfft's own RCCL binding is not available."""
+    owns_stream = False
+
+    def __init__(self, comm):
+        self._comm = comm
+        self.size, self.rank = comm.Get_size(), comm.Get_rank()
+
+    def exchange_chunk(self, send, send_off, recv, recv_off, block_bytes, stream):
+        n = self.size
+        # a chunk region is its p equal blocks back to back: one contiguous equal-split all-to-all
+        return self._comm.alltoall_views(recv[recv_off: recv_off + n * block_bytes],
+                                         send[send_off: send_off + n * block_bytes])
+
+
+def torch_wires(subcomm):
+    """TorchWire (or None for single-rank axes) per entry of a Subcomm tuple."""
+    return [TorchWire(c) if (c.Get_size() > 1 and hasattr(c, 'alltoall_views')) else None for c in subcomm]
+
 
 def native_wires(subcomm):
     """NativeWire (or None for single-rank axes) per entry of a Subcomm tuple.  COLLECTIVE over
@@ -295,6 +327,11 @@ class TorchComm(Comm):
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+
+    def alltoall_views(self, out, inp):
+        """Asynchronous equal-split all-to-all between two contiguous 1-D views; returns the work
+        handle (wait() orders the current stream behind it on nccl)."""
+        return self._dist.all_to_all_single(out, inp, group=self._pg, async_op=True)
 
     def alltoall_async(self, send, recv, send_counts, recv_counts):
         """Non-blocking variant: returns a handle with ``wait()``.  On the nccl backend the

@@ -179,8 +179,10 @@ class PFFT:
         'auto' (time both at the first call and keep the faster).  Default: the GFFT_RELAY
         environment switch, else 'auto'.
     wire : 'native' = chunked redistributions overlapped with the serial transforms on libgfft's
-        own RCCL communicators (pipeline.py); 'torch' = the staged path on torch.distributed's
-        collectives.  Default: GFFT_WIRE, else 'auto' (native when the grid runs on RCCL).
+        own RCCL communicators (pipeline.py); 'overlap' = the same pipeline on asynchronous
+        torch.distributed all-to-alls; 'torch' = the staged path on torch.distributed's collectives.
+        Default: GFFT_WIRE, else 'auto' (native when the grid runs on RCCL, 'overlap' if libgfft
+        cannot bind an RCCL library).
     fuse : single-GPU transforms run as one all-axes plan (default True)
     fuse_pack : serial transforms write / read the exchange buffers directly (default True)
     """
@@ -263,12 +265,15 @@ class PFFT:
         if parent is None or (mode == 'auto' and parent.backend != 'nccl'):
             return None
         from . import pipeline
+        if mode == 'overlap':
+            # the chunked pipeline on torch.distributed's own collectives (asynchronous all_to_all)
+            return pipeline.Pipeline.build(self, _comm.torch_wires(self.subcomm), 'direct')
         try:
             wires = _comm.native_wires(self.subcomm)
         except Exception:
             if mode == 'native':
                 raise
-            return None
+            return pipeline.Pipeline.build(self, _comm.torch_wires(self.subcomm), 'direct')
         return pipeline.Pipeline.build(self, wires, exchange)
 
     # ---- planning steps (what mpifft.py:202-347 decides, one decision per helper) ---------------

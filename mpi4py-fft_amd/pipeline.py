@@ -31,6 +31,11 @@ import numpy as np
 from . import _lib
 
 
+def _bytes(t):
+    import torch
+    return (torch.view_as_real(t) if t.is_complex() else t).reshape(-1).view(torch.uint8)
+
+
 def _cstrides(shape):
     st, acc = [], 1
     for n in reversed(shape):
@@ -198,6 +203,7 @@ class Pipeline:
         self.M = [x.M for x in stages]
         self.comm_stream = torch.cuda.Stream()
         self._events = {}
+        self._works = {}
         if str(exchange).lower() in ('relay', '1', 'on'):
             self._plan_relays(pfft, lay_out)
         return self
@@ -288,10 +294,10 @@ class Pipeline:
             send_whole = t_next is not None and t_next['p'] > 1 and st.iter_side != 'out'
             for c in range(st.nchunks):
                 if arrives and st.iter_side == 'in':
-                    compute.wait_event(self._event((tag, 'x', pos - 1, c)))      # chunk c has arrived
+                    self._arrived(compute, tag, pos - 1, c)                      # chunk c has arrived
                 elif arrives and c == 0:
                     for cc in range(st.lay_in.K):                                # walks its output: needs it all
-                        compute.wait_event(self._event((tag, 'x', pos - 1, cc)))
+                        self._arrived(compute, tag, pos - 1, cc)
                 eng.execute_ptr(st.plan, pin + c * st.step_in * isz, pout + c * st.step_out * isz, scale)
                 if st.iter_side == 'out':
                     # chunk c of the send buffer is complete: put it on the wire
@@ -304,17 +310,32 @@ class Pipeline:
                                    record=(c == 0))
         return dst if dst is not None else (self.out_buf[L - 1] if forward else self.in_buf[0])
 
+    def _arrived(self, compute, tag, pos, c):
+        """Make the compute stream wait for chunk c of the exchange after stage position `pos`."""
+        work = self._works.pop((tag, pos, c), None)
+        if work is not None:
+            work.wait()                    # torch.distributed handle: orders the CURRENT stream
+        else:
+            compute.wait_event(self._event((tag, 'x', pos, c)))
+
     def _exchange(self, tag, pos, c, t, lay, send_ptr, forward, i, compute, cs, cs_raw, record=True):
         """Chunk c of the redistribution after stage position `pos`: wait (on the communication
         stream) for the compute stream's work so far, all-to-all the chunk, signal its arrival."""
+        j = i + 1 if forward else i - 1                       # the receiving stage
+        recv_t = self.in_buf[j] if forward else self.out_buf[j]
+        isz = self.isz
+        off = c * lay.chunk * isz
+        wire = t['wire']
+        if not wire.owns_stream:
+            # torch.distributed orders the collective after the current (compute) stream by itself
+            send_t = self.out_buf[i] if forward else self.in_buf[i]
+            self._works[(tag, pos, c)] = wire.exchange_chunk(_bytes(send_t), off, _bytes(recv_t), off, lay.block * isz, None)
+            return
         if record:
             ev = self._event((tag, 'k', pos, c))
             ev.record(compute)
             cs.wait_event(ev)
-        j = i + 1 if forward else i - 1                       # the receiving stage
-        recv = (self.in_buf[j] if forward else self.out_buf[j]).data_ptr()
-        isz = self.isz
-        off = c * lay.chunk * isz
+        recv = recv_t.data_ptr()
         rl = t.get('relay')
         if rl is None:
             t['wire'].alltoall_blocks(send_ptr + off, recv + off, lay.block * isz, cs_raw)

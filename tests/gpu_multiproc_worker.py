@@ -40,6 +40,27 @@ def main():
             back = np.asarray(fft.backward())
             assert np.abs(back - G[fft.local_slice(False)]).max() <= 100 * tol
         fft.destroy()
+    # the chunked, stream-overlapped pipeline (pipeline.py) on torch.distributed's asynchronous
+    # all-to-all: same bits as the staged path, across real processes
+    from mpi4py_fft_amd import pipeline
+    pipeline.Pipeline.MIN_CHUNK_BYTES = 0
+    pipeline.Pipeline.MIN_WIDTH = 4
+    os.environ['GFFT_RELAY'] = '0'
+    for shape, dt, kw in (((64, 64, 64), 'D', {}), ((128, 64, 32), 'F', {}), ((64, 64, 128), 'D', dict(grid=(-1,)))):
+        staged = PFFT(world, shape, dtype=dt, wire='torch', **kw)
+        piped = PFFT(world, shape, dtype=dt, wire='overlap', **kw)
+        assert piped.pipeline is not None and any(e['chunks'] > 1 for e in piped.pipeline.describe()), piped.pipeline
+        G = O.rng_array(shape, dt, 9)
+        u = newDistArray(staged, False)
+        u[...] = G[staged.local_slice(False)]
+        a = np.asarray(staged.forward(u)).copy()
+        b = np.asarray(piped.forward(u)).copy()
+        assert np.array_equal(a, b), (shape, dt, kw, 'forward')
+        assert np.array_equal(np.asarray(staged.backward()), np.asarray(piped.backward())), (shape, dt, kw, 'backward')
+        b2 = np.asarray(piped.forward(u)).copy()
+        assert np.array_equal(a, b2)
+        staged.destroy()
+        piped.destroy()
     world.barrier()
     if r == 0:
         print('GPU_MULTIPROC_OK ranks=%d' % P)
