@@ -271,7 +271,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', dest='n', type=int, default=1024, help='cube edge (default: the BASELINE config)')
-    ap.add_argument('--extras-deadline', type=float, default=200.0,
+    ap.add_argument('--extras-deadline', type=float, default=180.0,
                     help='seconds the phases after the headline may take at N > 1')
     ap.add_argument('--no-slab', action='store_true', help='skip the slab-grid extra at N > 1')
     ap.add_argument('--no-tune', action='store_true', help='skip the measured route choice at N > 1')
@@ -489,10 +489,12 @@ def main():
         # all-link exchange on the transform's own buffers and keeps the faster (as FFTW_MEASURE does
         # for serial plans).  (2) the chunked redistribution overlapped with the serial transforms
         # on libgfft's own RCCL communicators (pipeline.py).
+        # (ordered from the most conservative wire to the least tried one: a hang in a later one only
+        # loses the ones after it)
         variants = [] if args.no_tune else [('measured routes', dict(wire='torch')),
+                                           ('pipelined on torch.distributed', dict(wire='overlap', exchange='direct')),
                                            ('pipelined', dict(wire='auto', exchange='direct')),
-                                           ('pipelined routed', dict(wire='auto', exchange='relay')),
-                                           ('pipelined on torch.distributed', dict(wire='overlap', exchange='direct'))]
+                                           ('pipelined routed', dict(wire='auto', exchange='relay'))]
         for label, kw in variants:
             state['phase'] = label
             try:
