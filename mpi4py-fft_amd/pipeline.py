@@ -44,6 +44,25 @@ def _cstrides(shape):
     return st
 
 
+class _NoStream:
+    """Stand-ins for torch.cuda streams / events where the arrays live in host memory (CPU tests of
+    the pipeline's layouts and exchange plans with a checker engine): everything is synchronous."""
+    cuda_stream = 0
+
+    def wait_event(self, e):
+        pass
+
+    def record(self, stream=None):
+        pass
+
+
+def _streams():
+    import torch
+    if torch.cuda.is_available():
+        return torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Event
+    return _NoStream(), _NoStream(), _NoStream
+
+
 class Layout:
     """Where element (i_0, .., i_{d-1}) of a stage's local array lives, in elements: natural C
     order, or an exchange buffer -- axis `axis` cut into `p` blocks, optionally chunk-major in `K`
@@ -128,7 +147,7 @@ class Pipeline:
     def build(cls, pfft, wires, exchange=None):
         import torch
         stages, transfers = pfft.xfftn, pfft.transfer
-        if not transfers or not torch.cuda.is_available():
+        if not transfers or not (torch.cuda.is_available() or _lib.engine().name != 'hip'):
             return None
         dtype = np.dtype(stages[0].forward.input_array.dtype)
         if dtype.kind != 'c' or len(stages[0].forward.input_array.shape) != 3:
@@ -201,7 +220,7 @@ class Pipeline:
             self.destroy()
             return None
         self.M = [x.M for x in stages]
-        self.comm_stream = torch.cuda.Stream()
+        self.comm_stream = _streams()[1]
         self._events = {}
         self._works = {}
         if str(exchange).lower() in ('relay', '1', 'on'):
@@ -250,10 +269,9 @@ class Pipeline:
 
     # ---------------------------------------------------------------------------------------
     def _event(self, key):
-        import torch
         e = self._events.get(key)
         if e is None:
-            e = self._events[key] = torch.cuda.Event()
+            e = self._events[key] = _streams()[2]()
         return e
 
     def describe(self):
@@ -266,7 +284,7 @@ class Pipeline:
         import torch
         eng = _lib.engine()
         L = len(self.fwd)
-        compute = torch.cuda.current_stream()
+        compute = _streams()[0]
         cs = self.comm_stream
         cs_raw = cs.cuda_stream
         isz = self.isz

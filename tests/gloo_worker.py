@@ -49,6 +49,28 @@ def main():
             assert np.abs(back - G[fft.local_slice(False)]).max() < 1e-12
         fft.destroy()
     assert bool(relayed) == (P > 2)
+    # the chunked pipeline (pipeline.py) on torch.distributed's asynchronous all-to-all: layouts,
+    # chunk offsets, guru-plan geometry and exchange order, against the staged path and the oracle
+    from mpi4py_fft_amd import pipeline
+    pipeline.Pipeline.MIN_CHUNK_BYTES = 0
+    pipeline.Pipeline.MIN_WIDTH = 2
+    os.environ['GFFT_RELAY'] = '0'
+    for shape, dt, kw in (((32, 16, 64), 'D', {}), ((16, 32, 32), 'F', {}), ((32, 32, 16), 'D', dict(grid=(-1,)))):
+        if any(n % 8 for n in shape) and P == 8:
+            continue
+        ref = O.OPFFT(P, shape, dtype=dt, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
+        G = O.rng_array(shape, dt, 17)
+        want = ref.forward(ref.scatter(G))[r]
+        piped = PFFT(world, shape, dtype=dt, wire='overlap', **kw)
+        assert piped.pipeline is not None, (shape, kw)
+        u = newDistArray(piped, False)
+        u[...] = G[piped.local_slice(False)]
+        uh = np.asarray(piped.forward(u))
+        tol = 1e-12 if dt == 'D' else 1e-5
+        assert np.abs(uh - want).max() <= tol * max(1.0, np.abs(want).max()), (shape, dt, kw, np.abs(uh - want).max())
+        back = np.asarray(piped.backward())
+        assert np.abs(back - G[piped.local_slice(False)]).max() <= 10 * tol
+        piped.destroy()
     # DistArray.redistribute over the real communicator (tests/test_darray.py:50-57)
     N = (8, 10, 12)
     sub = Subcomm(world, [0, 0, 1])

@@ -71,6 +71,41 @@ class HostEngine:
             r = np.fft.irfftn(a, s=s, axes=axes) * np.prod(s)
         _np(tout).reshape(h['sizes_out'])[...] = (r * scale).astype(_np(tout).dtype)
 
+    # strided batched 1-D plans on raw addresses (gfft_plan_create_guru / gfft_execute): what the
+    # chunked pipeline (pipeline.py) drives; host memory here, so that its layouts, chunk offsets and
+    # exchange plans can be checked over gloo without a GPU
+    def plan_create_guru(self, precision, kind, dim, howmany, in_blocks=1, in_block_stride=0, out_blocks=1,
+                         out_block_stride=0):
+        n = int(dim[0])
+        if n & (n - 1) or n < 16 or len(howmany) > 3:          # acceptance of the register kernels, roughly
+            return None
+        for nb in (in_blocks, out_blocks):
+            if nb & (nb - 1) or nb > 8 or n % nb:
+                return None
+        return dict(guru=True, precision=precision, kind=kind, dim=tuple(int(x) for x in dim),
+                    howmany=[tuple(int(x) for x in d) for d in howmany], inb=(in_blocks, in_block_stride),
+                    outb=(out_blocks, out_block_stride))
+
+    def execute_ptr(self, h, ptr_in, ptr_out, scale, stream=None):
+        import ctypes
+        n, es_in, es_out = h['dim']
+        cdt = np.complex128 if h['precision'] == 8 else np.complex64
+        isz = np.dtype(cdt).itemsize
+
+        def view(ptr, es, blocks, which):
+            nb, bs = blocks
+            per = n // nb
+            shape = [d[0] for d in h['howmany']] + [nb, per]
+            strides = [d[which] for d in h['howmany']] + [bs if nb > 1 else per * es, es]
+            extent = 1 + sum((sz - 1) * abs(st) for sz, st in zip(shape, strides))
+            flat = np.frombuffer((ctypes.c_char * (extent * isz)).from_address(ptr), dtype=cdt)
+            return np.lib.stride_tricks.as_strided(flat, shape=shape, strides=[st * isz for st in strides])
+        vin = view(ptr_in, es_in, h['inb'], 1)
+        vout = view(ptr_out, es_out, h['outb'], 2)
+        lines = np.ascontiguousarray(vin).reshape(vin.shape[:-2] + (n,))
+        r = np.fft.fft(lines, axis=-1) if h['kind'] == -1 else np.fft.ifft(lines, axis=-1) * n
+        vout[...] = (r * scale).astype(cdt).reshape(vout.shape)
+
     def plan_set_truncation(self, h, n_keep):
         return False
 
