@@ -170,10 +170,6 @@ class NativeWire:
     # ---- what pipeline.Pipeline calls (same on TorchWire) --------------------------------------
     owns_stream = True      # exchanges are enqueued on a stream the caller passes and orders itself
 
-    def exchange_chunk(self, send, send_off, recv, recv_off, block_bytes, stream):
-        """Equal-block all-to-all between byte ranges of two device tensors (uint8 views)."""
-        self.alltoall_blocks(send.data_ptr() + send_off, recv.data_ptr() + recv_off, block_bytes, stream)
-        return None
 
 
 class TorchWire:
@@ -188,11 +184,11 @@ class TorchWire:
         self._comm = comm
         self.size, self.rank = comm.Get_size(), comm.Get_rank()
 
-    def exchange_chunk(self, send, send_off, recv, recv_off, block_bytes, stream):
-        n = self.size
-        # a chunk region is its p equal blocks back to back: one contiguous equal-split all-to-all
-        return self._comm.alltoall_views(recv[recv_off: recv_off + n * block_bytes],
-                                         send[send_off: send_off + n * block_bytes])
+    def exchange_chunk(self, send, send_off, send_sizes, recv, recv_off, recv_sizes):
+        """A chunk region is its p blocks back to back (byte sizes per peer): one all-to-all(v)
+        between two contiguous ranges of the uint8 views `send` / `recv`; returns the work handle."""
+        return self._comm.alltoall_views(recv[recv_off: recv_off + sum(recv_sizes)],
+                                         send[send_off: send_off + sum(send_sizes)], recv_sizes, send_sizes)
 
 
 def torch_wires(subcomm):
@@ -328,10 +324,11 @@ class TorchComm(Comm):
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
 
-    def alltoall_views(self, out, inp):
-        """Asynchronous equal-split all-to-all between two contiguous 1-D views; returns the work
-        handle (wait() orders the current stream behind it on nccl)."""
-        return self._dist.all_to_all_single(out, inp, group=self._pg, async_op=True)
+    def alltoall_views(self, out, inp, out_sizes, in_sizes):
+        """Asynchronous all-to-all(v) between two contiguous 1-D views; returns the work handle
+        (wait() orders the current stream behind it on nccl)."""
+        return self._dist.all_to_all_single(out, inp, [int(n) for n in out_sizes], [int(n) for n in in_sizes],
+                                            group=self._pg, async_op=True)
 
     def alltoall_async(self, send, recv, send_counts, recv_counts):
         """Non-blocking variant: returns a handle with ``wait()``.  On the nccl backend the

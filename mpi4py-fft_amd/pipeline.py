@@ -29,6 +29,7 @@ import os
 import numpy as np
 
 from . import _lib
+from .pencil import _blockdist
 
 
 def _bytes(t):
@@ -123,13 +124,63 @@ class _Stage:
             self.plan = _lib.engine().plan_create_guru(
                 precision, kind, (shape[axis], lay_in.stride[axis], lay_out.stride[axis]), dims,
                 lay_in.p, lay_in.block, lay_out.p, lay_out.block)
-        # element offsets of chunk c on either side
+        # byte offsets of chunk c on either side
+        isz = 2 * precision
         if self.iter_side == 'in':
-            self.step_in, self.step_out = lay_in.chunk, lay_in.width * lay_out.stride[fi]
+            self.step_in, self.step_out = lay_in.chunk * isz, lay_in.width * lay_out.stride[fi] * isz
         elif self.iter_side == 'out':
-            self.step_in, self.step_out = lay_out.width * lay_in.stride[fi], lay_out.chunk
+            self.step_in, self.step_out = lay_out.width * lay_in.stride[fi] * isz, lay_out.chunk * isz
         else:
             self.step_in = self.step_out = 0
+
+    def destroy(self):
+        if self.plan is not None:
+            _lib.engine().plan_destroy(self.plan)
+            self.plan = None
+
+
+class _WholeStage:
+    """A stage run as the staged path runs it: its own natural-layout plan on the whole local array
+    (the real first stage of an r2c transform whose first redistribution is local)."""
+    def __init__(self, plan_handle):
+        self.plan = plan_handle
+        self.nchunks, self.iter_side, self.step_in, self.step_out = 1, None, 0, 0
+        self.lay_in = self.lay_out = type('Side', (), dict(K=1, p=1))()
+
+    def destroy(self):
+        self.plan = None           # owned by the PFFT's stage object
+
+
+class _RealRows:
+    """The real first stage of an r2c transform (last stage of c2r) inside the pipeline: packed-real
+    rows (fft_real_*.hip) run slab by slab along array axis 0, the half-spectrum side being the
+    chunk-major exchange buffer of UNEVEN blocks that gfft_plan_set_split addresses (n/2 + 1
+    entries dealt to p ranks by the block rule).  `forward`: real natural -> buffer, else buffer ->
+    real natural."""
+    def __init__(self, shape, p, K, forward, precision):
+        n0, n1, n = (int(v) for v in shape)
+        nh = n // 2 + 1
+        rows = (n0 // K) * n1
+        eng = _lib.engine()
+        self.plan = None
+        if forward:
+            h = eng.plan_create((rows, n), (rows, nh), (1,), _lib.R2C, precision)
+            ok = eng.plan_set_split(h, 1, p)
+        else:
+            h = eng.plan_create((rows, nh), (rows, n), (1,), _lib.C2R, precision)
+            ok = eng.plan_set_split(h, 0, p)
+        if not ok:
+            eng.plan_destroy(h)
+            return
+        self.plan = h
+        self.nchunks = K
+        self.iter_side = 'out' if forward else 'in'
+        real_step, buf_step = rows * n * precision, rows * nh * 2 * precision
+        self.step_in, self.step_out = (real_step, buf_step) if forward else (buf_step, real_step)
+        # what run() asks of a stage's layouts
+        side = type('Side', (), dict(K=K, p=p))()
+        natural = type('Side', (), dict(K=1, p=1))()
+        self.lay_in, self.lay_out = (natural, side) if forward else (side, natural)
 
     def destroy(self):
         if self.plan is not None:
@@ -149,11 +200,19 @@ class Pipeline:
         stages, transfers = pfft.xfftn, pfft.transfer
         if not transfers or not (torch.cuda.is_available() or _lib.engine().name != 'hip'):
             return None
-        dtype = np.dtype(stages[0].forward.input_array.dtype)
+        dtype = np.dtype(stages[-1].forward.output_array.dtype)          # the complex type of the chain
         if dtype.kind != 'c' or len(stages[0].forward.input_array.shape) != 3:
             return None
-        for x in stages:
-            if len(x.axes) != 1 or x._padded or np.dtype(x.forward.input_array.dtype) != dtype \
+        # an r2c transform: real rows along the last axis first, the rest of the chain complex
+        real0 = np.dtype(stages[0].forward.input_array.dtype).kind == 'f'
+        for k, x in enumerate(stages):
+            if len(x.axes) != 1 or x._padded:
+                return None
+            if k == 0 and real0:
+                if x.axes[0] != 2 or np.dtype(x.forward.output_array.dtype) != dtype:
+                    return None
+                continue
+            if np.dtype(x.forward.input_array.dtype) != dtype \
                     or tuple(x.forward.input_array.shape) != tuple(x.forward.output_array.shape):
                 return None
         nd = 3
@@ -170,20 +229,30 @@ class Pipeline:
             wire = by_ranks.get(tuple(t.comm._ranks))
             if wire is None or wire.size != p or p & (p - 1) or p > 8:
                 return None
-            if t.subshapeA[a] % p or t.subshapeB[b] % p:
+            uneven = real0 and i == 0            # the half spectrum never splits evenly: block rule
+            if (t.subshapeA[a] % p and not uneven) or t.subshapeB[b] % p:
                 return None
             free = [d for d in range(nd) if d not in (a, b)]
             f = free[0]
+            if uneven and (a != 2 or f != 0):
+                return None
             nf = t.subshapeA[f]
+            if real0 and i > 0 and f == 2 and plan and plan[0].get('uneven'):
+                # the free axis is the half-spectrum axis, whose local width differs from rank to
+                # rank: every rank must cut the same number of chunks (routed exchanges involve the
+                # whole grid), so only a common divisor of all widths qualifies
+                nf = int(np.gcd.reduce(plan[0]['widths']))
             K = 1
             nbytes = int(np.prod(t.subshapeA, dtype=np.int64)) * isz
             for k in range(min(cls.CHUNKS, nf), 1, -1):
                 if nf % k == 0 and nf // k >= cls.MIN_WIDTH and nbytes // k >= cls.MIN_CHUNK_BYTES:
                     K = k
                     break
-            plan.append(dict(p=p, wire=wire, f=f, K=K, a=a, b=b, comm=t.comm))
+            plan.append(dict(p=p, wire=wire, f=f, K=K, a=a, b=b, comm=t.comm, uneven=uneven,
+                             widths=[_blockdist(t.shape[a], p, r)[0] for r in range(p)] if uneven else None))
         if all(e['p'] == 1 for e in plan):
             return None
+
         self = cls()
         self.pfft = pfft
         self.dtype, self.isz = dtype, isz
@@ -207,18 +276,40 @@ class Pipeline:
                 lay_in.append(Layout(shape, ax, e['p'], e['f'], e['K']))
             else:
                 lay_in.append(Layout(shape))
-            if i < L - 1 and plan[i]['p'] > 1:
+            if i < L - 1 and plan[i]['p'] > 1 and not plan[i]['uneven']:
                 e = plan[i]
                 lay_out.append(Layout(shape, ax, e['p'], e['f'], e['K']))
             else:
-                lay_out.append(Layout(shape))
+                lay_out.append(Layout(shape))            # (uneven: described by _RealRows / e['A'])
         self.fwd = [_Stage(tuple(x.forward.input_array.shape), x.axes[0], lay_in[i], lay_out[i], -1, self.precision)
-                    for i, x in enumerate(stages)]
+                    for i, x in enumerate(stages) if not (real0 and i == 0)]
         self.bwd = [_Stage(tuple(x.forward.input_array.shape), x.axes[0], lay_out[i], lay_in[i], +1, self.precision)
-                    for i, x in enumerate(stages)]
+                    for i, x in enumerate(stages) if not (real0 and i == 0)]
+        if real0 and plan[0]['p'] > 1:
+            shape0 = tuple(stages[0].forward.input_array.shape)
+            self.fwd.insert(0, _RealRows(shape0, plan[0]['p'], plan[0]['K'], True, self.precision))
+            self.bwd.insert(0, _RealRows(shape0, plan[0]['p'], plan[0]['K'], False, self.precision))
+        elif real0:
+            # local first redistribution (slab-like grids): the real stage keeps its natural plan
+            self.fwd.insert(0, _WholeStage(stages[0].fwd._plan))
+            self.bwd.insert(0, _WholeStage(stages[0].bck._plan))
         if any(s.plan is None for s in self.fwd + self.bwd):
             self.destroy()
             return None
+        # per redistribution: bytes of one chunk region and of the per-peer messages, on the side of
+        # the earlier stage (A) and of the later one (B); forward sends A -> B, backward B -> A
+        for i, e in enumerate(plan):
+            if e['p'] == 1:
+                continue
+            lb = lay_in[i + 1]
+            e['B'] = dict(chunk=lb.chunk * isz, sizes=[lb.block * isz] * e['p'])
+            if e['uneven']:
+                n0, n1l = stages[0].forward.input_array.shape[:2]
+                rows = (n0 // e['K']) * n1l
+                e['A'] = dict(chunk=rows * sum(e['widths']) * isz, sizes=[rows * w * isz for w in e['widths']])
+            else:
+                la = lay_out[i]
+                e['A'] = dict(chunk=la.chunk * isz, sizes=[la.block * isz] * e['p'])
         self.M = [x.M for x in stages]
         self.comm_stream = _streams()[1]
         self._events = {}
@@ -249,18 +340,37 @@ class Pipeline:
             g = next(k for k, c in enumerate(pfft.subcomm) if c.Get_size() > 1 and tuple(c._ranks) == tuple(e['comm']._ranks))
             if pwire is None:
                 pwire = _comm.NativeWire.create(parent)
-            per_peer = lay_out[i].block * 2                      # real scalars per (chunk, peer) message
-            meta = []
+            # real scalars per (chunk, peer) message, forward (A -> B) and backward (B -> A): equal
+            # everywhere for complex stages; behind a real first stage rank a sends w_j-wide blocks
+            # forward and w_a-wide blocks backward
+            rows_b = e['B']['sizes'][0] // scalar            # my backward message, scalars
+            meta_f, meta_b = [], []
+            # behind a real first stage the local half-spectrum width differs from rank to rank
+            # (block rule over the first redistribution's communicator): later messages scale with it
+            e0 = self.tplan[0]
+            wide = e0.get('uneven') and i > 0
+            if wide:
+                g0 = next(k for k, c in enumerate(pfft.subcomm) if c.Get_size() > 1 and tuple(c._ranks) == tuple(e0['comm']._ranks))
+                w_me = e0['widths'][np.unravel_index(me, dims)[g0]]
             for a in range(W):
                 coords = list(np.unravel_index(a, dims))
+                va = coords[g]
+                if wide:
+                    rows_b = e['B']['sizes'][0] // scalar // w_me * e0['widths'][coords[g0]]
                 members = []
                 for v in range(dims[g]):
                     coords[g] = v
                     members.append(int(np.ravel_multi_index(coords, dims)))
-                meta.append((tuple(members), [per_peer] * dims[g]))
-            sched = _relay.Schedule(meta, me)
-            nbytes = max(1, sched.relay_size) * scalar
-            e['relay'] = dict(wire=pwire, sched=sched, scalar=scalar,
+                if e['uneven']:
+                    unit = e['A']['sizes'][0] // e['widths'][0] // scalar      # scalars per column
+                    meta_f.append((tuple(members), [unit * w for w in e['widths']]))
+                    meta_b.append((tuple(members), [unit * e['widths'][va]] * dims[g]))
+                else:
+                    meta_f.append((tuple(members), [rows_b] * dims[g]))
+                    meta_b.append((tuple(members), [rows_b] * dims[g]))
+            sf, sb = _relay.Schedule(meta_f, me), _relay.Schedule(meta_b, me)
+            nbytes = max(1, sf.relay_size, sb.relay_size) * scalar
+            e['relay'] = dict(wire=pwire, sched={True: sf, False: sb}, scalar=scalar,
                               buf=torch.empty(2 * nbytes, dtype=torch.uint8, device='cuda'), bytes=nbytes)
 
     def destroy(self):
@@ -316,16 +426,15 @@ class Pipeline:
                 elif arrives and c == 0:
                     for cc in range(st.lay_in.K):                                # walks its output: needs it all
                         self._arrived(compute, tag, pos - 1, cc)
-                eng.execute_ptr(st.plan, pin + c * st.step_in * isz, pout + c * st.step_out * isz, scale)
+                eng.execute_ptr(st.plan, pin + c * st.step_in, pout + c * st.step_out, scale)
                 if st.iter_side == 'out':
                     # chunk c of the send buffer is complete: put it on the wire
-                    self._exchange(tag, pos, c, t_next, st.lay_out, pout, forward, i, compute, cs, cs_raw)
+                    self._exchange(tag, pos, c, t_next, pout, forward, i, compute, cs, cs_raw)
             if send_whole:
                 # this stage filled every chunk of its send buffer (it walked its INPUT chunks):
                 # all chunks go on the wire now, the next stage picks them up one by one
                 for c in range(st.lay_out.K):
-                    self._exchange(tag, pos, c, t_next, st.lay_out, pout, forward, i, compute, cs, cs_raw,
-                                   record=(c == 0))
+                    self._exchange(tag, pos, c, t_next, pout, forward, i, compute, cs, cs_raw, record=(c == 0))
         return dst if dst is not None else (self.out_buf[L - 1] if forward else self.in_buf[0])
 
     def _arrived(self, compute, tag, pos, c):
@@ -336,18 +445,19 @@ class Pipeline:
         else:
             compute.wait_event(self._event((tag, 'x', pos, c)))
 
-    def _exchange(self, tag, pos, c, t, lay, send_ptr, forward, i, compute, cs, cs_raw, record=True):
+    def _exchange(self, tag, pos, c, t, send_ptr, forward, i, compute, cs, cs_raw, record=True):
         """Chunk c of the redistribution after stage position `pos`: wait (on the communication
         stream) for the compute stream's work so far, all-to-all the chunk, signal its arrival."""
         j = i + 1 if forward else i - 1                       # the receiving stage
         recv_t = self.in_buf[j] if forward else self.out_buf[j]
-        isz = self.isz
-        off = c * lay.chunk * isz
+        snd, rcv = (t['A'], t['B']) if forward else (t['B'], t['A'])
+        soff, roff = c * snd['chunk'], c * rcv['chunk']
         wire = t['wire']
+        K = t['K']
         if not wire.owns_stream:
             # torch.distributed orders the collective after the current (compute) stream by itself
             send_t = self.out_buf[i] if forward else self.in_buf[i]
-            self._works[(tag, pos, c)] = wire.exchange_chunk(_bytes(send_t), off, _bytes(recv_t), off, lay.block * isz, None)
+            self._works[(tag, pos, c)] = wire.exchange_chunk(_bytes(send_t), soff, snd['sizes'], _bytes(recv_t), roff, rcv['sizes'])
             return
         if record:
             ev = self._event((tag, 'k', pos, c))
@@ -356,15 +466,21 @@ class Pipeline:
         recv = recv_t.data_ptr()
         rl = t.get('relay')
         if rl is None:
-            t['wire'].alltoall_blocks(send_ptr + off, recv + off, lay.block * isz, cs_raw)
+            sends, recvs, so, ro = [], [], soff, roff
+            for peer in range(t['p']):
+                sends.append((send_ptr + so, snd['sizes'][peer], peer))
+                recvs.append((recv + ro, rcv['sizes'][peer], peer))
+                so += snd['sizes'][peer]
+                ro += rcv['sizes'][peer]
+            wire.sendrecv(sends, recvs, cs_raw)
             self._event((tag, 'x', pos, c)).record(cs)
             return
         # routed: batch c carries round 1 of chunk c and round 2 of chunk c - 1; the batch after the
         # last chunk carries the last round 2
-        sc, sched, K = rl['scalar'], rl['sched'], lay.K
+        sc, sched = rl['scalar'], rl['sched'][forward]
 
         def msgs(lst, chunk):
-            base = {'send': send_ptr + chunk * lay.chunk * isz, 'recv': recv + chunk * lay.chunk * isz,
+            base = {'send': send_ptr + chunk * snd['chunk'], 'recv': recv + chunk * rcv['chunk'],
                     'relay': rl['buf'].data_ptr() + (chunk & 1) * rl['bytes']}
             return [(base[b] + o * sc, n * sc, peer) for b, o, n, peer in lst]
         sends, recvs = [], []
@@ -376,8 +492,8 @@ class Pipeline:
         if sched.self_copy is not None:
             so, ro, n = sched.self_copy
             me = rl['wire'].rank
-            sends.append((send_ptr + off + so * sc, n * sc, me))
-            recvs.append((recv + off + ro * sc, n * sc, me))
+            sends.append((send_ptr + soff + so * sc, n * sc, me))
+            recvs.append((recv + roff + ro * sc, n * sc, me))
         rl['wire'].sendrecv(sends, recvs, cs_raw)
         if c >= 1:
             self._event((tag, 'x', pos, c - 1)).record(cs)

@@ -46,10 +46,14 @@ def main():
     pipeline.Pipeline.MIN_CHUNK_BYTES = 0
     pipeline.Pipeline.MIN_WIDTH = 4
     os.environ['GFFT_RELAY'] = '0'
-    for shape, dt, kw in (((64, 64, 64), 'D', {}), ((128, 64, 32), 'F', {}), ((64, 64, 128), 'D', dict(grid=(-1,)))):
+    for shape, dt, kw in (((64, 64, 64), 'D', {}), ((128, 64, 32), 'F', {}), ((64, 64, 128), 'D', dict(grid=(-1,))),
+                          ((64, 64, 64), 'd', {}), ((64, 64, 128), 'f', {})):
         staged = PFFT(world, shape, dtype=dt, wire='torch', **kw)
         piped = PFFT(world, shape, dtype=dt, wire='overlap', **kw)
-        assert piped.pipeline is not None and any(e['chunks'] > 1 for e in piped.pipeline.describe()), piped.pipeline
+        assert piped.pipeline is not None, (shape, dt, kw)
+        # (on two ranks a real transform's only redistribution runs along the ragged half-spectrum
+        # axis -- 33 | 32 columns -- which no common chunk count divides: one chunk there)
+        assert any(e['chunks'] > 1 for e in piped.pipeline.describe()) or (dt in 'df' and P == 2), piped.pipeline.describe()
         G = O.rng_array(shape, dt, 9)
         u = newDistArray(staged, False)
         u[...] = G[staged.local_slice(False)]

@@ -124,7 +124,7 @@ def test_transforms_that_do_not_qualify_keep_the_staged_path(monkeypatch):
 
     def body(comm):
         out = []
-        for shape, dt, kw in (((64, 64, 64), 'd', {}), ((48, 64, 60), 'D', {}),
+        for shape, dt, kw in (((64, 64, 66), 'd', {}), ((48, 64, 60), 'D', {}),
                               ((64, 64, 64), 'D', dict(padding=[1.5, 1.5, 1.5])), ((32, 32), 'D', {})):
             f = PFFT(comm, shape, dtype=dt, wire='native', **kw)
             out.append(f.pipeline is None)
@@ -165,3 +165,47 @@ def test_pipelined_routed_exchange_is_bit_identical(P, shape, chunks, monkeypatc
     for a, b, ab, bb, b2, info in cases.run_ranks(P, body):
         assert [e['route'] for e in info if e['ranks'] > 1] == ['relay'] * sum(1 for e in info if e['ranks'] > 1), info
         assert np.array_equal(a, b) and np.array_equal(ab, bb) and np.array_equal(a, b2)
+
+
+@pytest.mark.parametrize('P,shape', [(2, (64, 64, 64)), (4, (64, 64, 128)), (8, (64, 64, 64)), (8, (128, 64, 256))])
+@pytest.mark.parametrize('dt', ['d', 'f'])
+@pytest.mark.parametrize('exchange', ['direct', 'relay'])
+def test_pipelined_r2c_transform(P, shape, dt, exchange, monkeypatch):
+    """r2c / c2r through the pipeline (config C5 in small): packed-real rows run slab by slab and
+    write the chunk-major exchange buffer of UNEVEN blocks (n/2 + 1 entries over p ranks) themselves;
+    the first exchange is an all-to-all(v).  Same bits as the staged path."""
+    from mpi4py_fft_amd import PFFT, newDistArray, pipeline
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_CHUNK_BYTES', 0)
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_WIDTH', 4)
+    G = O.rng_array(shape, dt, 23)
+
+    def body(comm):
+        staged = PFFT(comm, shape, dtype=dt, wire='torch', exchange='direct')
+        piped = PFFT(comm, shape, dtype=dt, wire='native', exchange=exchange)
+        assert piped.pipeline is not None
+        info = piped.pipeline.describe()
+        u = newDistArray(staged, False)
+        u[...] = G[staged.local_slice(False)]
+        a = np.asarray(staged.forward(u)).copy()
+        b = np.asarray(piped.forward(u)).copy()
+        out = newDistArray(piped, True)
+        piped.forward(u, out)
+        c = np.asarray(out).copy()
+        ab = np.asarray(staged.backward()).copy()
+        bb = np.asarray(piped.backward()).copy()
+        back = newDistArray(piped, False)
+        piped.backward(out, back)
+        bc = np.asarray(back).copy()
+        staged.destroy()
+        piped.destroy()
+        return a, b, c, ab, bb, bc, info
+    res = cases.run_ranks(P, body)
+    ref = O.OPFFT(P, shape, dtype=dt)
+    want = ref.forward(ref.scatter(G))
+    for r, (a, b, c, ab, bb, bc, info) in enumerate(res):
+        assert any(e['chunks'] > 1 for e in info), info
+        if exchange == 'relay' and P > 2:
+            assert any(e['route'] == 'relay' for e in info), info
+        assert np.array_equal(a, b) and np.array_equal(a, c), (P, shape, dt, r)
+        assert np.array_equal(ab, bb) and np.array_equal(ab, bc)
+        assert np.abs(a - want[r]).max() <= cases.tol_for(dt) * np.abs(want[r]).max()
