@@ -6,10 +6,23 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tests import cases
 
+# the pipelined path on libgfft's own wire needs an RCCL that accepts several ranks per GPU: the
+# in-process stand-in of tests/fake_rccl (built on demand)
+import subprocess
+from mpi4py_fft_amd import _lib, pipeline
+_here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'fake_rccl')
+_so = os.path.join(_here, 'libfake_rccl.so')
+if not os.path.exists(_so):
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '-O2', '-std=c++17', '-fPIC', '-shared', '-x', 'hip',
+                           '--offload-arch=gfx950', os.path.join(_here, 'fake_rccl.cpp'), '-o', _so])
+_lib.check_wire(_lib.lib().gfft_rccl_load(_so.encode()))
+pipeline.Pipeline.MIN_CHUNK_BYTES = 0
+pipeline.Pipeline.MIN_WIDTH = 4
+
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 rng = np.random.default_rng(seed)
-pool = [8, 12, 13, 16, 16, 18, 24, 27, 28, 32, 32, 40, 48, 56, 64, 64, 96, 128]
+pool = [8, 12, 13, 16, 16, 18, 24, 27, 28, 32, 32, 32, 40, 48, 56, 64, 64, 64, 96, 128, 128]
 t0, done, skipped = time.time(), 0, 0
 while time.time() - t0 < budget:
     nd = int(rng.choice([2, 3, 3, 3, 4]))
@@ -35,6 +48,8 @@ while time.time() - t0 < budget:
         kw['r2r'] = {(i,): int(rng.integers(3, 11)) for i in range(first, nd)}
     os.environ['GFFT_RELAY'] = str(rng.choice(['0', '1', 'measure']))
     os.environ['GFFT_FUSE_PACK'] = str(rng.choice(['0', '1', '1']))
+    os.environ['GFFT_WIRE'] = str(rng.choice(['torch', 'native', 'native']))
+    pipeline.Pipeline.CHUNKS = int(rng.choice([1, 2, 3, 4]))
     try:
         cases.check_pfft_vs_oracle(P, shape, dt, seed=int(rng.integers(1 << 30)), **kw)
         done += 1
@@ -43,12 +58,12 @@ while time.time() - t0 < budget:
         if msg == '' or 'size' in msg or 'assert n >= size' in msg:
             skipped += 1
             continue
-        print('FAIL', P, shape, dt, kw, os.environ['GFFT_RELAY'], os.environ['GFFT_FUSE_PACK'], msg[:300], flush=True)
+        print('FAIL', P, shape, dt, kw, os.environ['GFFT_RELAY'], os.environ['GFFT_FUSE_PACK'], os.environ['GFFT_WIRE'], msg[:300], flush=True)
         raise
     except RuntimeError as e:
         if 'AssertionError' in str(e) and 'n >= size' in str(e):
             skipped += 1
             continue
-        print('FAIL', P, shape, dt, kw, os.environ['GFFT_RELAY'], os.environ['GFFT_FUSE_PACK'], flush=True)
+        print('FAIL', P, shape, dt, kw, os.environ['GFFT_RELAY'], os.environ['GFFT_FUSE_PACK'], os.environ['GFFT_WIRE'], flush=True)
         raise
 print('stress seed %d: %d configurations checked, %d skipped (invalid for the rank count), %.0f s' % (seed, done, skipped, time.time() - t0))
