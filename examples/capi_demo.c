@@ -132,6 +132,77 @@ int main(void) {
     free(back);
     free(spec);
   }
+  /* 4. the exchange entries on a communicator of ONE rank (a plain C host has no launcher here;
+   *    with MPI, rank 0 would MPI_Bcast the id): RCCL is bound at run time, the communicator is
+   *    created and split by the real library, and an uneven all-to-all(v) to oneself plus a strided
+   *    guru plan run on a stream the host owns. */
+  {
+    char info[256], id[GFFT_UNIQUE_ID_BYTES];
+    int rc = gfft_rccl_info(info, sizeof info);
+    if (rc == GFFT_ERR_UNSUPPORTED) {
+      printf("exchange: no RCCL library on this host (%s) -- skipped\n", gfft_exchange_last_error());
+    } else {
+      CHECK(rc);
+      printf("exchange: RCCL bound from %s\n", info);
+      gfft_comm world = NULL, line = NULL;
+      CHECK(gfft_comm_get_unique_id(id));
+      CHECK(gfft_comm_create(&world, id, 1, 0));
+      CHECK(gfft_comm_split(world, 0, 0, &line));
+      int r = -1, n = -1;
+      CHECK(gfft_comm_rank(line, &r, &n));
+      if (r != 0 || n != 1) return 1;
+      void *stream = NULL, *ev = NULL;
+      CHECK(gfft_stream_create(&stream));
+      CHECK(gfft_event_create_untimed(&ev));
+      const int64_t m = 1000;
+      double *hs = (double *)malloc(m * sizeof(double)), *hr = (double *)malloc(m * sizeof(double));
+      for (int64_t i = 0; i < m; i++) hs[i] = (double)i;
+      void *ds, *dr;
+      CHECK(gfft_malloc(&ds, m * sizeof(double)));
+      CHECK(gfft_malloc(&dr, m * sizeof(double)));
+      CHECK(gfft_memcpy_h2d(ds, hs, m * sizeof(double), NULL));
+      CHECK(gfft_stream_synchronize(NULL));
+      CHECK(gfft_event_record(ev, NULL));
+      CHECK(gfft_stream_wait_event(stream, ev));
+      const int64_t cnt[1] = {700}, sdis[1] = {100}, rdis[1] = {300};
+      CHECK(gfft_alltoallv(line, ds, cnt, sdis, dr, cnt, rdis, (int)sizeof(double), stream));
+      CHECK(gfft_memcpy_d2h(hr, dr, m * sizeof(double), stream));
+      CHECK(gfft_stream_synchronize(stream));
+      for (int64_t i = 0; i < 700; i++)
+        if (hr[300 + i] != hs[100 + i]) { printf("alltoallv mismatch at %lld\n", (long long)i); return 1; }
+      /* guru plan: 64 lines of length 256 stored with stride 64 (a strided axis), out of place */
+      gfft_plan g = NULL;
+      gfft_iodim dim = {256, 64, 64}, hm[1] = {{64, 1, 1}};
+      CHECK(gfft_plan_create_guru(&g, GFFT_F64, GFFT_C2C_FORWARD, &dim, 1, hm, 1, 0, 1, 0));
+      const size_t nel = 256 * 64;
+      double *hx = (double *)calloc(2 * nel, sizeof(double)), *hy = (double *)malloc(2 * nel * sizeof(double));
+      for (int e = 0; e < 256; e++) hx[2 * (e * 64 + 5)] = cos(PI2 * 3 * e / 256.0), hx[2 * (e * 64 + 5) + 1] = sin(PI2 * 3 * e / 256.0);
+      void *dx, *dy;
+      CHECK(gfft_malloc(&dx, 2 * nel * sizeof(double)));
+      CHECK(gfft_malloc(&dy, 2 * nel * sizeof(double)));
+      CHECK(gfft_memcpy_h2d(dx, hx, 2 * nel * sizeof(double), stream));
+      CHECK(gfft_execute(g, dx, dy, 1.0 / 256, stream));
+      CHECK(gfft_memcpy_d2h(hy, dy, 2 * nel * sizeof(double), stream));
+      CHECK(gfft_stream_synchronize(stream));
+      /* column 5 held exp(+2 pi i 3 e / 256): all of it lands in bin 3 */
+      double worst = 0;
+      for (int k = 0; k < 256; k++) {
+        const double want = k == 3 ? 1.0 : 0.0;
+        const double er = fabs(hy[2 * (k * 64 + 5)] - want), ei = fabs(hy[2 * (k * 64 + 5) + 1]);
+        if (er > worst) worst = er;
+        if (ei > worst) worst = ei;
+      }
+      printf("guru plan (256 along a strided axis): max |err| = %.3e\n", worst);
+      if (worst > 1e-14) return 1;
+      CHECK(gfft_plan_destroy(g));
+      CHECK(gfft_free(ds)); CHECK(gfft_free(dr)); CHECK(gfft_free(dx)); CHECK(gfft_free(dy));
+      CHECK(gfft_event_destroy(ev));
+      CHECK(gfft_stream_destroy(stream));
+      CHECK(gfft_comm_destroy(line));
+      CHECK(gfft_comm_destroy(world));
+      free(hs); free(hr); free(hx); free(hy);
+    }
+  }
   printf("capi_demo OK\n");
   return 0;
 }
