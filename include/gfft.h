@@ -24,7 +24,8 @@
  * Scratch and re-entrancy: plans that need a workspace (3-D all-axes plans, multi-axis c2r, four-step
  * and Bluestein lengths) carve it from ONE buffer per (calling thread, stream), shared by every
  * plan that thread executes on that stream and grown -- with a synchronisation of that stream --
- * when a larger request arrives (gfft_scratch_release frees them).  Consequences: (1) a thread may
+ * when a larger request arrives (gfft_scratch_release frees them; so does destroying the last
+ * plan of the process).  Consequences: (1) a thread may
  * run any sequence of plans on a stream; (2) two executions issued by one thread that may overlap
  * in time must be on different streams; (3) the first
  * gfft_execute of the largest plan on a stream allocates, so run each plan once on the stream

@@ -13,6 +13,7 @@
 #include "../../include/gfft.h"
 #include "gfft_internal.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -273,6 +274,8 @@ ScratchPool &scratch_pool() {
   static ScratchPool p;
   return p;
 }
+// plans alive: when the last one goes the shared workspaces go with it (a 1024^3 plan leaves 16 GiB)
+std::atomic<int> g_live_plans{0};
 
 }  // namespace
 
@@ -1124,6 +1127,7 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
   // the scale factor rides on the last pass
   pl->passes.back().carries_scale = true;
   *plan = pl;
+  ++g_live_plans;
   return GFFT_OK;
 }
 
@@ -1169,6 +1173,7 @@ int gfft_plan_create_r2r(gfft_plan *plan, int ndims, const int64_t *sizes, int n
   }
   pl->passes.back().carries_scale = true;
   *plan = pl;
+  ++g_live_plans;
   return GFFT_OK;
 }
 
@@ -1430,6 +1435,7 @@ int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_i
   if (n > 1) pl->flops = 5.0 * (double)n * std::log2((double)n) * batch;
   pl->bytes = batch * (double)n * 4.0 * precision;
   *plan = pl;
+  ++g_live_plans;
   return GFFT_OK;
 }
 
@@ -1439,6 +1445,7 @@ int gfft_scratch_release(void) { return scratch_pool().release(); }
 int gfft_plan_destroy(gfft_plan pl) {
   if (!pl) return GFFT_OK;
   delete pl;
+  if (--g_live_plans == 0) (void)scratch_pool().release();
   return GFFT_OK;
 }
 
