@@ -793,6 +793,10 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
         const cx<real> wb = {w.x * b.x + w.y * b.y, w.x * b.y - w.y * b.x};   // conj(w) b
         v[q] = {a.x - wb.y, -(a.y + wb.x)};                        // conj(a + i conj(w) b)
       });
+      // Pin the line here: left free, the scheduler interleaves this pass with the first butterfly
+      // stage and keeps both generations of the line alive (fp32 R = 16: 175 VGPRs -> 107).
+#pragma unroll
+      for (int q = 0; q < R; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y));
     }
     // (the row index `tl` is laundered for the same reason: fp32 n=1024 R=32 104 bytes of scratch
     // -> none; fp64 n=1024 R=16 T=16 127 -> 107 VGPRs)
