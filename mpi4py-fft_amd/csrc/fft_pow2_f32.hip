@@ -36,23 +36,23 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 2048: return P32F(2048, 16, 8, true, true, 4, 32, 16, 16, 8);
       case 4096: return P32F(4096, 16, 4, true, true, 4, 32, 16, 16, 16);
     }
-  } else if (d.mode == MODE_C2C && d.tr_dir && !d.tw_hi && (d.n == 512 || (variant == 7 && d.tr_dir == 2 && d.n >= 1024))) {
+  } else if (d.mode == MODE_C2C && d.tr_dir && !d.tw_hi && (d.n == 512 || (variant == 7 && d.n >= 1024))) {
     // complex strided passes with fused truncation (store side) / zero padding (load side) on the
-    // 256-byte tiles of the plain passes below.  n = 512 compiles clean (100 / 82 VGPRs); from
-    // n = 1024 the R = 32 plans spill (store side 85-147 VGPRs of scratch, load side 12-31), so they
-    // stay on the shared table's 128-byte tiles unless variant 7 asks for the load side (A/B runs).
+    // 256-byte tiles of the plain passes below.  n = 512 compiles clean (100 / 82 VGPRs).  From
+    // n = 1024 the R = 32 plans fit 128 VGPRs only with 9-16 registers of scratch (145 before the
+    // line was pinned between the last stage and the stores) and measured SLOWER than the shared
+    // table's 128-byte tiles -- (1024,1024,2048) c64, padded axis 1: 7.9 / 10.2 ms forward /
+    // backward against 7.2 / 7.0 ms -- so they stay behind variant 7 (A/B runs).
 #define P32T(N, R, T, ...)                                                                                          \
   (d.tr_dir == 1 ? launch_pow2_one<float, N, R, T, true, true, 1, 16, MODE_C2C, false, __VA_ARGS__>(d, in, out, s) \
                  : launch_pow2_one<float, N, R, T, true, true, 1, 16 | 64, MODE_C2C, false, __VA_ARGS__>(d, in, out, s))
-#define P32TL(N, R, T, ...) launch_pow2_one<float, N, R, T, true, true, 1, 16 | 64, MODE_C2C, false, __VA_ARGS__>(d, in, out, s)
     switch (d.n) {
       case 512: return P32T(512, 16, 32, 16, 8, 4);
-      case 1024: return P32TL(1024, 32, 32, 16, 16, 4);
-      case 2048: return P32TL(2048, 32, 16, 16, 16, 8);
-      case 4096: return P32TL(4096, 32, 8, 16, 16, 16);
+      case 1024: return P32T(1024, 32, 32, 16, 16, 4);
+      case 2048: return P32T(2048, 32, 16, 16, 16, 8);
+      case 4096: return P32T(4096, 32, 8, 16, 16, 16);
     }
 #undef P32T
-#undef P32TL
   } else if (d.mode != MODE_C2C || d.tw_hi || d.tr_dir || d.out_es == 1 || d.in_es == 1) {
     // real modes along a strided axis, fused truncation / padding, four-step passes: the widest
     // tile whose every mode compiles without spills (R = 16 up to n = 4096; the four-step twiddle

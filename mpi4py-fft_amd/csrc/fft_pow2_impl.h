@@ -801,6 +801,12 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     // (the row index `tl` is laundered for the same reason: fp32 n=1024 R=32 104 bytes of scratch
     // -> none; fp64 n=1024 R=16 T=16 127 -> 107 VGPRs)
     if constexpr (!(FLAGS & 4)) Stage<real, N, R, SPLIT, 1, RADS...>::run(v, tl, col, twl);
+    if constexpr ((FLAGS & 16) != 0 && !HALF) {
+      // pin the line between the last stage and the truncating / masked stores: interleaved by the
+      // scheduler the two keep extra copies alive (fp32 n = 1024 R = 32: 145 spilled VGPRs -> 11)
+#pragma unroll
+      for (int q = 0; q < R; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y));
+    }
     [[maybe_unused]] cx<real> z0 = v[0];
     if constexpr (MODE == MODE_R2C_H) {
       // packed spectrum Z[0..N-1] -> Hermitian half spectrum X[0..N-1] in place (twice the values:
