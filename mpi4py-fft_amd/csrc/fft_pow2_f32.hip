@@ -105,6 +105,7 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
         switch (variant) {
           default: return P32F(1024, 32, 32, true, true, 1, 8, 16, 16, 4);
           case 1: return P32(1024, 16, 16, true, true, 1, 16, 16, 4);
+          case 8: return P32F(1024, 32, 32, true, true, 1, 8 | 256, 16, 16, 4);   // A/B: line not pinned before the stores
         }
       case 2048:
         switch (variant) {

@@ -801,9 +801,10 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     // (the row index `tl` is laundered for the same reason: fp32 n=1024 R=32 104 bytes of scratch
     // -> none; fp64 n=1024 R=16 T=16 127 -> 107 VGPRs)
     if constexpr (!(FLAGS & 4)) Stage<real, N, R, SPLIT, 1, RADS...>::run(v, tl, col, twl);
-    if constexpr ((FLAGS & 16) != 0 && !HALF) {
-      // pin the line between the last stage and the truncating / masked stores: interleaved by the
-      // scheduler the two keep extra copies alive (fp32 n = 1024 R = 32: 145 spilled VGPRs -> 11)
+    if constexpr (!HALF && !(FLAGS & 256)) {      // (FLAGS & 256: A/B switch, no pin)
+      // pin the line between the last stage and the stores: interleaved by the scheduler the two
+      // keep extra copies alive (fp32 n = 1024 R = 32 with the truncating store: 145 spilled VGPRs
+      // -> 11; the plain fp32 R = 32 pass: 127 VGPRs + 4 spilled -> 121, none)
 #pragma unroll
       for (int q = 0; q < R; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y));
     }
