@@ -679,8 +679,9 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   // ROWS: the batch is flat (each column is itself a contiguous row of the array).
   // (four-step passes -- BIGTW -- run their columns along `mid` and use the flat form too.)
   constexpr bool ROWTILES = COLS && !BIGTW;
-  const unsigned chunks = ROWTILES ? (inner + T - 1) / T : 1;
-  const unsigned ntiles = ROWTILES ? (batch / inner) * chunks : (batch + T - 1) / T;
+  const unsigned flat_cols = mid * inner;                       // d.flat: columns per outer index
+  const unsigned chunks = ROWTILES ? ((d.flat ? flat_cols : inner) + T - 1) / T : 1;
+  const unsigned ntiles = ROWTILES ? (d.flat ? batch / flat_cols : batch / inner) * chunks : (batch + T - 1) / T;
   const real sy_in = d.conj_in ? (real)-1 : (real)1;
   const real sx_out = (real)(MODE == MODE_R2C_H ? 0.5 * d.scale : d.scale);   // (the Hermitian pass leaves 2 X)
   const real sy_out = d.conj_out ? -sx_out : sx_out;
@@ -710,12 +711,22 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
     unsigned o, m, i;
     if constexpr (ROWTILES) {
       const unsigned row = tile / chunks, j = tile - row * chunks;
-      i = j * T + c;
-      valid = i < (d.inner_ld ? (unsigned)d.inner_ld : inner);          // columns that are read
-      valid_st = i < (d.inner_st ? (unsigned)d.inner_st : inner);       // columns that are written
-      if (!(valid || valid_st)) i = 0;
-      o = row / mid;
-      m = row - o * mid;
+      if (d.flat) {
+        // tiles over the flattened (m, i) index of one outer slab: per-lane row and column
+        o = row;
+        unsigned J = j * T + c;
+        valid = valid_st = J < flat_cols;
+        if (!valid) J = 0;
+        m = J / inner;
+        i = J - m * inner;
+      } else {
+        i = j * T + c;
+        valid = i < (d.inner_ld ? (unsigned)d.inner_ld : inner);          // columns that are read
+        valid_st = i < (d.inner_st ? (unsigned)d.inner_st : inner);       // columns that are written
+        if (!(valid || valid_st)) i = 0;
+        o = row / mid;
+        m = row - o * mid;
+      }
     } else {
       const unsigned b = tile * T + c;
       valid = valid_st = b < batch;
@@ -972,7 +983,10 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const int64_t ntiles = (COLS && !BIGTW) ? (d.batch / d.inner) * ((d.inner + T - 1) / T) : (d.batch + T - 1) / T;
+  const int64_t flat_cols = d.mid * d.inner;
+  const int64_t ntiles = (COLS && !BIGTW) ? (d.flat ? (d.batch / flat_cols) * ((flat_cols + T - 1) / T)
+                                                    : (d.batch / d.inner) * ((d.inner + T - 1) / T))
+                                          : (d.batch + T - 1) / T;
   const int64_t cap = pow2_grid_cap();
   int grid = (int)(ntiles < cap ? ntiles : cap);
   PassDesc dd = d;

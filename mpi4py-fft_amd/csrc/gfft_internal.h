@@ -43,6 +43,11 @@ struct PassDesc {
   // 0.5 ms per 1024^3 pass, profiles/r02b_ragged_probe.txt -- while the caller's natural arrays are
   // touched only where they have data.
   int64_t inner_ld, inner_st;
+  // strided (COLS) passes: tiles of adjacent columns run over the FLATTENED (mid, inner) index
+  // J = m * inner + i instead of staying inside one row -- for a side whose rows lie back to back
+  // (ms == inner * is) the tile's segments are then aligned whenever the array is, whatever the row
+  // width (513-wide half spectra); the other side is addressed per lane through (m, i) = divmod(J, inner)
+  int flat;
   int out_pad;    // MODE_R2C_H: zero entries written after X[N] (fills the output row's last line)
   // Packed-real rows writing (r2c) / reading (c2r) an all-to-all buffer whose blocks are UNEVEN: the
   // N + 1 entries of the half spectrum dealt to ub_p ranks by the reference's block rule

@@ -70,6 +70,8 @@ struct Options {
   int profile = 0;           // record HIP events around every pass (bench.py roofline leg)
   int fused3 = 1;            // reorder + padded-pitch workspace for 3-D all-axes plans
   int real_half = 1;         // contiguous real lines as half-length complex transforms (fft_real_*.hip)
+  int debug_flat = 0;        // gfft_debug_pass: tiles over the flattened (mid, inner) index
+  int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
   int64_t fused3_min_bytes = 32 << 20;
   Options() {
     if (const char *s = getenv("GFFT_GRID_CAP")) grid_cap = atoi(s);
@@ -851,7 +853,16 @@ int plan_fused3(gfft_plan_s *pl) {
   // (stride P), axis 1 the far one (stride n0*P).  The in-place middle pass then runs on near
   // strides on both its sides, and the pass that touches the user's natural array does so along
   // axis 1, the near axis of the natural layout (measured: near pad->pad 7.2 ms, far 7.9 ms).
-  const int64_t w_i0 = P, w_i1 = n0 * P;
+  int64_t w_i0 = P, w_i1 = n0 * P;
+  // Forward r2c with rows that are not whole lines wide (odd n/2 + 1): the pass that writes the
+  // caller's array would store 256-byte segments off the line grid (4.6-5.0 ms per 1024^3 pass
+  // against 3.4 aligned).  Stores hurt more than loads (tools/flat_probe.py), so that pass becomes
+  // the FAR-axis one with tiles over the flattened (i1, c) index of the output -- aligned stores
+  // whenever n1 * (n/2+1) * 16 B is a multiple of 128 -- reading the workspace, now W[i0][i1][c],
+  // through per-lane (row, column) addresses (misaligned loads, 3.8 ms).  Backward keeps the
+  // layout above: its first pass already has the misalignment on the load side.
+  const bool flat_out = real && !inverse && Pu != nc && (n1 * nc * esz) % 128 == 0 && opts().flat_out;
+  if (flat_out) { w_i0 = n1 * P; w_i1 = P; }
   // rows: transform along axis 2.  The batch runs fastest along whichever of (i0, i1) makes the
   // rows it READS consecutive in memory (reading scattered 16-KiB rows measured 6.7 ms per pass,
   // writing them scattered 5.8 ms): forward reads the natural array -> i1 fastest; backward
@@ -917,8 +928,25 @@ int plan_fused3(gfft_plan_s *pl) {
     p.src = src; p.dst = dst;
     return p;
   };
+  // axis 0 from W[i0][i1][c] to the natural output, tiles over the flattened (i1, c) index
+  auto axis0_flat = [&](int src, int dst) {
+    Pass p = base((int)n0, MODE_C2C);
+    p.cols = true;
+    p.d.batch = n1 * nc;
+    p.d.mid = n1;
+    p.d.inner = nc;
+    p.d.flat = 1;
+    p.d.in_os = 0;  p.d.in_ms = w_i1;  p.d.in_es = w_i0;
+    p.d.out_os = 0; p.d.out_ms = nc;   p.d.out_es = n1 * nc;
+    p.src = src; p.dst = dst;
+    return p;
+  };
   std::vector<Pass> seq;
-  if (!inverse) {
+  if (flat_out) {
+    seq.push_back(rows(MODE_R2C, false, true, BUF_IN, BUF_WS));
+    seq.push_back(axis1(true, true, BUF_WS, BUF_WS));
+    seq.push_back(axis0_flat(BUF_WS, BUF_OUT));
+  } else if (!inverse) {
     seq.push_back(rows(real ? MODE_R2C : MODE_C2C, false, true, BUF_IN, BUF_WS));
     seq.push_back(axis0(BUF_WS, BUF_WS));
     seq.push_back(axis1(true, false, BUF_WS, BUF_OUT));
@@ -933,7 +961,7 @@ int plan_fused3(gfft_plan_s *pl) {
     const bool half = p.d.mode == MODE_R2C_H || p.d.mode == MODE_C2R_H;
     if (half && (rc = get_twiddles(2 * (int64_t)p.d.n, prec, &p.d.rtw))) return rc;
     // (strided passes tile the line-rounded width Pu; the work model counts the nc data columns)
-    const double lines = p.cols ? (double)p.d.batch / (double)Pu * (double)nc : (double)p.d.batch;
+    const double lines = p.data_inner ? (double)p.d.batch / (double)p.d.inner * (double)p.data_inner : (double)p.d.batch;
     const double n = half ? 2.0 * p.d.n : p.d.n;          // logical length of the line
     const bool r2c = p.d.mode == MODE_R2C || p.d.mode == MODE_R2C_H, c2r = p.d.mode == MODE_C2R || p.d.mode == MODE_C2R_H;
     pl->flops += (p.d.mode == MODE_C2C ? 1.0 : 0.5) * 5.0 * n * std::log2(n) * lines;
@@ -952,16 +980,16 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   if (p.kind == PK_MULB) return launch_mulb(p.pt, pl->precision, out, s);
   if (p.kind == PK_EXTRACT) return launch_extract(p.pt, pl->precision, in, out, scale * p.extra_scale, s);
   PassDesc d = d0;
-  // auto: only where a strided pass reads or writes rows that do not start on 128-byte lines
-  // (odd-width half spectra): neighbouring chunks then meet in one L2 and their partial lines merge
-  // (FETCH_SIZE of the backward first pass of a 1024^3 r2c, which READS the 513-wide array and was
-  // left unswizzled at first: 1.44 x the algorithmic bytes, profiles/r02_real_*)
+  // auto: only where a strided pass WRITES rows that do not start on 128-byte lines (odd-width
+  // half spectra): neighbouring chunks then meet in one L2 and their partial lines merge.  For a
+  // pass that only READS such rows the order lowers FETCH_SIZE (1.44 -> 1.13 x the algorithmic
+  // bytes) but not the time (3.48 ms plain, 3.65 ms XCD-contiguous, tools/flat_probe.py): off.
   // (measured 1024^3 r2c: 5.4 -> 5.0 ms fp64, 3.6 -> 2.6 ms fp32; neutral-to-slightly-negative on
   // aligned arrays, so it stays off there)
   const int64_t esz_out = ((d.mode == MODE_C2R || d.mode == MODE_R2R) ? 1 : 2) * (int64_t)pl->precision;
   const int64_t esz_in = ((d.mode == MODE_R2C || d.mode == MODE_R2R) ? 1 : 2) * (int64_t)pl->precision;
-  d.swizzle = pl->xcd_swizzle >= 0 ? pl->xcd_swizzle
-                                   : (p.cols && (((d.out_es * esz_out) % 128 != 0) || ((d.in_es * esz_in) % 128 != 0)) ? 1 : 0);
+  (void)esz_in;
+  d.swizzle = pl->xcd_swizzle >= 0 ? pl->xcd_swizzle : (p.cols && !d.flat && ((d.out_es * esz_out) % 128 != 0) ? 1 : 0);
   if ((d.mode == MODE_R2C_H || d.mode == MODE_C2R_H) && real_half_supported(d.n))
     return pl->precision == 8 ? launch_real_half_f64(d, pl->variant_rows, in, out, s)
                               : launch_real_half_f32(d, pl->variant_rows, in, out, s);
@@ -1035,6 +1063,8 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "copy_nt")) gfft::g_copy_nt = value;
   else if (!strcmp(key, "fused3")) opts().fused3 = value;
   else if (!strcmp(key, "real_half")) opts().real_half = value;
+  else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
+  else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "profile")) opts().profile = value;
   else if (!strcmp(key, "xcd_swizzle")) opts().xcd_swizzle = value;
   else if (!strcmp(key, "fused3_min_mib")) opts().fused3_min_bytes = (int64_t)value << 20;
@@ -1634,6 +1664,8 @@ int gfft_debug_pass(const int64_t *geom, int precision, int cols, int variant, i
   d.in_os = geom[4]; d.in_ms = geom[5]; d.in_is = geom[6]; d.in_es = geom[7];
   d.out_os = geom[8]; d.out_ms = geom[9]; d.out_is = geom[10]; d.out_es = geom[11];
   d.scale = 1.0;
+  d.flat = opts().debug_flat;
+  d.swizzle = opts().xcd_swizzle > 0 ? 1 : 0;
   rc = get_twiddles(d.n, precision, &d.tw);
   if (rc) return rc;
   hipError_t e = precision == 8 ? launch_pow2_f64(d, cols != 0, variant, d_in, d_out, (hipStream_t)stream)
