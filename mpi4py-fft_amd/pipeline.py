@@ -12,17 +12,21 @@ neither the axis being gathered nor the one being scattered), and
 
 run as a pipeline: the serial transforms on the caller's (compute) stream, the exchanges on a
 communication stream this module owns, chained by events -- no host synchronisation.  The wire is
-libgfft's own RCCL communicator (comm.NativeWire: grouped ncclSend / ncclRecv, C ABI gfft_sendrecv).
+libgfft's own RCCL communicator (comm.NativeWire: grouped ncclSend / ncclRecv, C ABI gfft_sendrecv;
+optionally routed over all links of the grid in two rounds, relay.py) or, where that cannot be
+bound, asynchronous torch.distributed all-to-alls (comm.TorchWire).
 
 Buffers are chunk-major exchange buffers  [chunk][block = peer][C order of the chunk's sub-box],
 so every chunk of every peer is one contiguous message, and the transform kernels address them
 directly (gfft_plan_create_guru: explicit strides + block stride along the transformed axis):
 neither pack nor unpack kernels run, exactly as in the fused staged path (PFFT._fuse_packs).
 
-Applies to 3-D complex-to-complex transforms whose stages are single-axis register-kernel lengths
-and whose redistributions split evenly over a power-of-two number of ranks <= 8 (the BASELINE
-configurations); anything else keeps the staged path.  Results are bit-identical to it (same
-kernels, same arithmetic; tests/test_gpu_pipeline.py).
+Applies to 3-D transforms whose stages are single-axis register-kernel lengths and whose
+redistributions run over a power-of-two number of ranks <= 8 (the BASELINE configurations):
+complex-to-complex with even splits, and real ones, whose first stage (packed-real rows, _RealRows)
+runs slab by slab on the exchange buffer of UNEVEN blocks that the half spectrum's n/2 + 1 entries
+make.  Anything else keeps the staged path.  Results are bit-identical to it (same kernels, same
+arithmetic; tests/test_gpu_pipeline.py, tests/gpu_multiproc_worker.py, tests/gloo_worker.py).
 """
 import os
 
