@@ -231,17 +231,20 @@ class PFFT:
             if fuse_pack:
                 self._fuse_packs()
             # the route of every exchange (relay.py): collective over the grid, same order everywhere
+        self.pipeline = None
+        if not local and padding is False and transforms is None:
+            self.pipeline = self._plan_pipeline(wire, exchange)
+        if not local:
+            # the staged path's routes (it stays available: stage_times, fall-back); timed only when
+            # it is the path that will run
             for t in self.transfer:
-                t.plan_relay(exchange)
+                t.plan_relay('direct' if (self.pipeline is not None and exchange is None) else exchange)
             # 'auto': the routes are timed NOW, on the planned exchange buffers (their contents do
             # not matter), as FFTW_MEASURE times candidate plans inside the planner -- not inside the
             # caller's first forward()
             for i, t in enumerate(self.transfer):
                 if t.exchange is None:
                     t.forward(self.xfftn[i].forward.output_array, self.xfftn[i + 1].forward.input_array)
-        self.pipeline = None
-        if not local and padding is False and transforms is None:
-            self.pipeline = self._plan_pipeline(wire, exchange)
 
         self.forward = Transform(
             [o.forward for o in self.xfftn],
