@@ -113,3 +113,25 @@ def test_r2r_slab_roundtrips(P):
 @pytest.mark.parametrize('P', [1, 2, 4])
 def test_distarray_tour(P):
     assert all(cases.run_ranks(P, distarray_tour))
+
+
+def test_multi_gpu_example_script_across_processes():
+    """examples/pfft_multi_gpu.py under torch.distributed.run: 4 processes sharing the GPU (gloo),
+    the pipelined wire on torch.distributed, real data; its own checks decide."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GFFT_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '4', '--master-addr',
+           '127.0.0.1', '--master-port', '29581', os.path.join(root, 'examples', 'pfft_multi_gpu.py'),
+           '--size', '128', '--dtype', 'd', '--wire', 'overlap', '--steps', '2']
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert res.returncode == 0, res.stdout[-3000:]
+    m = re.search(r'peak \|u_hat\[3,5,7\]\| = ([0-9.]+), round trip max err ([0-9.e+-]+)', res.stdout)
+    assert m, res.stdout[-2000:]
+    assert abs(float(m.group(1)) - 0.5) < 1e-12 and float(m.group(2)) < 1e-12
+    assert "'chunks'" in res.stdout            # the pipelined plan ran
