@@ -19,11 +19,21 @@ def _run(script, nranks, size, extra_env=None, extra_args=()):
     env.update(extra_env or {})
     cmd = [sys.executable, script, '--gpus', str(nranks), '--size', str(size), '--no-cpu', '--steps', '2',
            '--warmup', '1'] + list(extra_args)
-    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    res = _launch(cmd, env, 600)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, res.stdout[-2000:]
     return json.loads(lines[0])
+
+
+def _launch(cmd, env, timeout):
+    """One retry: the launcher picks a free rendezvous port and releases it before torchrun binds
+    it, which another process on a busy test box can win."""
+    for attempt in range(2):
+        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+        if res.returncode == 0:
+            break
+    return res
 
 
 def _check_line(out, nranks, size):
@@ -65,7 +75,7 @@ def test_bench_keeps_the_headline_when_an_extra_hangs():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, 'tests', 'bench_host_runner.py'), '--gpus', '2', '--size', '16',
            '--no-cpu', '--steps', '1', '--warmup', '0', '--extras-deadline', '5']
-    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+    res = _launch(cmd, env, 300)
     assert res.returncode == 0, res.stderr[-3000:]
     out_lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
     assert len(out_lines) == 1
