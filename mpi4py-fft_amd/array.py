@@ -30,6 +30,7 @@ PIN_CHUNK_BYTES = 64 << 20
 PIN_MIN_BYTES = 32 << 20
 HOST_COPY_THREADS = 16
 _pinned = {}
+_pinned_lock = __import__('threading').Lock()     # the bounce buffers are shared by a process's threads
 _pool = None
 
 
@@ -75,22 +76,23 @@ def d2h(src):
     if n < PIN_MIN_BYTES or not src.is_cuda:
         torch.from_numpy(out).copy_(s)
         return out
-    b = _bounce(src.device)
-    chunk = b['buf'][0].numel()
-    pending = None
-    for k, off in enumerate(range(0, n, chunk)):
-        m = min(chunk, n - off)
-        i = k & 1
-        b['buf'][i][:m].copy_(s[off:off + m], non_blocking=True)      # buffer i was drained two rounds ago
-        b['ev'][i].record()
-        if pending is not None:                      # drain the previous chunk while this one flies
-            j, poff, pm = pending
-            b['ev'][j].synchronize()
-            _host_copy(out[poff:poff + pm], b['buf'][j][:pm].numpy())
-        pending = (i, off, m)
-    j, poff, pm = pending
-    b['ev'][j].synchronize()
-    _host_copy(out[poff:poff + pm], b['buf'][j][:pm].numpy())
+    with _pinned_lock:         # one staged read-back at a time per process (the link is shared anyway)
+        b = _bounce(src.device)
+        chunk = b['buf'][0].numel()
+        pending = None
+        for k, off in enumerate(range(0, n, chunk)):
+            m = min(chunk, n - off)
+            i = k & 1
+            b['buf'][i][:m].copy_(s[off:off + m], non_blocking=True)      # buffer i was drained two rounds ago
+            b['ev'][i].record()
+            if pending is not None:                      # drain the previous chunk while this one flies
+                j, poff, pm = pending
+                b['ev'][j].synchronize()
+                _host_copy(out[poff:poff + pm], b['buf'][j][:pm].numpy())
+            pending = (i, off, m)
+        j, poff, pm = pending
+        b['ev'][j].synchronize()
+        _host_copy(out[poff:poff + pm], b['buf'][j][:pm].numpy())
     return out
 
 

@@ -268,16 +268,26 @@ class PFFT:
         if parent is None or (mode == 'auto' and parent.backend != 'nccl'):
             return None
         from . import pipeline
+
+        def agreed(pipe):
+            # all ranks of the grid run the pipelined form or none does (a rank whose local shape
+            # makes one of its stage plans impossible must not leave the others waiting for it)
+            if all(parent.allgather_obj(pipe is not None)):
+                pipe.plan_relays()
+                return pipe
+            if pipe is not None:
+                pipe.destroy()
+            return None
         if mode == 'overlap':
             # the chunked pipeline on torch.distributed's own collectives (asynchronous all_to_all)
-            return pipeline.Pipeline.build(self, _comm.torch_wires(self.subcomm), 'direct')
+            return agreed(pipeline.Pipeline.build(self, _comm.torch_wires(self.subcomm), 'direct'))
         try:
             wires = _comm.native_wires(self.subcomm)
         except Exception:
             if mode == 'native':
                 raise
-            return pipeline.Pipeline.build(self, _comm.torch_wires(self.subcomm), 'direct')
-        return pipeline.Pipeline.build(self, wires, exchange)
+            return agreed(pipeline.Pipeline.build(self, _comm.torch_wires(self.subcomm), 'direct'))
+        return agreed(pipeline.Pipeline.build(self, wires, exchange))
 
     # ---- planning steps (what mpifft.py:202-347 decides, one decision per helper) ---------------
     @staticmethod
@@ -423,10 +433,17 @@ class PFFT:
                     stage.destroy()
                     self.xfftn[k] = stage = new
                 # forward plan: A side = its output (1), B side = its input (0); backward mirrored
-                if not stage.fwd.set_split(io[0], p):
-                    continue
-                if not stage.bck.set_split(io[1], p):
+                ok = bool(stage.fwd.set_split(io[0], p))
+                if ok and not stage.bck.set_split(io[1], p):
                     stage.fwd.set_split(io[0], 1)
+                    ok = False
+                # every rank of the redistribution takes the same decision (a packed side changes
+                # how the exchange is cut into slabs, Transfer._move): one refusal -- a rank whose
+                # local array differs in shape -- reverts the side everywhere
+                if not all(tr.comm.allgather_obj(ok)):
+                    if ok:
+                        stage.fwd.set_split(io[0], 1)
+                        stage.bck.set_split(io[1], 1)
                     continue
                 setattr(tr, attr, True)
 

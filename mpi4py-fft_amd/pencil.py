@@ -92,6 +92,14 @@ class Transfer:
         self._countsB = [restB * _blockdist(self.shape[self.axisB], p, i)[0] for i in range(p)]
         assert self.subshapeA[self.axisA] == self.shape[self.axisA]
         assert self.subshapeB[self.axisB] == self.shape[self.axisB]
+        # the largest local array of any rank of `comm` (block 0 of the block rule is the largest;
+        # the other axes have the same local extent on every rank of this sub-communicator): what
+        # decisions that every rank of the group must take alike are based on -- a rank's own
+        # size differs across the group whenever a split is uneven
+        def largest(sub, cut):
+            return int(np.prod([_blockdist(self.shape[cut], p, 0)[0] if d == cut else n
+                                for d, n in enumerate(sub)], dtype=np.int64)) * self.dtype.itemsize
+        self._group_bytes = max(largest(self.subshapeA, self.axisB), largest(self.subshapeB, self.axisA))
         self._stage = {}
         self.trace = None                 # list -> _move appends (phase, seconds), synchronising
         # set by PFFT when the neighbouring serial transforms write / read the exchange buffers
@@ -156,8 +164,9 @@ class Transfer:
     # per-rank exchange volume below which routes are not measured (GFFT_RELAY_MIN_BYTES overrides)
     RELAY_MIN_BYTES = int(os.environ.get('GFFT_RELAY_MIN_BYTES', 8 << 20))
 
-    def _nchunks(self, shape_src, axis_src, axis_dst, nbytes):
-        if self._p == 1 or 0 in (axis_src, axis_dst) or nbytes < self.CHUNK_MIN_BYTES:
+    def _nchunks(self, shape_src, axis_src, axis_dst):
+        # (same answer on every rank of the group: the slabs' all-to-alls must pair up)
+        if self._p == 1 or 0 in (axis_src, axis_dst) or self._group_bytes < self.CHUNK_MIN_BYTES:
             return 1
         if not hasattr(self.comm, 'alltoall_async'):
             return 1
@@ -206,7 +215,7 @@ class Transfer:
                                                  shape_dst, axis_dst, counts_dst, packed_src, packed_dst)
         use_relay = self._relay and self.exchange == 'relay'
         K = 1 if (use_relay or packed_src or packed_dst) else \
-            self._nchunks(shape_src, axis_src, axis_dst, ts.numel() * isz)
+            self._nchunks(shape_src, axis_src, axis_dst)
         tick = self._tick
         tick(None)
         if K > 1 and self.trace is None:

@@ -200,6 +200,7 @@ class Pipeline:
 
     @classmethod
     def build(cls, pfft, wires, exchange=None):
+        """Local planning only (no communication); `plan_relays` afterwards is collective."""
         import torch
         stages, transfers = pfft.xfftn, pfft.transfer
         if not transfers or not (torch.cuda.is_available() or _lib.engine().name != 'hip'):
@@ -247,7 +248,10 @@ class Pipeline:
                 # whole grid), so only a common divisor of all widths qualifies
                 nf = int(np.gcd.reduce(plan[0]['widths']))
             K = 1
-            nbytes = int(np.prod(t.subshapeA, dtype=np.int64)) * isz
+            sub = list(t.subshapeA)
+            if real0 and i > 0 and plan and plan[0].get('uneven'):
+                sub[2] = max(plan[0]['widths'])      # (the same number on every rank, like nf above)
+            nbytes = int(np.prod(sub, dtype=np.int64)) * isz
             for k in range(min(cls.CHUNKS, nf), 1, -1):
                 if nf % k == 0 and nf // k >= cls.MIN_WIDTH and nbytes // k >= cls.MIN_CHUNK_BYTES:
                     K = k
@@ -318,11 +322,16 @@ class Pipeline:
         self.comm_stream = _streams()[1]
         self._events = {}
         self._works = {}
-        if str(exchange).lower() in ('relay', '1', 'on'):
-            self._plan_relays(pfft, lay_out)
+        # (routes are planned by the owner once every rank of the grid has a pipeline: plan_relays
+        # is collective over the grid, build is not and may return None on single ranks)
+        self._want_relays = str(exchange).lower() in ('relay', '1', 'on')
         return self
 
-    def _plan_relays(self, pfft, lay_out):
+    def plan_relays(self):
+        if self._want_relays:
+            self._plan_relays(self.pfft)
+
+    def _plan_relays(self, pfft):
         """Routed exchanges (relay.py) on the native wire: a redistribution inside a small
         sub-communicator is carried over ALL links of the grid in two rounds, and round 2 of chunk
         k shares one grouped batch with round 1 of chunk k+1.  The grid is regular, so every rank

@@ -209,6 +209,20 @@ def test_chunked_transfer_pipeline_on_device(monkeypatch):
     cases.check_pfft_vs_oracle(4, (33, 20, 18), 'd')
 
 
+def test_chunk_decision_is_the_same_on_every_rank_of_the_group(monkeypatch):
+    """An r2c half spectrum of 9 entries over 2 ranks: 5 | 4 columns, so the two ranks' local arrays
+    differ in size; a threshold between the two sizes must not make one rank cut its exchange into
+    slabs and its peer not (found by tools/stress.py mid: all-to-all counts off by the slab count)."""
+    from mpi4py_fft_amd import pencil
+    monkeypatch.setenv('GFFT_FUSE_PACK', '0')
+    monkeypatch.setenv('GFFT_WIRE', 'torch')
+    monkeypatch.setenv('GFFT_RELAY', '0')
+    # local arrays at P = 4, grid (2,2): A (8,16,9) 18432 B; B (8,32,5) 20480 B or (8,32,4) 16384 B
+    for threshold in (17000, 19000, 21000):
+        monkeypatch.setattr(pencil.Transfer, 'CHUNK_MIN_BYTES', threshold)
+        cases.check_pfft_vs_oracle(4, (16, 32, 16), 'd')
+
+
 def test_relayed_exchange_on_device(monkeypatch):
     """Two-round multi-path exchange (relay.py) around the real pack/unpack kernels."""
     monkeypatch.setenv('GFFT_RELAY', '1')

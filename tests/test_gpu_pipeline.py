@@ -136,6 +136,45 @@ def test_transforms_that_do_not_qualify_keep_the_staged_path(monkeypatch):
     cases.check_pfft_vs_oracle(4, (48, 40, 64), 'D')
 
 
+def test_one_rank_without_a_pipeline_keeps_every_rank_on_the_staged_path(monkeypatch):
+    """Pipeline.build is local planning and may fail on a single rank (a local shape one of its
+    stage plans cannot take); the grid then agrees on the staged path instead of leaving that
+    rank's peers waiting in the pipelined exchange."""
+    from mpi4py_fft_amd import PFFT, newDistArray, pipeline
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_CHUNK_BYTES', 0)
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_WIDTH', 4)
+    build = pipeline.Pipeline.build.__func__
+
+    def flaky(cls, pfft, wires, exchange=None):
+        pipe = build(cls, pfft, wires, exchange)
+        parent = next(c.relay_parent for c in pfft.subcomm if getattr(c, 'relay_parent', None) is not None)
+        if pipe is not None and parent.Get_rank() == 1:
+            pipe.destroy()
+            return None
+        return pipe
+    monkeypatch.setattr(pipeline.Pipeline, 'build', classmethod(flaky))
+    shape = (64, 64, 64)
+    G = O.rng_array(shape, 'D', 3)
+
+    def body(comm):
+        f = PFFT(comm, shape, dtype='D', wire='native', exchange='relay')
+        u = newDistArray(f, False)
+        u[...] = G[f.local_slice(False)]
+        a = np.asarray(f.forward(u)).copy()
+        b = np.asarray(f.backward()).copy()
+        piped = f.pipeline is not None
+        sl = f.local_slice(False)
+        f.destroy()
+        return piped, a, b, sl
+    res = cases.run_ranks(4, body)
+    ref = O.OPFFT(4, shape, dtype='D')
+    want = ref.forward(ref.scatter(G))
+    for r, (piped, a, b, sl) in enumerate(res):
+        assert not piped
+        assert np.abs(a - want[r]).max() <= 1e-12 * np.abs(want[r]).max()
+        assert np.allclose(b, G[sl], rtol=0, atol=1e-12)
+
+
 @pytest.mark.parametrize('P,shape', [(4, (64, 64, 64)), (8, (64, 64, 64)), (8, (128, 64, 256))])
 @pytest.mark.parametrize('chunks', [1, 4])
 def test_pipelined_routed_exchange_is_bit_identical(P, shape, chunks, monkeypatch):

@@ -423,6 +423,36 @@ def test_pinned_staging_round_trip(monkeypatch):
     array._pinned.clear()
 
 
+def test_staged_read_back_from_several_threads(monkeypatch):
+    """np.asarray(u) from several threads of one process at once (thread ranks; a multi-threaded
+    host): the pinned bounce buffers are shared, the read-backs must not interleave.  (Found by
+    tools/stress.py mid: 8 thread ranks reading 178 MB results back got each other's chunks.)"""
+    import threading
+    from mpi4py_fft_amd import array, empty
+    monkeypatch.setattr(array, 'PIN_CHUNK_BYTES', 1 << 18)
+    monkeypatch.setattr(array, 'PIN_MIN_BYTES', 1 << 16)
+    array._pinned.clear()
+    hosts = [np.random.default_rng(r).standard_normal((37, 129, 65)) for r in range(6)]
+    devs = []
+    for h in hosts:
+        u = empty(h.shape, 'd')
+        u[...] = h
+        devs.append(u)
+    bad = []
+
+    def body(r):
+        for _ in range(5):
+            if not np.array_equal(np.asarray(devs[r]), hosts[r]):
+                bad.append(r)
+    th = [threading.Thread(target=body, args=(r,)) for r in range(len(hosts))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    array._pinned.clear()
+    assert not bad, bad
+
+
 @pytest.mark.parametrize('dt', ['d', 'f'])
 @pytest.mark.parametrize('n', [32, 64, 1024, 96, 40])
 def test_packed_real_rows_address_uneven_exchange_blocks(n, dt):

@@ -22,12 +22,20 @@ pipeline.Pipeline.MIN_WIDTH = 4
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 rng = np.random.default_rng(seed)
+mode = sys.argv[3] if len(sys.argv) > 3 else 'small'
 pool = [8, 12, 13, 16, 16, 18, 24, 27, 28, 32, 32, 32, 40, 48, 56, 64, 64, 64, 96, 128, 128]
+limit = 3_000_000
+if mode == 'mid':
+    # the lengths the big configurations run (register kernels with wide tiles, line-rounded
+    # workspace passes, packed-real rows, 513-style widths) at sizes the oracle still does in seconds
+    pool = [16, 20, 34, 64, 66, 100, 128, 192, 256, 256, 320, 384, 500, 512, 512, 640, 768, 1000, 1024, 1024,
+            1536, 2048, 4096]
+    limit = 48_000_000
 t0, done, skipped = time.time(), 0, 0
 while time.time() - t0 < budget:
-    nd = int(rng.choice([2, 3, 3, 3, 4]))
+    nd = int(rng.choice([2, 3, 3, 3, 4] if mode == 'small' else [2, 3, 3, 3]))
     shape = tuple(int(rng.choice(pool)) for _ in range(nd))
-    if np.prod(shape) > 3_000_000:
+    if np.prod(shape) > limit or (mode == 'mid' and np.prod(shape) < 200_000):
         continue
     P = int(rng.choice([1, 2, 4, 4, 8, 8, 3, 6]))
     dt = str(rng.choice(list('dDfF')))
