@@ -96,6 +96,7 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
         switch (variant) {
           default: return P32F(512, 16, 32, true, true, 1, 8, 16, 8, 4);
           case 1: return P32(512, 8, 16, true, true, 1, 8, 8, 8);
+          case 2: return P32F(512, 16, 16, true, true, 4, 8, 16, 8, 4);           // A/B as for n = 1024: 0.95 / 1.26 ms against 0.91 / 1.04
         }
       // n >= 1024: R = 32 elements per thread (the 64 data VGPRs R = 16 costs in fp64) doubles the
       // columns per workgroup at the same 1024 threads: 256-byte segments at n = 1024, 128 at 2048.
@@ -106,6 +107,9 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
           default: return P32F(1024, 32, 32, true, true, 1, 8, 16, 16, 4);
           case 1: return P32(1024, 16, 16, true, true, 1, 16, 16, 4);
           case 8: return P32F(1024, 32, 32, true, true, 1, 8 | 256, 16, 16, 4);   // A/B: line not pinned before the stores
+          // A/B: two 512-thread workgroups per CU (one computes while the other loads) on 128-byte
+          // segments: 1024^3 c64 axis 1 3.60 ms (default 3.58), axis 0 5.38 (4.43) -- segment width wins
+          case 2: return P32F(1024, 32, 16, true, true, 4, 8, 16, 16, 4);
         }
       case 2048:
         switch (variant) {

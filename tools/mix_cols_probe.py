@@ -43,6 +43,12 @@ def case(shape, dt, axis):
 
 
 print(torch.cuda.get_device_name(0))
+if os.environ.get('MIX_PROBE_SET') == 'pow2f':
+    for shape, axis in [((1024, 1024, 1024), 1), ((1024, 1024, 1024), 0), ((1024, 512, 512), 0), ((512, 1024, 512), 1),
+                        ((512, 512, 1024), 1), ((512, 512, 1024), 0), ((2048, 512, 513), 0), ((512, 1024, 513), 1)]:
+        case(shape, 'F', axis)
+        torch.cuda.empty_cache()
+    sys.exit(0)
 for dt in 'FD':
     for shape, axis in [((1536, 512, 512), 0), ((1536, 512, 513), 0), ((512, 1536, 512), 1), ((512, 1536, 513), 1),
                         ((768, 1024, 512), 0), ((1024, 768, 512), 1), ((1024, 768, 257), 1),

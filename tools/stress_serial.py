@@ -14,12 +14,23 @@ rng = np.random.default_rng(seed)
 LONG = [64, 128, 256, 512, 1024, 2048, 4096, 8192, 48, 96, 192, 384, 768, 1536, 3072, 1152, 20, 40, 80, 160, 320,
         640, 1000, 1280, 2000, 2560, 896, 448, 1792, 704, 1408, 832, 960, 1920, 1232, 97, 251, 1021, 2049]
 SHORT = [1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 17, 33, 64, 65, 128, 130]
+mode = sys.argv[3] if len(sys.argv) > 3 else 'small'
+MID = [16, 34, 66, 100, 128, 192, 256, 257, 384, 512, 513, 640, 768, 1000, 1024, 1536, 2048, 4096]
 t0, done = time.time(), 0
 while time.time() - t0 < budget:
     nd = int(rng.integers(1, 4))
     ax_long = int(rng.integers(0, nd))
-    shape = tuple(int(rng.choice(LONG)) if i == ax_long else int(rng.choice(SHORT)) for i in range(nd))
-    if np.prod(shape) > 6_000_000:
+    if mode == 'mid':
+        # several long axes at once: the multi-axis schedules (workspace passes, flattened tiles)
+        # and wide strided passes at the sizes the big configurations have
+        nd = int(rng.integers(2, 4))
+        ax_long = int(rng.integers(0, nd))
+        shape = tuple(int(rng.choice(MID)) for _ in range(nd))
+        if not 200_000 <= np.prod(shape) <= 48_000_000:
+            continue
+    else:
+        shape = tuple(int(rng.choice(LONG)) if i == ax_long else int(rng.choice(SHORT)) for i in range(nd))
+    if np.prod(shape) > 48_000_000 or (mode != 'mid' and np.prod(shape) > 6_000_000):
         continue
     k = int(rng.integers(1, nd + 1))
     axes = tuple(int(a) for a in rng.permutation(nd)[:k])
