@@ -168,3 +168,50 @@ def check_pfft_vs_oracle(P, shape, dt, seed=7, **kw):
             d = back - G[sl]
             rel = np.linalg.norm(d) / np.linalg.norm(G[sl])
             assert rel <= (1e-10 if dt in 'dD' else 1e-4), (shape, dt, kw, rel)
+
+
+def check_redistribute_chain(rng, mid=False):
+    """A random DistArray (shape, tensor rank, dtype, grid, alignment) walked through four random
+    redistributions on thread ranks; after each one every rank must hold exactly its local_slice() of
+    the global array.  Returns False when the draw is not a valid configuration."""
+    from mpi4py_fft_amd import DistArray
+    nd = int(rng.choice([2, 3, 3, 4]))
+    pool = [5, 8, 9, 12, 13, 16, 17, 24, 31, 32, 33, 40, 64] if not mid else [16, 33, 64, 100, 128, 129, 256, 257, 512, 513]
+    P = int(rng.choice([2, 3, 4, 4, 6, 8, 8]))
+    shape = tuple(int(rng.choice(pool)) for _ in range(nd))
+    if min(shape) < P or np.prod(shape) > (24_000_000 if mid else 2_000_000):
+        return False
+    rank = int(rng.choice([0, 0, 1, 2])) if not mid else int(rng.choice([0, 0, 1]))
+    dt = str(rng.choice(list('fdFD')))
+    align = int(rng.integers(0, nd))
+    # how many axes are distributed: 1 (slab) ... nd - 1
+    ndist = int(rng.integers(1, nd))
+    walk = [int(a) for a in rng.integers(0, nd, size=4)]
+    comps = (3,) * rank
+    G = (rng.standard_normal(comps + shape) + (1j * rng.standard_normal(comps + shape) if dt in 'FD' else 0)).astype(dt)
+
+    def body(comm):
+        from mpi4py_fft_amd.pencil import Subcomm
+        dims = [0] * nd
+        # the aligned axis is undivided; distribute `ndist` of the others
+        others = [a for a in range(nd) if a != align]
+        for a in others[ndist:]:
+            dims[a] = 1
+        dims[align] = 1
+        sub = Subcomm(comm, dims)
+        a = DistArray(comps + shape, subcomm=sub, dtype=dt, alignment=align, rank=rank)
+        sl = a.local_slice()
+        a[...] = G[sl]
+        bad = []
+        cur = a
+        for ax in walk:
+            cur = cur.redistribute(ax)
+            got = np.asarray(cur)
+            if cur.alignment != ax and cur.commsizes[rank + ax] != 1:
+                bad.append(('alignment', ax, cur.alignment))
+            if not np.array_equal(got, G[cur.local_slice()]):
+                bad.append(('values', ax, got.shape))
+        return bad
+    res = run_ranks(P, body)
+    assert not any(res), (P, shape, dt, rank, align, ndist, walk, [r for r in res if r][:1])
+    return True

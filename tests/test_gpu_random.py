@@ -70,3 +70,20 @@ def test_random_pfft(seed):
                 continue
             raise
         done += 1
+
+
+@pytest.mark.parametrize('seed', range(3))
+def test_random_redistribute_chains(seed):
+    """Random DistArrays (uneven blocks, tensor ranks 0-2, slab ... pencil grids on 2-8 thread ranks)
+    walked through random redistributions: every rank holds its local_slice() of the global array
+    after each (tests/test_darray.py:57-96 does one fixed walk)."""
+    from tests import cases
+    rng = np.random.default_rng(3000 + seed)
+    done = 0
+    while done < 12:
+        done += bool(cases.check_redistribute_chain(rng))
+    if seed == 0:
+        rng = np.random.default_rng(3100)
+        done = 0
+        while done < 3:
+            done += bool(cases.check_redistribute_chain(rng, mid=True))

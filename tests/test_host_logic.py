@@ -36,6 +36,14 @@ def test_pfft_vs_oracle(P, shape, dt, kw):
     cases.check_pfft_vs_oracle(P, shape, dt, **kw)
 
 
+def test_random_redistribute_chains():
+    """Random DistArray redistribution walks (see tests/test_gpu_random.py) on the host logic."""
+    rng = np.random.default_rng(77)
+    done = 0
+    while done < 25:
+        done += bool(cases.check_redistribute_chain(rng))
+
+
 def test_distarray_api():
     from mpi4py_fft_amd import DistArray, newDistArray, PFFT, comm
     from tests import thread_comm
