@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -47,6 +48,22 @@ int g_next_id = 1;
 thread_local int t_depth = 0;
 thread_local std::vector<Op> t_ops;
 
+// FAKE_RCCL_DELAY_US=<n>: every message lands n microseconds late (a spin kernel on the receiver's
+// stream ahead of the copy), so a consumer that does not wait for the arrival event reads stale
+// data instead of getting away with it because device copies of test-sized messages are instant.
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+long long delay_ticks() {
+  static const long long t = [] {
+    const char *e = getenv("FAKE_RCCL_DELAY_US");
+    return e ? atoll(e) * 100 : 0LL;          // wall_clock64 runs at 100 MHz
+  }();
+  return t;
+}
+
 size_t dtype_size(int dt) {
   switch (dt) { case 0: case 1: return 1; case 2: case 3: case 7: return 4; case 4: case 5: case 8: return 8; case 6: case 9: return 2; }
   return 1;
@@ -82,6 +99,7 @@ int run_group(std::vector<Op> &ops) {
     }
     if (msg.bytes != o.bytes) return 5;     // ncclInvalidArgument: mismatched message sizes
     if (hipStreamWaitEvent(o.s, msg.ready, 0) != hipSuccess) return 1;
+    if (delay_ticks() > 0) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, o.s, delay_ticks());
     if (o.bytes && hipMemcpyAsync(o.ptr, msg.ptr, o.bytes, hipMemcpyDeviceToDevice, o.s) != hipSuccess) return 1;
     hipEvent_t done;
     if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return 1;

@@ -248,3 +248,19 @@ def test_pipelined_r2c_transform(P, shape, dt, exchange, monkeypatch):
         assert np.array_equal(a, b) and np.array_equal(a, c), (P, shape, dt, r)
         assert np.array_equal(ab, bb) and np.array_equal(ab, bc)
         assert np.abs(a - want[r]).max() <= cases.tol_for(dt) * np.abs(want[r]).max()
+
+
+def test_late_messages_are_waited_for():
+    """The pipelined path with every message of the wire landing 400 us late (FAKE_RCCL_DELAY_US,
+    tests/fake_rccl): c2c and r2c, direct and routed, 2 and 4 chunks against the oracle -- and the
+    negative control: with the arrival waits removed the same run must come out wrong (without the
+    delay it does not: device copies of test-sized messages are over before the next kernel starts)."""
+    import sys
+    env = dict(os.environ, FAKE_RCCL_DELAY_US='400')
+    worker = os.path.join(HERE, 'late_messages_worker.py')
+    ok = subprocess.run([sys.executable, worker], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                        timeout=600, text=True)
+    assert ok.returncode == 0 and 'results correct' in ok.stdout, ok.stdout[-2000:]
+    neg = subprocess.run([sys.executable, worker, 'broken'], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert neg.returncode == 0 and 'results WRONG' in neg.stdout, neg.stdout[-2000:]
