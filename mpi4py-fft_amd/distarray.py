@@ -198,10 +198,28 @@ class DistArray(DeviceArray):
                 out[where] = data
         return out
 
-    def write(self, *a, **k):
-        raise NotImplementedError('HDF5/NetCDF output is outside the PFFT hot path')
+    def write(self, filename, name='darray', step=0, global_slice=None, domain=None, as_scalar=False):
+        """Store snapshot `step` of this array (or of ``global_slice`` of it) in an HDF5 (``*.h5``)
+        or NetCDF file, or in an open :class:`.io.FileBase` (distarray.py:365-403)."""
+        from .io import FileBase, HDF5File, NCFile
+        if isinstance(filename, str):
+            f = (HDF5File if filename.endswith('.h5') else NCFile)(filename, domain=domain, mode='a')
+        else:
+            assert isinstance(filename, FileBase)
+            f = filename
+        field = [self] if global_slice is None else [(self, global_slice)]
+        f.write(step, {name: field}, as_scalar=as_scalar)
 
-    read = write
+    def read(self, filename, name='darray', step=0):
+        """Fill this array from field `name`, snapshot `step`, of a file written by :meth:`write`
+        (whole arrays only; distarray.py:405-439)."""
+        from .io import FileBase, HDF5File, NCFile
+        if isinstance(filename, str):
+            f = (HDF5File if filename.endswith('.h5') else NCFile)(filename, mode='r')
+        else:
+            assert isinstance(filename, FileBase)
+            f = filename
+        f.read(self, name, step=step)
 
 
 def newDistArray(pfft, forward_output=True, val=0, rank=0, view=False):
