@@ -233,16 +233,26 @@ __host__ __device__ constexpr bool is_pow2_c(int n) { return n > 0 && (n & (n - 
 // compile-time property of N so that pad(a + b) splits into pad(a) + constant (see Stage::run).
 template <bool PAD> __host__ __device__ constexpr int pad_slot(int e) { return PAD ? e + (e >> 4) : e; }
 
-template <int N, bool COLS, int T> struct Lds {
+template <int N, bool COLS, int T, bool W4 = false> struct Lds {
   static constexpr bool PAD = is_pow2_c(N);
   static constexpr int NP = PAD ? N + N / 16 + 1 : N + 1;
-  // COLS: lanes run over T adjacent columns first, so the column stride CS (in 8-byte words)
-  // decides the banks.  T <= 8: CS == 2 (mod 16): 8 columns x 2 rows cover the 32 write banks.
+  // COLS: lanes run over T adjacent columns first, so the column stride CS (in words) decides the
+  // banks.  8-byte words (fp64 planes, unsplit fp32 pairs; ds_*_b64, 64 banks):
+  // T <= 8: CS == 2 (mod 16): 8 columns x 2 rows cover the 32 write banks.
   // T >= 16: CS == 17 (mod 32): 16 columns land on 16 distinct bank pairs for ds_write_b64
   // (34c mod 32 = 2c) and, with two rows per 32-lane ds_read_b64 group, on 32 distinct pairs of
   // the 64 read banks.  (With CS == 2 mod 16 the T = 16 kernel measured 48 % of its LDS cycles
   // as bank conflicts: profiles/r01b_*_pmc_lds.txt.)
-  static constexpr int CS = !COLS ? NP : (T >= 16 ? ((NP + 31) / 32) * 32 + 17 : ((NP + 15) / 16) * 16 + 2);
+  // 4-byte words (W4: fp32 planes; ds_*_b32, 32 banks, 32 lanes per LDS cycle = T columns x 32/T
+  // consecutive rows): the columns take every (32/T)-th bank, CS == 32/T (mod 32), and the rows
+  // of a group fill the gaps -- consecutive rows sit 1 slot apart on the read side and in the
+  // stages with Ns > 1, pad(16) = 17 slots apart in a first radix-16 stage: both run through all
+  // residues mod 32/T.  (The 8-byte rule on 4-byte words made row t + 1 of column c collide with
+  // row t of column c + 1 in that first stage: fp32 n = 2048, T = 16 measured 48 % of its LDS
+  // cycles as conflicts, profiles/r02_c5cols_pmc_lds.txt.)
+  static constexpr int CS8 = T >= 16 ? ((NP + 31) / 32) * 32 + 17 : (T == 4 ? ((NP + 31) / 32) * 32 + 8 : ((NP + 15) / 16) * 16 + 2);
+  static constexpr int CS4 = T >= 32 ? ((NP + 31) / 32) * 32 + 17 : ((NP + 31) / 32) * 32 + 32 / (T < 1 ? 1 : T);
+  static constexpr int CS = !COLS ? NP : (W4 ? CS4 : CS8);
 };
 
 // multiply v[i + m*S] (m = 1..r-1) by w^(m*k); w = exp(-2 pi i/(Ns*r)); table stride = N/(Ns*r)
@@ -660,8 +670,8 @@ __global__ void __launch_bounds__(T *(N / R), MINW)
 fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
   static_assert(SPLIT || sizeof(real) == 4, "fp64 exchanges split planes");
   constexpr int NT = N / R;
-  constexpr int CS = Lds<N, COLS, T>::CS;
   constexpr int WORD = SPLIT ? sizeof(real) : 2 * sizeof(real);
+  constexpr int CS = Lds<N, COLS, T, WORD == 4>::CS;
   // packed-real modes move complex pairs on both sides; the Hermitian pass is in the kernel body
   constexpr bool HALF = MODE == MODE_R2C_H || MODE == MODE_C2R_H;
   constexpr int IOMODE = HALF ? MODE_C2C : MODE;
@@ -966,7 +976,7 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   constexpr int NT = N / R;
   constexpr int threads = T * NT;
   static_assert(threads >= 64 && threads <= 1024, "workgroup size");
-  constexpr size_t lds_x = (sizeof...(RADS) > 1 || (FLAGS & 32) || MODE == MODE_R2C_H || MODE == MODE_C2R_H) ? (size_t)T * Lds<N, COLS, T>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
+  constexpr size_t lds_x = (sizeof...(RADS) > 1 || (FLAGS & 32) || MODE == MODE_R2C_H || MODE == MODE_C2R_H) ? (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real) == 4)>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
   constexpr size_t lds_f = (FLAGS & 16) ? (size_t)T * 2 * sizeof(real) : 0;
   constexpr size_t lds = lds_x > lds_f ? lds_x : lds_f;
   static_assert(lds <= 160 * 1024, "LDS budget");

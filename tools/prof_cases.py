@@ -49,6 +49,10 @@ CASES = {
     'c2f': lambda: serial((128, 1 << 20), 'F', (1,)),
     'cols4096': lambda: serial((4096, 4096), 'D', (0,)),
     'cols2048': lambda: serial((2048, 2048, 4), 'D', (0,)),
+    'mix3f': lambda: serial((512, 1536, 512), 'F', (1,)),
+    'mix5f': lambda: serial((512, 1280, 512), 'F', (1,)),
+    'mix3f8': lambda: serial((256, 3072, 512), 'F', (1,)),
+    'cols4096f': lambda: serial((4096, 4096, 8), 'F', (0,)),
 }
 for name in sys.argv[1:]:
     CASES[name]()

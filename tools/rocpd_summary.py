@@ -23,7 +23,7 @@ def main():
     tot = sum(r[2] for r in rows) or 1
     print('# kernel-trace summary of %s' % db)
     print('%-8s %12s %12s %12s %12s %7s  %s' % ('calls', 'total_us', 'avg_us', 'min_us', 'max_us', 'pct', 'kernel'))
-    for name, n, s, a, mn, mx in rows[:12]:
+    for name, n, s, a, mn, mx in rows[:40]:
         print('%-8d %12.1f %12.1f %12.1f %12.1f %6.2f%%  %s' % (n, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100 * s / tot, short(name)))
     try:
         crow = cur.execute("select counter_name, kernel_name, count(*), avg(value), min(value), max(value) "
@@ -36,7 +36,7 @@ def main():
         print('%-12s %-8s %16s %16s %16s  %s' % ('counter', 'calls', 'mean', 'min', 'max', 'kernel'))
         # this library's kernels first (a counter that reads 0 would otherwise fall off the list)
         crow.sort(key=lambda r: 0 if 'gfft::' in r[1] else 1)
-        for cn, kn, n, a, mn, mx in crow[:12]:
+        for cn, kn, n, a, mn, mx in crow[:80]:
             print('%-12s %-8d %16.1f %16.1f %16.1f  %s' % (cn, n, a, mn, mx, short(kn)))
 
 
