@@ -108,7 +108,11 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
           case 1: return P32(1024, 16, 16, true, true, 1, 16, 16, 4);
           case 8: return P32F(1024, 32, 32, true, true, 1, 8 | 256, 16, 16, 4);   // A/B: line not pinned before the stores
           // A/B: two 512-thread workgroups per CU (one computes while the other loads) on 128-byte
-          // segments: 1024^3 c64 axis 1 3.60 ms (default 3.58), axis 0 5.38 (4.43) -- segment width wins
+          // segments: 1024^3 c64 axis 1 3.60 ms (default 3.58), axis 0 5.38 (4.43) -- segment width wins.
+          // Re-measured after the 4-byte LDS bank rule (tools/variant_probe_f32.py; this variant's T = 16
+          // exchanges had been the conflicting ones): pitched rows near 3.40 (3.55) / far 3.90 (3.99),
+          // natural rows near 3.50 (3.53) / far 4.94 (4.15) -- ahead by 2-4 % only where both sides are
+          // pitched, behind by 19 % on natural far strides: still not the default.
           case 2: return P32F(1024, 32, 16, true, true, 4, 8, 16, 16, 4);
         }
       case 2048:
