@@ -80,6 +80,30 @@ def main():
     z1 = z.redistribute(1)
     n1 = sum(world.allgather_obj(float(np.sum(np.asarray(z1) ** 2))))
     assert np.isclose(n0, n1)
+    # storage boundary (io.py): the ranks take turns at one NetCDF file, then everybody reads it back
+    import tempfile
+    from mpi4py_fft_amd import NCFile
+    from scipy.io import netcdf_file
+    path = world.bcast(os.path.join(tempfile.mkdtemp(), 'snap.nc') if r == 0 else None)
+    G = np.random.default_rng(5).standard_normal(N)
+    z[...] = G[z.local_slice()]
+    if r == 0:
+        NCFile(path, mode='w')
+    world.barrier()
+    f = NCFile(path, mode='a')
+    for step in (0, 1):
+        f.write(step, {'u': [z, (z, [slice(None), 3, slice(None)])]})
+    z1.write(path, 'u1', 0)                     # a differently aligned array of the same grid
+    back = DistArray(N, subcomm=sub, dtype=float, alignment=2)
+    back.read(path, 'u', 1)
+    assert np.array_equal(np.asarray(back), G[z.local_slice()])
+    world.barrier()
+    if r == 0:
+        nc = netcdf_file(path, 'r', mmap=False)
+        assert np.array_equal(nc.variables['u'].data[1], G)
+        assert np.array_equal(nc.variables['u_slice_3_slice'].data[0], G[:, 3, :])
+        assert nc.variables['u1'].data.shape[1:] == N           # (records are shared: two of them)
+        nc.close()
     world.barrier()
     if r == 0:
         print('GLOO_WORKER_OK ranks=%d' % P)
