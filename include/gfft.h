@@ -97,6 +97,18 @@ int gfft_scratch_release(void);           /* frees the shared per-stream workspa
  * reference's Nyquist rules.  GFFT_ERR_UNSUPPORTED = not fusable for this plan (use
  * gfft_truncate / gfft_pad); the plan is left unchanged. */
 int gfft_plan_set_truncation(gfft_plan plan, int64_t n_keep);
+/* The whole padded 3-D transform of a one-rank PFFT(padding=...) as ONE plan: what the reference runs
+ * as three FFT objects, each followed (forward) by _truncation_forward or preceded (backward) by
+ * _padding_backward (libfft.py:263-311, 408-422; chained by mpifft.py:68-73 with identity transfers).
+ * `padded` = the transformed lengths = shape of the physical array (real for R2C / C2R); `kept` =
+ * shape of the truncated spectral array (entries kept per axis: N on complex axes, N/2 + 1 on the
+ * real half-axis, axis 2).  Forward kinds read the physical array and write the truncated one,
+ * backward kinds the reverse; every pass carries its axis's truncating store / zero-padding load and
+ * the intermediates live in the plan's pitched workspace (rows of the odd-width half spectrum start on
+ * 128-byte lines there), never in arrays of the caller.  The input is preserved.
+ * GFFT_ERR_UNSUPPORTED when a padded length has no single-pass kernel (caller keeps the per-axis
+ * plans with gfft_plan_set_truncation). */
+int gfft_plan_create_padded(gfft_plan *plan, const int64_t *padded, const int64_t *kept, int kind, int precision);
 /* Fuse the pack / unpack side of Transfer (pencil.py:12-29,182,200: the subarray datatypes of
  * Alltoallw) into a single-axis complex plan.  side 1: gfft_execute writes its output directly
  * in the layout of the all-to-all SEND buffer for `nblocks` equal blocks of the transformed axis

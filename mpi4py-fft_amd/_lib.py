@@ -49,6 +49,7 @@ def _declare(lib):
         'gfft_plan_destroy': (c.c_int, [vp]),
         'gfft_scratch_release': (c.c_int, []),
         'gfft_plan_set_truncation': (c.c_int, [vp, c.c_int64]),
+        'gfft_plan_create_padded': (c.c_int, [c.POINTER(vp), i64p, i64p, c.c_int, c.c_int]),
         'gfft_plan_set_split': (c.c_int, [vp, c.c_int, c.c_int]),
         'gfft_plan_create_guru': (c.c_int, [c.POINTER(vp), c.c_int, c.c_int, c.POINTER(IoDim), c.c_int, c.POINTER(IoDim),
                                             c.c_int, c.c_int64, c.c_int, c.c_int64]),
@@ -205,6 +206,16 @@ class HipEngine:
         self.require_device(tin)
         self.require_device(tout)
         check(lib().gfft_execute(h, tin.data_ptr(), tout.data_ptr(), float(scale), current_stream()))
+
+    def plan_create_padded(self, padded, kept, kind, precision):
+        """The padded 3-D transform of a one-rank PFFT as one plan, or None when libgfft keeps the
+        per-axis form (gfft_plan_create_padded)."""
+        h = ctypes.c_void_p()
+        rc = lib().gfft_plan_create_padded(ctypes.byref(h), _i64(padded), _i64(kept), int(kind), int(precision))
+        if rc == -2:
+            return None
+        check(rc)
+        return h
 
     def plan_set_truncation(self, h, n_keep):
         """True if the truncation/padding was fused into the plan, False if it cannot be."""

@@ -290,6 +290,7 @@ struct gfft_plan_s {
   double flops = 0, bytes = 0;
   int variant_rows = 0, variant_cols = 0, xcd_swizzle = 0;
   bool fused3 = false;
+  std::vector<int64_t> trunc;                  // gfft_plan_create_padded: kept entries per axis (else empty)
   std::vector<std::vector<hipEvent_t>> prof;   // per execute: events before pass 0 and after each pass
 };
 
@@ -821,9 +822,20 @@ int plan_fused3(gfft_plan_s *pl) {
   const int prec = pl->precision;
   const bool real = pl->kind == GFFT_R2C || pl->kind == GFFT_C2R;
   const bool inverse = pl->kind == GFFT_C2C_BACKWARD || pl->kind == GFFT_C2R;
-  const std::vector<int64_t> &full = (pl->kind == GFFT_C2R) ? pl->sizes_out : pl->sizes_in;
+  // the transformed (padded, physical-side) lengths; with gfft_plan_create_padded the spectral side
+  // keeps t0 x t1 x nc entries of them (3/2-rule truncation / zero padding fused into every pass)
+  const std::vector<int64_t> &full = inverse ? pl->sizes_out : pl->sizes_in;
   const int64_t n0 = full[0], n1 = full[1], n2 = full[2];
-  const int64_t nc = real ? n2 / 2 + 1 : n2;           // complex entries per row
+  const bool tr = pl->trunc.size() == 3;
+  const int64_t nc_full = real ? n2 / 2 + 1 : n2;      // complex entries per transformed row
+  const int64_t nc = tr ? pl->trunc[2] : nc_full;      // complex entries per stored row
+  const int64_t t0 = tr ? pl->trunc[0] : n0, t1 = tr ? pl->trunc[1] : n1;
+  auto keep = [&](Pass &p, int64_t kept, int64_t of) {   // libfft.py:263-311 as the pass's store / load adapter
+    if (kept == of) return;
+    p.d.tr_dir = inverse ? 2 : 1;
+    p.d.tr_n = p.d.tr_N = (int)kept;
+    p.d.tr_even = (kept % 2 == 0) ? 1 : 0;
+  };
   const int64_t esz = 2 * prec;
   // workspace row pitch: rows start on 128-B lines; +256 B when the pitch would be a multiple of 2 KiB
   const int64_t seg = 128 / esz;
@@ -861,7 +873,7 @@ int plan_fused3(gfft_plan_s *pl) {
   // whenever n1 * (n/2+1) * 16 B is a multiple of 128 -- reading the workspace, now W[i0][i1][c],
   // through per-lane (row, column) addresses (misaligned loads, 3.8 ms).  Backward keeps the
   // layout above: its first pass already has the misalignment on the load side.
-  const bool flat_out = real && !inverse && Pu != nc && (n1 * nc * esz) % 128 == 0 && opts().flat_out;
+  const bool flat_out = real && !inverse && !tr && Pu != nc && (n1 * nc * esz) % 128 == 0 && opts().flat_out;
   if (flat_out) { w_i0 = n1 * P; w_i1 = P; }
   // rows: transform along axis 2.  The batch runs fastest along whichever of (i0, i1) makes the
   // rows it READS consecutive in memory (reading scattered 16-KiB rows measured 6.7 ms per pass,
@@ -871,7 +883,7 @@ int plan_fused3(gfft_plan_s *pl) {
     Pass p = base((int)n2, mode);
     p.cols = false;
     p.d.batch = n0 * n1;
-    const int64_t nat_in = (mode == MODE_R2C) ? n2 : nc, nat_out = (mode == MODE_C2R) ? n2 : nc;
+    const int64_t nat_in = n2, nat_out = n2;   // the natural side of a row pass is the physical array
     const int64_t in_i0 = in_ws ? w_i0 : n1 * nat_in, in_i1 = in_ws ? w_i1 : nat_in;
     const int64_t out_i0 = out_ws ? w_i0 : n1 * nat_out, out_i1 = out_ws ? w_i1 : nat_out;
     if (!in_ws) {   // o = i0, i = i1
@@ -897,6 +909,7 @@ int plan_fused3(gfft_plan_s *pl) {
       else { p.d.out_os /= 2; p.d.out_is /= 2; }
       if (mode == MODE_R2C && out_ws) p.d.out_pad = (int)(Pu - nc);
     }
+    keep(p, nc, nc_full);
     return p;
   };
   // axis 1: batch (o = i0, i = c)
@@ -904,16 +917,17 @@ int plan_fused3(gfft_plan_s *pl) {
     Pass p = base((int)n1, MODE_C2C);
     p.cols = true;
     // tiles cover the line-rounded width; the natural side is masked to its nc columns
-    p.d.batch = n0 * Pu;
+    p.d.batch = t0 * Pu;
     p.d.inner = Pu;
     p.data_inner = nc;
     if (Pu != nc) {
       if (!in_ws) p.d.inner_ld = nc;
       if (!out_ws) p.d.inner_st = nc;
     }
-    p.d.in_os = in_ws ? w_i0 : n1 * nc;   p.d.in_es = in_ws ? w_i1 : nc;
-    p.d.out_os = out_ws ? w_i0 : n1 * nc; p.d.out_es = out_ws ? w_i1 : nc;
+    p.d.in_os = in_ws ? w_i0 : t1 * nc;   p.d.in_es = in_ws ? w_i1 : nc;
+    p.d.out_os = out_ws ? w_i0 : t1 * nc; p.d.out_es = out_ws ? w_i1 : nc;
     p.src = src; p.dst = dst;
+    keep(p, t1, n1);
     return p;
   };
   // axis 0 inside the workspace: batch (o = i1, i = c)
@@ -926,6 +940,7 @@ int plan_fused3(gfft_plan_s *pl) {
     p.d.in_os = w_i1;  p.d.in_es = w_i0;
     p.d.out_os = w_i1; p.d.out_es = w_i0;
     p.src = src; p.dst = dst;
+    keep(p, t0, n0);      // in place: a column is loaded whole before its first entry is stored
     return p;
   };
   // axis 0 from W[i0][i1][c] to the natural output, tiles over the flattened (i1, c) index
@@ -966,7 +981,9 @@ int plan_fused3(gfft_plan_s *pl) {
     const bool r2c = p.d.mode == MODE_R2C || p.d.mode == MODE_R2C_H, c2r = p.d.mode == MODE_C2R || p.d.mode == MODE_C2R_H;
     pl->flops += (p.d.mode == MODE_C2C ? 1.0 : 0.5) * 5.0 * n * std::log2(n) * lines;
     const double ein = r2c ? prec : esz, eout = c2r ? prec : esz;
-    const double nin = c2r ? (double)nc : n, nout = r2c ? (double)nc : n;
+    double nin = c2r ? (double)nc_full : n, nout = r2c ? (double)nc_full : n;
+    if (p.d.tr_dir == 1) nout = p.d.tr_n;
+    if (p.d.tr_dir == 2) nin = p.d.tr_n;
     pl->bytes += lines * (nin * ein + nout * eout);
     pl->passes.push_back(p);
   }
@@ -1155,6 +1172,52 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
     return rc;
   }
   // the scale factor rides on the last pass
+  pl->passes.back().carries_scale = true;
+  *plan = pl;
+  ++g_live_plans;
+  return GFFT_OK;
+}
+
+int gfft_plan_create_padded(gfft_plan *plan, const int64_t *padded, const int64_t *kept, int kind, int precision) {
+  if (!plan || !padded || !kept) return fail(GFFT_ERR_INVALID, "null argument");
+  *plan = nullptr;
+  if (precision != GFFT_F32 && precision != GFFT_F64) return fail(GFFT_ERR_INVALID, "precision must be 4 or 8");
+  if (kind != GFFT_C2C_FORWARD && kind != GFFT_C2C_BACKWARD && kind != GFFT_R2C && kind != GFFT_C2R)
+    return fail(GFFT_ERR_INVALID, "kind must be c2c forward / backward, r2c or c2r");
+  const bool real = kind == GFFT_R2C || kind == GFFT_C2R;
+  const bool inverse = kind == GFFT_C2C_BACKWARD || kind == GFFT_C2R;
+  for (int i = 0; i < 3; ++i) {
+    const int64_t of = (real && i == 2) ? padded[i] / 2 + 1 : padded[i];
+    if (padded[i] < 1 || kept[i] < 1 || kept[i] > of) return fail(GFFT_ERR_INVALID, "kept entries must lie in 1 .. transformed entries");
+  }
+  int rc = check_device();
+  if (rc) return rc;
+  // the all-axes schedule needs one register-kernel pass per axis (packed-real rows on a real axis)
+  if (!opts().fused3) return fail(GFFT_ERR_UNSUPPORTED, "fused 3-D plans are switched off");
+  for (int i = 0; i < 3; ++i)
+    if (!regk_ok(padded[i], precision)) return fail(GFFT_ERR_UNSUPPORTED, "padded length without a single-pass kernel");
+  if (real && !(opts().real_half && padded[2] % 2 == 0 &&
+                (real_half_supported((int)(padded[2] / 2)) || real_half_mix_supported((int)(padded[2] / 2)))))
+    return fail(GFFT_ERR_UNSUPPORTED, "real axis without a packed-real row kernel");
+  const int64_t bytes = padded[0] * padded[1] * padded[2] * (real ? 1 : 2) * precision;
+  if (bytes < opts().fused3_min_bytes) return fail(GFFT_ERR_UNSUPPORTED, "below the size where the workspace schedule pays");
+  gfft_plan_s *pl = new gfft_plan_s;
+  pl->ndims = 3;
+  pl->kind = kind;
+  pl->precision = precision;
+  std::vector<int64_t> phys(padded, padded + 3), spec(kept, kept + 3);
+  pl->sizes_in = inverse ? spec : phys;
+  pl->sizes_out = inverse ? phys : spec;
+  pl->axes = {0, 1, 2};
+  pl->trunc = spec;
+  pl->variant_rows = opts().variant_rows;
+  pl->variant_cols = opts().variant_cols;
+  pl->xcd_swizzle = opts().xcd_swizzle;
+  rc = plan_fused3(pl);
+  if (rc) {
+    delete pl;
+    return rc;
+  }
   pl->passes.back().carries_scale = true;
   *plan = pl;
   ++g_live_plans;

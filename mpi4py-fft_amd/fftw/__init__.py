@@ -87,6 +87,27 @@ class FFT:
             # same failure mode as fftw_xfftn.pyx:152-153
             raise RuntimeError('Failure creating gfft plan: %s' % e)
 
+    @classmethod
+    def padded(cls, input_array, output_array, kind, normalization=1.0):
+        """The whole padded 3-D transform of a one-rank PFFT as one plan (gfft_plan_create_padded):
+        the physical side has the padded shape, the spectral side the truncated one.  None when the
+        engine keeps the per-axis form."""
+        eng = _lib.engine()
+        if not hasattr(eng, 'plan_create_padded'):
+            return None
+        inverse = kind in (C2C_BACKWARD, C2R)
+        phys, spec = (output_array, input_array) if inverse else (input_array, output_array)
+        h = eng.plan_create_padded(phys.shape, spec.shape, kind, _lib.precision_of(input_array.dtype))
+        if h is None:
+            return None
+        self = cls.__new__(cls)
+        self.axes, self.kind, self._M = (0, 1, 2), kind, float(normalization)
+        self._input_array, self._output_array = input_array, output_array
+        self.input_shape, self.output_shape = tuple(input_array.shape), tuple(output_array.shape)
+        self.input_strides, self.output_strides = input_array.strides, output_array.strides
+        self._precision, self._eng, self._plan = _lib.precision_of(input_array.dtype), eng, h
+        return self
+
     def __del__(self):
         self.destroy()
 

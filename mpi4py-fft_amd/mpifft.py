@@ -227,6 +227,8 @@ class PFFT:
         local = all(t.comm.Get_size() == 1 for t in self.transfer)
         if local and padding is False and transforms is None and len(self.xfftn) > 1 and fuse:
             fused_fwd, fused_bck = self._plan_fused()
+        elif local and transforms is None and len(self.xfftn) == 3 and fuse:
+            fused_fwd, fused_bck = self._plan_fused_padded()
         if not local:
             if fuse_pack:
                 self._fuse_packs()
@@ -461,6 +463,46 @@ class PFFT:
         s = tuple(np.take(U.shape, flat))
         fwd = (fftw.rfftn if real else fftw.fftn)(U, s=s, axes=flat, output_array=V)
         bck = (fftw.irfftn if real else fftw.ifftn)(V, s=s, axes=flat, output_array=U)
+        return self._fused_callables(fwd, bck, U, V)
+
+    def _plan_fused_padded(self):
+        """One rank, 3-D, ``padding=``: the three padded stages (each an FFT with its 3/2-rule
+        truncation / zero padding, libfft.py:263-311,408-422) as ONE plan whose intermediates live in
+        libgfft's pitched workspace (gfft_plan_create_padded) -- the odd-width half-spectrum rows of
+        a real transform are then line aligned everywhere except in the caller's own arrays.
+        (None, None) keeps the staged chain (lengths without single-pass kernels, small arrays)."""
+        from . import fftw
+        U = self.xfftn[0].forward.input_array
+        V = self.xfftn[-1].forward.output_array
+        if len(U.shape) != 3 or self.axes != ((0,), (1,), (2,)):
+            return None, None
+        if all(abs(x.padding_factor - 1.0) < 1e-8 for x in self.xfftn):
+            return None, None
+        # Which direction takes the one-plan form is a measurement (tools/padded_probe.py, one MI355X):
+        # the gain is the pitched workspace under the FAR-axis pass, which the staged chain runs on the
+        # caller's power-of-two strides in the backward direction only -- 683^3 -> 1024^3 c128 backward
+        # 14.4 -> 12.7 ms, 512^3 -> 768^3 r2c f64 2.95 -> 2.80 ms; forward is level (13.2 vs 13.6 ms),
+        # and in fp32 the mixed-radix strided kernels bound both forms alike (3.7 / 4.6 ms either way).
+        # GFFT_PADDED_ONE_PLAN = "fwd,bwd" | "bwd" | "fwd" | "none" overrides.
+        which = os.environ.get('GFFT_PADDED_ONE_PLAN')
+        if which is None:
+            which = 'bwd' if np.dtype(U.dtype).itemsize // (1 if np.dtype(U.dtype).kind == 'f' else 2) == 8 else 'none'
+        which = [w for w in which.replace(' ', '').split(',') if w in ('fwd', 'bwd')]
+        if not which:
+            return None, None
+        real = np.dtype(U.dtype).kind == 'f'
+        M = 1.0 / float(np.prod(U.shape))
+        fwd = fftw.FFT.padded(U, V, fftw.R2C if real else fftw.C2C_FORWARD, M)
+        if fwd is None:
+            return None, None
+        bck = fftw.FFT.padded(V, U, fftw.C2R if real else fftw.C2C_BACKWARD, M)
+        if bck is None:
+            fwd.destroy()
+            return None, None
+        forward, backward = self._fused_callables(fwd, bck, U, V)
+        return (forward if 'fwd' in which else None), (backward if 'bwd' in which else None)
+
+    def _fused_callables(self, fwd, bck, U, V):
         self._fused_plans = (fwd, bck)
         M = fwd.get_normalization()
 

@@ -354,3 +354,52 @@ def test_reference_docs_convolution_example(P):
     for r, got in enumerate(cases.run_ranks(P, body)):
         assert got.shape == want[r].shape
         assert np.abs(got - want[r]).max() <= 1e-12 * np.abs(want[r]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', 'dfDF')
+@pytest.mark.parametrize('shape,padding', [((32, 32, 64), [1.5] * 3), ((64, 32, 128), [1.5] * 3),
+                                           ((32, 64, 32), [1.5, 1, 2]), ((27, 32, 64), [1.5] * 3),
+                                           ((128, 27, 64), [1.5, 1.5, 1.5])])
+def test_padded_transform_as_one_plan(dt, shape, padding, monkeypatch):
+    """One rank, padding: the three padded stages run as ONE plan through libgfft's pitched workspace
+    (gfft_plan_create_padded).  Forward against the oracle (libfft.py:263-311 per stage), forward and
+    backward against the staged chain of per-axis plans, and the reference's idempotence checks
+    (tests/test_mpifft.py:229-251)."""
+    from mpi4py_fft_amd import PFFT, comm, _lib
+    from oracle import pfft_oracle as O
+    _lib.set_option('fused3_min_mib', 0)
+    monkeypatch.setenv('GFFT_PADDED_ONE_PLAN', 'fwd,bwd')       # (the default picks per direction by measurement)
+    try:
+        one = PFFT(comm.COMM_SELF, shape, dtype=dt, padding=list(padding))
+        assert one._fused_plans is not None, 'the padded plan was not taken'
+    finally:
+        _lib.set_option('fused3_min_mib', 32)
+    monkeypatch.delenv('GFFT_PADDED_ONE_PLAN')
+    staged = PFFT(comm.COMM_SELF, shape, dtype=dt, padding=list(padding), fuse=False)
+    assert staged._fused_plans is None
+    ref = O.OPFFT(1, shape, dtype=dt, padding=list(padding))
+    G = O.rng_array(ref.input_shape, dt, 11)
+    want = ref.forward(ref.scatter(G))[0]
+    tol = 2e-10 if dt in 'dD' else 2e-4
+    u = np.asarray(G)
+    uh = np.asarray(one.forward(u)).copy()
+    assert uh.shape == want.shape
+    assert np.abs(uh - want).max() <= tol * np.abs(want).max()
+    uh_s = np.asarray(staged.forward(u)).copy()
+    assert np.abs(uh - uh_s).max() <= tol * np.abs(uh_s).max()
+    assert np.array_equal(np.asarray(one.forward.input_array), u), 'the input must be preserved'
+    # backward of the same spectrum, both ways; then forward again (idempotence on the truncated space)
+    b1 = np.asarray(one.backward(uh_s)).copy()
+    b2 = np.asarray(staged.backward(uh_s)).copy()
+    assert b1.shape == b2.shape == tuple(one.forward.input_array.shape)
+    assert np.abs(b1 - b2).max() <= tol * max(np.abs(b2).max(), 1e-30)
+    again = np.asarray(one.forward(b1))
+    assert np.abs(again - uh_s).max() <= 10 * tol * np.abs(uh_s).max()
+    # swapped normalisation (test_mpifft.py:240-248)
+    one.backward.input_array[...] = uh_s
+    one.backward(normalize=True)
+    one.forward(normalize=False)
+    assert np.abs(np.asarray(one.forward.output_array) - uh_s).max() <= 10 * tol * np.abs(uh_s).max()
+    one.destroy()
+    staged.destroy()

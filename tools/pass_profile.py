@@ -25,6 +25,11 @@ def run(shape, dt, **kw):
     fft.destroy()
 
 print(torch.cuda.get_device_name(0))
+if len(sys.argv) > 1 and sys.argv[1] == 'padded':
+    for fuse in (True, False):
+        run((1024, 512, 512), 'f', padding=[1.5] * 3, fuse=fuse)
+        run((512, 512, 512), 'd', padding=[1.5] * 3, fuse=fuse)
+    sys.exit(0)
 run((1024,) * 3, 'D')
 run((1024,) * 3, 'd')
 run((1024,) * 3, 'F')
