@@ -114,6 +114,10 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
           // natural rows near 3.50 (3.53) / far 4.94 (4.15) -- ahead by 2-4 % only where both sides are
           // pitched, behind by 19 % on natural far strides: still not the default.
           case 2: return P32F(1024, 32, 16, true, true, 4, 8, 16, 16, 4);
+          // A/B: two radix-32 stages = ONE exchange instead of two (LDS cycles and barriers halved), but the
+          // 32-point butterfly with its 31 stage twiddles does not fit 128 VGPRs at 1024 threads
+          // (116 B of scratch per lane): pitched near 4.33 ms against 3.61, far 5.18 against 4.02
+          case 3: return P32F(1024, 32, 32, true, true, 1, 8, 32, 32);
         }
       case 2048:
         switch (variant) {

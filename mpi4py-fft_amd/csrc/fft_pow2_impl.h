@@ -105,6 +105,48 @@ template <typename real, int S> __device__ __forceinline__ void dft16(cx<real> *
     }
 }
 
+// compile-time cos of 2 pi m / 32 for the radix-32 internal twiddles
+template <typename real> struct W32 {
+  static constexpr real C[32] = {
+      (real)1.0, (real)0.98078528040323044913, (real)0.92387953251128675613, (real)0.83146961230254523708,
+      (real)0.70710678118654752440, (real)0.55557023301960222474, (real)0.38268343236508977173, (real)0.19509032201612826785,
+      (real)0.0, (real)-0.19509032201612826785, (real)-0.38268343236508977173, (real)-0.55557023301960222474,
+      (real)-0.70710678118654752440, (real)-0.83146961230254523708, (real)-0.92387953251128675613, (real)-0.98078528040323044913,
+      (real)-1.0, (real)-0.98078528040323044913, (real)-0.92387953251128675613, (real)-0.83146961230254523708,
+      (real)-0.70710678118654752440, (real)-0.55557023301960222474, (real)-0.38268343236508977173, (real)-0.19509032201612826785,
+      (real)0.0, (real)0.19509032201612826785, (real)0.38268343236508977173, (real)0.55557023301960222474,
+      (real)0.70710678118654752440, (real)0.83146961230254523708, (real)0.92387953251128675613, (real)0.98078528040323044913};
+  // exp(-2 pi i m / 32) = (C[m], -C[(m + 24) % 32])   since sin(x) = cos(x - pi/2)
+  static __device__ __forceinline__ cx<real> mul(cx<real> a, int m) {
+    const real wx = C[m % 32], wy = -C[(m + 24) % 32];
+    return {a.x * wx - a.y * wy, a.x * wy + a.y * wx};
+  }
+};
+
+template <typename real, int S> __device__ __forceinline__ void dft32(cx<real> *v) {
+  // n = i + 4a (i < 4, a < 8);  X[k1 + 8 k2] = sum_i W4^(i k2) W32^(i k1) sum_a x[i + 4a] W8^(a k1)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dft8<real, 4 * S>(v + i * S);          // Y_i[k1] at position i + 4 k1
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) {
+      if (i * k1 == 4) v[(i + 4 * k1) * S] = mul_w8_1(v[(i + 4 * k1) * S]);
+      else if (i * k1 == 8) v[(i + 4 * k1) * S] = mul_mi(v[(i + 4 * k1) * S]);
+      else if (i * k1 == 12) v[(i + 4 * k1) * S] = mul_w8_3(v[(i + 4 * k1) * S]);
+      else v[(i + 4 * k1) * S] = W32<real>::mul(v[(i + 4 * k1) * S], i * k1);
+    }
+#pragma unroll
+  for (int k1 = 0; k1 < 8; ++k1) bf4(v[(4 * k1) * S], v[(4 * k1 + 1) * S], v[(4 * k1 + 2) * S], v[(4 * k1 + 3) * S]);
+  cx<real> o[32];
+#pragma unroll
+  for (int k1 = 0; k1 < 8; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) o[k1 + 8 * k2] = v[(4 * k1 + k2) * S];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) v[k * S] = o[k];
+}
+
 template <typename real> __device__ __forceinline__ void bf3(cx<real> &a, cx<real> &b, cx<real> &c) {
   const real h = (real)0.86602540378443864676372317075294;   // sin(pi/3)
   cx<real> t1 = b + c;
@@ -214,7 +256,7 @@ template <typename real, int S> __device__ __forceinline__ void dft20(cx<real> *
 }
 
 template <typename real, int r, int S> __device__ __forceinline__ void dft(cx<real> *v) {
-  static_assert(r == 2 || r == 3 || r == 4 || r == 5 || r == 8 || r == 10 || r == 12 || r == 16 || r == 20, "radix");
+  static_assert(r == 2 || r == 3 || r == 4 || r == 5 || r == 8 || r == 10 || r == 12 || r == 16 || r == 20 || r == 32, "radix");
   if constexpr (r == 2) dft2<real, S>(v);
   else if constexpr (r == 3) dft3<real, S>(v);
   else if constexpr (r == 4) dft4<real, S>(v);
@@ -223,6 +265,7 @@ template <typename real, int r, int S> __device__ __forceinline__ void dft(cx<re
   else if constexpr (r == 10) dft10<real, S>(v);
   else if constexpr (r == 12) dft12<real, S>(v);
   else if constexpr (r == 16) dft16<real, S>(v);
+  else if constexpr (r == 32) dft32<real, S>(v);
   else dft20<real, S>(v);
 }
 
@@ -327,6 +370,26 @@ __device__ __forceinline__ void twiddle(cx<real> *v, int k, const cx<real> *__re
         v[13 * S] = cmul(v[13 * S], cmul(w5, w8));
         v[14 * S] = cmul(v[14 * S], cmul(w6, w8));
         v[15 * S] = cmul(v[15 * S], cmul(w7, w8));
+        if constexpr (r >= 32) {
+          const cx<real> w16 = tw[16 * k * step];
+          const cx<real> w24 = cmul(w8, w16);
+          v[16 * S] = cmul(v[16 * S], w16);
+          v[17 * S] = cmul(v[17 * S], cmul(w1, w16));
+          v[18 * S] = cmul(v[18 * S], cmul(w2, w16));
+          v[19 * S] = cmul(v[19 * S], cmul(w3, w16));
+          v[20 * S] = cmul(v[20 * S], cmul(w4, w16));
+          v[21 * S] = cmul(v[21 * S], cmul(w5, w16));
+          v[22 * S] = cmul(v[22 * S], cmul(w6, w16));
+          v[23 * S] = cmul(v[23 * S], cmul(w7, w16));
+          v[24 * S] = cmul(v[24 * S], w24);
+          v[25 * S] = cmul(v[25 * S], cmul(w1, w24));
+          v[26 * S] = cmul(v[26 * S], cmul(w2, w24));
+          v[27 * S] = cmul(v[27 * S], cmul(w3, w24));
+          v[28 * S] = cmul(v[28 * S], cmul(w4, w24));
+          v[29 * S] = cmul(v[29 * S], cmul(w5, w24));
+          v[30 * S] = cmul(v[30 * S], cmul(w6, w24));
+          v[31 * S] = cmul(v[31 * S], cmul(w7, w24));
+        }
       }
     }
   }
