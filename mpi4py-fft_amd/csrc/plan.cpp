@@ -988,6 +988,13 @@ int plan_fused3(gfft_plan_s *pl) {
     pl->passes.push_back(p);
   }
   pl->fused3 = true;
+  // fp32 strided passes of this schedule run between pitched rows, where two 512-thread workgroups
+  // per CU on 128-byte segments (variant 2 of the n = 512 / 1024 tables: one computes while the other
+  // loads) beat one 1024-thread workgroup on 256-byte segments since the 4-byte LDS bank rule --
+  // whole transforms, tools/variant2_pfft_probe.py: 1024^3 r2c f32 5.78 / 5.87 -> 5.44 / 5.59 ms,
+  // 512^3 c64 1.39 / 1.35 -> 1.30 / 1.30 ms, 1024^3 c64 10.7 / 10.9 -> 10.6 / 11.0 ms.  (On natural
+  // power-of-two strides -- the stage arrays of multi-GPU transforms -- the wide tile stays ahead.)
+  if (prec == GFFT_F32 && pl->variant_cols == 0) pl->variant_cols = 2;
   return GFFT_OK;
 }
 
