@@ -72,6 +72,7 @@ struct Options {
   int real_half = 1;         // contiguous real lines as half-length complex transforms (fft_real_*.hip)
   int debug_flat = 0;        // gfft_debug_pass: tiles over the flattened (mid, inner) index
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
+  int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int64_t fused3_min_bytes = 32 << 20;
   Options() {
     if (const char *s = getenv("GFFT_GRID_CAP")) grid_cap = atoi(s);
@@ -1089,6 +1090,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "real_half")) opts().real_half = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
+  else if (!strcmp(key, "ws_skew_kib")) opts().ws_skew_kib = value < 0 ? 0 : value;
   else if (!strcmp(key, "profile")) opts().profile = value;
   else if (!strcmp(key, "xcd_swizzle")) opts().xcd_swizzle = value;
   else if (!strcmp(key, "fused3_min_mib")) opts().fused3_min_bytes = (int64_t)value << 20;
@@ -1290,8 +1292,10 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
   }
   void *scratch = nullptr;
   if (total) {
-    int rc = scratch_pool().get(s, total, &scratch);
+    const size_t skew = (size_t)opts().ws_skew_kib << 10;     // (tools/placement_probe.py)
+    int rc = scratch_pool().get(s, total + skew, &scratch);
     if (rc) return rc;
+    scratch = static_cast<char *>(scratch) + skew;
   }
   void *bufs[BUF_COUNT] = {const_cast<void *>(d_in), d_out, nullptr, nullptr, nullptr};
   for (int b = BUF_WS; b < BUF_COUNT; ++b)
