@@ -1060,7 +1060,7 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   const int64_t ntiles = (COLS && !BIGTW) ? (d.flat ? (d.batch / flat_cols) * ((flat_cols + T - 1) / T)
                                                     : (d.batch / d.inner) * ((d.inner + T - 1) / T))
                                           : (d.batch + T - 1) / T;
-  const int64_t cap = pow2_grid_cap();
+  const int64_t cap = d.grid_cap > 0 ? d.grid_cap : pow2_grid_cap();
   int grid = (int)(ntiles < cap ? ntiles : cap);
   PassDesc dd = d;
   if (dd.swizzle) {

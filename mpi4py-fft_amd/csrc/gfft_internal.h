@@ -48,6 +48,7 @@ struct PassDesc {
   // (ms == inner * is) the tile's segments are then aligned whenever the array is, whatever the row
   // width (513-wide half spectra); the other side is addressed per lane through (m, i) = divmod(J, inner)
   int flat;
+  int grid_cap;   // workgroups launched at most for this pass (0 = the library default, pow2_grid_cap())
   int out_pad;    // MODE_R2C_H: zero entries written after X[N] (fills the output row's last line)
   // Packed-real rows writing (r2c) / reading (c2r) an all-to-all buffer whose blocks are UNEVEN: the
   // N + 1 entries of the half spectrum dealt to ub_p ranks by the reference's block rule

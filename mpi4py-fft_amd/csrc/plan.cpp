@@ -62,7 +62,7 @@ int check_device() {
 
 // ---- tunables ---------------------------------------------------------------------------
 struct Options {
-  int grid_cap = 4096;
+  int grid_cap = 0;          // workgroups per launch at most; 0 = 4096, and 16384 for the passes of complex 3-D schedules
   int variant_rows = 0;
   int variant_cols = 0;
   int force_generic = 0;
@@ -996,6 +996,15 @@ int plan_fused3(gfft_plan_s *pl) {
   // 512^3 c64 1.39 / 1.35 -> 1.30 / 1.30 ms, 1024^3 c64 10.7 / 10.9 -> 10.6 / 11.0 ms.  (On natural
   // power-of-two strides -- the stage arrays of multi-GPU transforms -- the wide tile stays ahead.)
   if (prec == GFFT_F32 && pl->variant_cols == 0) pl->variant_cols = 2;
+  // Workgroups per launch.  Each walks tiles block, block + grid, ...; more, shorter walks balance the
+  // tail better, too many lose the overlap of one tile's stores with the next one's loads.  Clean A/B
+  // on fixed caller arrays (tools/ab_option_probe.py grid_cap ...), fwd + bwd per step: 1024^3 c128
+  // 38.04 (4096) / 37.64 (16384) / 37.50 (32768) / 39.23 ms (65536 = one tile each); 512^3 c128 4.90 /
+  // 4.81 / 4.79; 768^3 c128 16.96 / 16.82 / 17.26; 1024^3 c64 20.76 / 20.50 / 20.65 -- but real
+  // transforms the other way (1024^3 r2c f64 20.60 / 20.70 / 21.21, f32 11.23 / 11.79): complex
+  // schedules take 16384, everything else keeps 4096 (GFFT_GRID_CAP overrides both).
+  if (!real && opts().grid_cap <= 0)
+    for (Pass &p : pl->passes) p.d.grid_cap = 16384;
   return GFFT_OK;
 }
 
