@@ -1023,6 +1023,11 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   const int64_t esz_out = ((d.mode == MODE_C2R || d.mode == MODE_R2R) ? 1 : 2) * (int64_t)pl->precision;
   const int64_t esz_in = ((d.mode == MODE_R2C || d.mode == MODE_R2R) ? 1 : 2) * (int64_t)pl->precision;
   (void)esz_in;
+  // workgroups per launch of stand-alone row passes (the first / last stage of every multi-GPU
+  // transform): tools/ab_gridcap_serial.py, caps alternated on one plan and the same arrays --
+  // (256,512,1024) c128 rows 0.803 (4096) -> 0.782 ms (16384), (512,1024,2048) f32 r2c rows 1.854 ->
+  // 1.803 ms; strided stand-alone passes are level or lose (far axis 1.001 -> 1.037 ms) and keep 4096
+  if (!d.grid_cap && p.regk && !p.cols && !pl->fused3 && opts().grid_cap <= 0) d.grid_cap = 16384;
   d.swizzle = pl->xcd_swizzle >= 0 ? pl->xcd_swizzle : (p.cols && !d.flat && ((d.out_es * esz_out) % 128 != 0) ? 1 : 0);
   if ((d.mode == MODE_R2C_H || d.mode == MODE_C2R_H) && real_half_supported(d.n))
     return pl->precision == 8 ? launch_real_half_f64(d, pl->variant_rows, in, out, s)
