@@ -1002,9 +1002,10 @@ int plan_fused3(gfft_plan_s *pl) {
   // 38.04 (4096) / 37.64 (16384) / 37.50 (32768) / 39.23 ms (65536 = one tile each); 512^3 c128 4.90 /
   // 4.81 / 4.79; 768^3 c128 16.96 / 16.82 / 17.26; 1024^3 c64 20.76 / 20.50 / 20.65 -- but real
   // transforms the other way (1024^3 r2c f64 20.60 / 20.70 / 21.21, f32 11.23 / 11.79): complex
-  // schedules take 16384, everything else keeps 4096 (GFFT_GRID_CAP overrides both).
-  if (!real && opts().grid_cap <= 0)
-    for (Pass &p : pl->passes) p.d.grid_cap = 16384;
+  // schedules take 16384, real ones 8192 (1024^3 r2c f64 20.60 -> 20.48, f32 11.09 -> 11.04 ms; 2048 and
+  // 1024 lose 1-2 % each), stand-alone strided passes keep 4096 (GFFT_GRID_CAP overrides them all).
+  if (opts().grid_cap <= 0)
+    for (Pass &p : pl->passes) p.d.grid_cap = real ? 8192 : 16384;
   return GFFT_OK;
 }
 
