@@ -106,6 +106,21 @@ class _Fftw:
             except Exception:
                 self.version, self.threads = 'MKL FFTW3 interface', cores
 
+    def set_timelimit(self, seconds):
+        """fftw_set_timelimit where it does something (the real FFTW; MKL's interface exports the
+        symbol as a no-op and its planner ignores the flags anyway): True if MEASURE is now bounded."""
+        import ctypes
+        if self.kind != 'fftw3':
+            return False
+        try:
+            fn = self.lib.fftw_set_timelimit
+            fn.argtypes = [ctypes.c_double]
+            fn.restype = None
+            fn(float(seconds))
+            return True
+        except Exception:
+            return False
+
     def plan(self, arr_in, arr_out, axes, sign, flags):
         """fftw_planxfftn for a c2c kind (fftw_planxfftn.c:10-57)."""
         import ctypes
@@ -121,21 +136,33 @@ class _Fftw:
                                            arr_out.ctypes.data, sign, flags)
 
 
-def _cpu_fftw(cores, budget_s):
+def _cpu_fftw(cores, budget_s, F=None, clock=time.perf_counter, max_n=1024, hard_cap_s=120.0):
     """3-D c2c fwd+bwd through FFTW's guru interface with the stage structure of a 1-rank PFFT
     (mpifft.py:313-331: axis 2, then 1, then 0, forward scaled by 1/N); when the library cannot plan
     a one-axis transform with two batch dims (MKL's interface) the collapse=True form -- one 3-D
-    plan -- is used instead."""
+    plan -- is used instead.
+
+    The sample ladder is 256^3 -> 512^3 -> 1024^3 (BASELINE.md section 4 asks for 1024^3, else 512^3
+    stated).  Planning has its OWN bound (FFTW_MEASURE under fftw_set_timelimit where the library
+    has it, FFTW_ESTIMATE otherwise) and never counts against `budget_s`, which bounds the timed
+    executions only: one warm-up and best of >= 3 per rung.  The ladder stops before a rung whose
+    predicted executions do not fit what is left of the budget -- except that 512^3 is still taken
+    while it fits `hard_cap_s`: a sample that never leaves the host caches is not a baseline for a
+    16 GiB transform.  `F`, `clock`, `max_n`: injection points of tests/test_bench_cpu_baseline.py."""
     import numpy as np
-    F = _Fftw(cores)
-    n, best = 128, None
-    while n <= 1024:
+    F = _Fftw(cores) if F is None else F
+    flags, flag_name = F.ESTIMATE, 'FFTW_ESTIMATE'
+    if getattr(F, 'set_timelimit', None) is not None and F.set_timelimit(4.0):
+        flags, flag_name = F.MEASURE, 'FFTW_MEASURE (fftw_set_timelimit 4 s per plan)'
+    best, spent, why_stopped = None, 0.0, ''
+    for n in (256, 512, 1024):
+        if n > max_n:
+            break
         shape = (n, n, n)
         u = np.empty(shape, dtype='D')
         v = np.empty(shape, dtype='D')
-        t_plan = time.perf_counter()
+        t_plan = clock()
         form = 'per-axis plans (2, 1, 0)'
-        flags = F.MEASURE if n <= 256 else F.ESTIMATE   # MEASURE at 512^3+ would eat the time budget
         fwd = [F.plan(u, v, [2], -1, flags), F.plan(v, v, [1], -1, flags), F.plan(v, v, [0], -1, flags)]
         bwd = [F.plan(v, v, [0], 1, flags), F.plan(v, v, [1], 1, flags), F.plan(v, u, [2], 1, flags)]
         if not all(fwd + bwd):
@@ -146,7 +173,7 @@ def _cpu_fftw(cores, budget_s):
             fwd, bwd = [F.plan(u, v, [0, 1, 2], -1, flags)], [F.plan(v, u, [0, 1, 2], 1, flags)]
             if not all(fwd + bwd):
                 raise RuntimeError('guru planner returned NULL')
-        t_plan = time.perf_counter() - t_plan
+        t_plan = clock() - t_plan
         # synthetic input: a random complex plane times a random complex factor per slab (filling
         # 16 GiB with the generator itself would take longer than the transforms being timed)
         rng = np.random.default_rng(1234)
@@ -156,43 +183,54 @@ def _cpu_fftw(cores, budget_s):
             np.multiply(plane, w[i], out=u[i])
         u0 = u[:4].copy()
         ex = F.lib.fftw_execute_dft
-        times = []
-        t_all = time.perf_counter()
-        while True:
-            t0 = time.perf_counter()
+
+        def fwd_bwd():
+            t0 = clock()
             srcs = [u] + [v] * (len(fwd) - 1)
             for p, a in zip(fwd, srcs):
                 ex(p, a.ctypes.data, v.ctypes.data)
-            v *= 1.0 / u.size                           # libfft.py:412-413
+            np.multiply(v, 1.0 / u.size, out=v)         # libfft.py:412-413
             dsts = [v] * (len(bwd) - 1) + [u]
             for p, b in zip(bwd, dsts):
                 ex(p, v.ctypes.data, b.ctypes.data)
-            times.append(time.perf_counter() - t0)
-            if len(times) >= 5 or time.perf_counter() - t_all > 0.5 * budget_s:
-                break
+            return clock() - t0
+        warm = fwd_bwd()                                # first touch of v, thread pool spin-up
+        times = []
+        while len(times) < 3 or (len(times) < 5 and spent + warm + sum(times) + min(times) <= budget_s):
+            times.append(fwd_bwd())
+        spent += warm + sum(times)
         err = float(np.linalg.norm(u[:4] - u0) / np.linalg.norm(u0))
         for p in fwd + bwd:
             F.lib.fftw_destroy_plan(p)
         dt = min(times)
         best = dict(value=round(2 * flops_c2c(shape) / dt / 1e9, 2), unit='GFLOP/s', cores=F.threads, kind='port',
                     library='%s (%s)' % (F.version, os.path.basename(F.path)),
-                    sample='%d^3 complex128 fwd+bwd, best of %d, FFTW guru interface as fftw_planxfftn.c builds it, %s, '
-                    '%s, %d threads, round-trip rel err %.1e, %.3f s per fwd+bwd (planning %.1f s)'
-                    % (n, len(times), form, 'FFTW_MEASURE' if flags == F.MEASURE else 'FFTW_ESTIMATE',
-                       F.threads, err, dt, t_plan))
+                    sample='%d^3 complex128 fwd+bwd, best of %d after one warm-up, FFTW guru interface as '
+                    'fftw_planxfftn.c builds it, %s, %s, %d threads, round-trip rel err %.1e, %.3f s per fwd+bwd '
+                    '(planning %.1f s, outside the %.0f s execution budget)'
+                    % (n, len(times), form, flag_name, F.threads, err, dt, t_plan, budget_s))
         assert err < 1e-10, best
         del u, v
-        if max(times[0], t_plan) * 9 > budget_s or n == 1024:
+        if n >= max_n or n == 1024:
             break
-        avail = 0
+        # the next rung: 8x the data, (log2 of it)/(log2 of this) more work per point; warm-up + 3 runs
+        nxt = 2 * n
+        need = 4 * dt * 8 * (np.log2(float(nxt) ** 3) / np.log2(float(n) ** 3)) * 1.1
+        avail = None
         try:
             with open('/proc/meminfo') as f:
                 avail = int(re.search(r'MemAvailable:\s+(\d+)', f.read()).group(1)) * 1024
         except Exception:
             pass
-        if 8 * n ** 3 * 16 * 3 > avail:              # next cube: two arrays + slack
+        if avail is not None and nxt ** 3 * 16 * 2.5 > avail:          # two arrays + slack
+            why_stopped = '%d^3 needs %.0f GiB of host memory, %.0f available' % (nxt, nxt ** 3 * 32 / 2 ** 30, avail / 2 ** 30)
             break
-        n *= 2
+        if spent + need > budget_s and not (nxt <= 512 and need <= hard_cap_s):
+            why_stopped = '%d^3 predicted at %.0f s for warm-up + 3 runs, over the %s' % (
+                nxt, need, '%.0f s budget' % budget_s if nxt > 512 else '%.0f s cap' % hard_cap_s)
+            break
+    if why_stopped:
+        best['sample'] += ' [ladder stopped: %s]' % why_stopped
     return best
 
 
@@ -242,16 +280,146 @@ def cpu_baseline(cores, budget_s=25.0):
 
 
 def relaunch(args):
-    """`python bench.py --gpus N` from a plain shell: one process per GPU under torch.distributed.run."""
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
+    """`python bench.py --gpus N` from a plain shell: one process per GPU under torch.distributed.run.
+    The rendezvous is torchrun's own stand-alone one on the loopback address (it binds its store to a
+    port the OS hands it and keeps it -- nothing is picked, released and re-bound by this script)."""
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (RCCL needs it on this driver)
     env.setdefault('OMP_NUM_THREADS', '1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), os.path.abspath(sys.argv[0])] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+class Guard:
+    """What keeps ONE JSON line coming out of a multi-rank run whatever happens, and every rank
+    leaving with exit code 0 once it has (torchrun reports the job by its workers' exit codes).
+
+    * a deadline per phase (`arm`): the headline itself (RCCL initialisation, the first exchanges)
+      and, later, the extras; on expiry the rank raises the shared abort flag;
+    * an abort flag on the job's rendezvous store (the c10d store every rank already holds; it does
+      not depend on any process group being healthy): raised by a deadline or by a rank whose phase
+      raised, watched by a daemon thread on every rank -- so ranks blocked inside a collective their
+      failed peer never entered still leave;
+    * one exit path (`leave`): rank 0 prints the line, ranks > 0 check out on the store and exit,
+      rank 0 exits LAST (it may be the process the others' connections hang on)."""
+    KEY = 'bench/abort'
+
+    def __init__(self, rank, size, line):
+        self.rank, self.size, self.line = rank, size, line     # line(): the JSON-able dict to print
+        self.phase, self._timer, self._lock, self._left = 'start', None, threading.Lock(), False
+        self._store = None
+        self._watch = None
+
+    def attach_store(self):
+        """A connection of this object's OWN to the job's rendezvous store (MASTER_ADDR:MASTER_PORT,
+        hosted by torchrun's agent or by rank 0): the process group's client serialises its
+        operations, so a watcher sharing it would sit behind a rank blocked in `new_group`."""
+        if self.size <= 1 or self._watch is not None:
+            return
+        try:
+            import datetime
+            import torch.distributed as dist
+            self._store = dist.TCPStore(os.environ['MASTER_ADDR'], int(os.environ['MASTER_PORT']), self.size,
+                                        is_master=False, wait_for_workers=False,
+                                        timeout=datetime.timedelta(seconds=30))
+        except Exception as e:
+            if os.environ.get('GFFT_BENCH_DEBUG'):
+                print('bench guard: no store connection: %r' % (e,), file=sys.stderr, flush=True)
+            self._store = None
+        if self._store is not None:
+            self._watch = threading.Thread(target=self._watcher, daemon=True)
+            self._watch.start()
+
+    def _watcher(self):
+        while True:
+            time.sleep(0.25)
+            try:
+                if self._store.check([self.KEY]):
+                    self.leave(self._store.get(self.KEY).decode(errors='replace'))
+            except Exception as e:
+                if os.environ.get('GFFT_BENCH_DEBUG'):
+                    print('bench watcher: %r' % (e,), file=sys.stderr, flush=True)
+                return                                   # store gone: the job is ending anyway
+
+    def arm(self, phase, seconds):
+        self.disarm()
+        self.phase = phase
+        self._timer = threading.Timer(seconds, lambda: self.abort('deadline of %.0f s hit in phase %r' % (seconds, self.phase)))
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+    def abort(self, why):
+        """Raise the flag for everybody (first writer wins) and leave."""
+        why = 'rank %d: %s' % (self.rank, why)
+        try:
+            if self._store is not None and self.size > 1:
+                if self._store.add(self.KEY + '/n', 1) == 1:
+                    self._store.set(self.KEY, why)
+                else:
+                    why = self._store.get(self.KEY).decode(errors='replace')
+        except Exception:
+            pass
+        self.leave(why)
+
+    def leave(self, why=None):
+        with self._lock:
+            if self._left:
+                time.sleep(3600)
+            self._left = True
+        self.disarm()
+        if self.rank == 0:
+            out = self.line(why)
+            print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        try:
+            if self._store is not None and self.size > 1:
+                if self.rank != 0:
+                    self._store.add(self.KEY + '/left', 1)
+                else:
+                    t_end = time.time() + 10.0
+                    while time.time() < t_end and self._store.add(self.KEY + '/left', 0) < self.size - 1:
+                        time.sleep(0.05)
+                    time.sleep(0.3)
+        except Exception:
+            pass
+        os._exit(0)
+
+
+def wire_diagnostics():
+    """What a failed first multi-GPU run needs on its one line: which RCCL each side binds, and the
+    environment that decides how ranks share memory."""
+    d = {'env': {k: v for k, v in os.environ.items()
+                 if k.startswith(('NCCL_', 'RCCL_', 'HSA_', 'HIP_VISIBLE', 'ROCR_VISIBLE', 'GFFT_', 'MASTER_', 'TORCH_NCCL'))
+                 or k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}}
+    try:
+        import torch
+        d['torch'] = torch.__version__
+        d['torch_rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version()) if torch.cuda.is_available() else None
+        d['devices'] = torch.cuda.device_count()
+    except Exception as e:
+        d['torch_error'] = repr(e)[:200]
+    try:
+        with open('/proc/self/maps') as f:
+            d['librccl_loaded'] = sorted({l.split()[-1] for l in f if 'librccl' in l or 'libnccl' in l})
+    except Exception:
+        pass
+    try:
+        import ctypes
+        from mpi4py_fft_amd import _lib
+        if _lib.engine().name == 'hip':
+            buf = ctypes.create_string_buffer(512)
+            rc = _lib.lib().gfft_rccl_info(buf, 512)
+            d['libgfft_rccl'] = buf.value.decode(errors='replace') if rc == 0 else \
+                'not bound: %s' % _lib.lib().gfft_exchange_last_error().decode(errors='replace')
+    except Exception as e:
+        d['libgfft_rccl'] = 'probe failed: %r' % (e,)
+    return d
 
 
 def timed_steps(world, sync, step, steps):
@@ -265,12 +433,25 @@ def timed_steps(world, sync, step, steps):
     return world.allreduce_max(time.perf_counter() - t0)
 
 
+def failure_line(args, size, why):
+    """The line of a run whose headline never completed: same keys, no number, the reason and the
+    wire's diagnostics."""
+    n = args.n
+    return {'metric': 'pfft_3d_c2c_%dcubed_fp64_gflops' % n, 'value': None, 'unit': 'GFLOP/s', 'n_gpus': size,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'PFFT 3D c2c %d^3 complex128 forward+backward per step' % n},
+            'error': why, 'diagnostics': wire_diagnostics()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', dest='n', type=int, default=1024, help='cube edge (default: the BASELINE config)')
+    ap.add_argument('--headline-deadline', type=float, default=900.0,
+                    help='seconds initialisation + the headline may take at N > 1 before the run gives up (with a line)')
     ap.add_argument('--extras-deadline', type=float, default=180.0,
                     help='seconds the phases after the headline may take at N > 1')
     ap.add_argument('--no-slab', action='store_true', help='skip the slab-grid extra at N > 1')
@@ -280,13 +461,51 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
         sys.exit(relaunch(args))
+    # (also when the driver calls torchrun itself: the host driver only does dmabuf IPC)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    rank_env, size_env = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    state = {'out': None}
 
+    def line(why):
+        out = state['out']
+        if out is None:
+            return failure_line(args, size_env, why or 'no headline')
+        if why:
+            out['extras_error'] = why
+        return out
+    guard = Guard(rank_env, size_env, line)
+    if size_env > 1:
+        guard.arm('initialisation', args.headline_deadline)
+    try:
+        run(args, guard, state)
+    except SystemExit:
+        raise
+    except BaseException as e:
+        if size_env == 1:
+            raise
+        guard.abort('phase %r: %s' % (guard.phase, repr(e)[:300]))
+
+
+def test_hook(guard, rank):
+    """tests/test_bench_launcher.py: GFFT_BENCH_TEST_HANG=<phase> never returns from that phase,
+    GFFT_BENCH_TEST_FAIL=<phase>:<rank> raises in it on one rank."""
+    if os.environ.get('GFFT_BENCH_TEST_HANG') == guard.phase:
+        time.sleep(3600)
+    spec = os.environ.get('GFFT_BENCH_TEST_FAIL', '')
+    if spec and spec.rsplit(':', 1)[0] == guard.phase and int(spec.rsplit(':', 1)[1]) == rank:
+        raise RuntimeError('injected failure in phase %r' % guard.phase)
+
+
+def run(args, guard, state):
     import numpy as np
     import torch
     from mpi4py_fft_amd import PFFT, comm, _lib
     world = comm.init_distributed()
     rank, size = world.Get_rank(), world.Get_size()
     assert size == args.gpus, 'launched with %d ranks but --gpus %d' % (size, args.gpus)
+    guard.attach_store()
+    guard.phase = 'headline'
+    test_hook(guard, rank)
     hip = _lib.engine().name == 'hip'      # anything else was injected by a CPU test of this script
     if hip:
         assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback exists)'
@@ -438,29 +657,19 @@ def main():
                 out['cpu_baseline'] = {'value': None, 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
 
-    def finish(code=0):
-        """Print the line (rank 0) and leave without touching the communicator again."""
-        if rank == 0:
-            print(json.dumps(out), flush=True)
-        sys.stdout.flush()
-        os._exit(code)
-
     if size == 1:
         print(json.dumps(out), flush=True)
         fft.destroy()
         return
 
     # ---------------------------------------------------------------- N > 1: guarded phases
-    state = {'phase': 'start'}
+    state['out'] = out                       # from here on a failure can only add to the line
+    guard.arm('start of the extras', args.extras_deadline)
     best = {'elapsed': elapsed}
 
-    def bail():
-        if rank == 0:
-            out['extras_error'] = 'deadline of %.0f s hit in phase %r' % (args.extras_deadline, state['phase'])
-        finish(0)
-    guard = threading.Timer(args.extras_deadline, bail)
-    guard.daemon = True
-    guard.start()
+    def phase(name):
+        guard.phase = name
+        test_hook(guard, rank)
 
     def stages(tr):
         st = tr.stage_times()
@@ -476,9 +685,7 @@ def main():
 
     try:
         # where a step spends its time, stage by stage (synchronised, max over ranks)
-        state['phase'] = 'stage breakdown'
-        if os.environ.get('GFFT_BENCH_TEST_HANG') == state['phase']:     # tests/test_bench_launcher.py
-            time.sleep(3600)
+        phase('stage breakdown')
         st = {'forward': stages(fft.forward), 'backward': stages(fft.backward)}
         if rank == 0:
             out['stages_ms'] = st
@@ -496,7 +703,7 @@ def main():
                                            ('pipelined', dict(wire='auto', exchange='direct')),
                                            ('pipelined routed', dict(wire='auto', exchange='relay'))]
         for label, kw in variants:
-            state['phase'] = label
+            phase(label)
             try:
                 tuned = PFFT(world, shape, dtype='D', **kw)      # exchange: GFFT_RELAY, default 'auto'
             except Exception as e:        # e.g. no RCCL library to bind: same on every rank
@@ -538,7 +745,7 @@ def main():
                         out['config']['pipeline'] = info['pipeline']
                 best['elapsed'] = min(best['elapsed'], el2)
                 if tuned.pipeline is None:
-                    state['phase'] = 'stage breakdown (%s)' % label
+                    phase('stage breakdown (%s)' % label)
                     st2 = {'forward': stages(tuned.forward), 'backward': stages(tuned.backward)}
                     if rank == 0:
                         out['stages_ms_' + label.replace(' ', '_')] = st2
@@ -552,7 +759,7 @@ def main():
         # the same cube on the slab grid (N,1,1), whose single exchange spans all ranks and
         # therefore all xGMI links
         if sum(1 for c in grid if c > 1) > 1 and n % size == 0 and not args.no_slab:
-            state['phase'] = 'slab grid'
+            phase('slab grid')
             fft.destroy()
             del fft, u, ur
             if dev == 'cuda':
@@ -570,17 +777,14 @@ def main():
             res = {'grid': [c.Get_size() for c in slab.subcomm], 'steps': ksteps,
                    'ms_per_step': round(sel / ksteps * 1e3, 3),
                    'gflops': round(flops / (sel / ksteps) / 1e9, 1)}
-            state['phase'] = 'slab grid stage breakdown'
+            phase('slab grid stage breakdown')
             res['stages_ms'] = {'forward': stages(slab.forward)}
             if rank == 0:
                 out['slab_grid'] = res
             slab.destroy()
-    except BaseException as e:      # never lose the headline to an extra
-        if rank == 0:
-            out['extras_error'] = 'phase %r: %s' % (state['phase'], repr(e)[:300])
-        guard.cancel()
-        finish(0)
-    guard.cancel()
+    except BaseException as e:      # never lose the headline to an extra: every rank leaves, rank 0 prints
+        guard.abort('phase %r: %s' % (guard.phase, repr(e)[:300]))
+    guard.disarm()
     if rank == 0:
         print(json.dumps(out), flush=True)
     world.barrier()

@@ -134,6 +134,30 @@ typedef struct { int64_t n, is, os; } gfft_iodim;
 int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_iodim *dim, int howmany_rank,
                           const gfft_iodim *howmany, int in_blocks, int64_t in_block_stride, int out_blocks,
                           int64_t out_block_stride);
+/* Layouts of INTERNAL exchange buffers (between two stages of a distributed transform; never of a
+ * caller's array, which keeps the reference's C order, pencil.py:347-354).  All three act on one-pass
+ * plans (gfft_plan_create_guru, or gfft_plan_create on one axis) and return GFFT_ERR_UNSUPPORTED,
+ * leaving the plan as it was, when the plan's kernel cannot address the layout.
+ *
+ * gfft_plan_set_tiles: `side` (0 input, 1 output) is tile-major in tiles of `tile` elements (a power
+ *   of two; 0 = off) that start `tile_stride` elements apart.  For a plan along a contiguous axis the
+ *   TRANSFORMED axis is tiled: entry e of a line at (e / tile) * tile_stride + e % tile from the line's
+ *   base (block starts -- gfft_plan_create_guru's in_blocks / out_blocks -- stay where they were).  For a
+ *   strided plan the adjacent COLUMNS (last batch dim) are tiled: column i at (i / tile) * tile_stride +
+ *   i % tile.  One describes the writer, the other the reader of the same buffer: the strided stage's
+ *   tile of adjacent columns is then one contiguous run per workgroup (tools/stage_layout_probe.py).
+ * gfft_plan_set_flat: a strided plan walks tiles over the FLATTENED (second-last, last) batch dims, so
+ *   its accesses are line aligned on a side whose rows lie back to back whatever their width (513-wide
+ *   half spectra).  body_width > 0: on the INPUT side a row is stored as `body_width` columns at the
+ *   planned strides plus its remaining columns at tail_offset + row * tail_row_stride (elements from
+ *   the outermost batch index's base) -- the layout a neighbouring stage writes with two plans.
+ * gfft_plan_set_split_slabs: gfft_plan_set_split for the half-spectrum side of packed-real rows, the
+ *   rows taken as slabs of `rows_per_slab`: block b of slab s is stored as a tile-major body
+ *   [tile][row][`tile` entries] followed by its leftover entries [row][w_b mod tile]; a block's slabs
+ *   lie back to back, the blocks one after the other (same message sizes as gfft_plan_set_split). */
+int gfft_plan_set_tiles(gfft_plan plan, int side, int tile, int64_t tile_stride);
+int gfft_plan_set_flat(gfft_plan plan, int64_t body_width, int64_t tail_offset, int64_t tail_row_stride);
+int gfft_plan_set_split_slabs(gfft_plan plan, int side, int nblocks, int64_t rows_per_slab, int tile);
 int gfft_plan_describe(gfft_plan plan, char *buf, size_t len);
 /* flops (5 n log2 n per line, half for real) and algorithmic bytes (one read + one write of
  * the array per 1-D pass) of one execute, and the number of kernel launches it issues */

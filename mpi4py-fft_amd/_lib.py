@@ -53,6 +53,9 @@ def _declare(lib):
         'gfft_plan_set_split': (c.c_int, [vp, c.c_int, c.c_int]),
         'gfft_plan_create_guru': (c.c_int, [c.POINTER(vp), c.c_int, c.c_int, c.POINTER(IoDim), c.c_int, c.POINTER(IoDim),
                                             c.c_int, c.c_int64, c.c_int, c.c_int64]),
+        'gfft_plan_set_tiles': (c.c_int, [vp, c.c_int, c.c_int, c.c_int64]),
+        'gfft_plan_set_flat': (c.c_int, [vp, c.c_int64, c.c_int64, c.c_int64]),
+        'gfft_plan_set_split_slabs': (c.c_int, [vp, c.c_int, c.c_int, c.c_int64, c.c_int]),
         'gfft_plan_describe': (c.c_int, [vp, c.c_char_p, c.c_size_t]),
         'gfft_plan_cost': (c.c_int, [vp, c.POINTER(c.c_double), c.POINTER(c.c_double), ip]),
         'gfft_pack': (c.c_int, [vp, vp, c.c_int, i64p, c.c_int, c.c_int, c.c_int, vp]),
@@ -229,6 +232,32 @@ class HipEngine:
         """Packed (all-to-all buffer) layout on the plan's input (side 0) / output (side 1);
         True if fused, False if this plan cannot (caller keeps the pack / unpack kernel)."""
         rc = lib().gfft_plan_set_split(h, int(side), int(nblocks))
+        if rc == -2:
+            return False
+        check(rc)
+        return True
+
+    def plan_set_tiles(self, h, side, tile, tile_stride):
+        """Tile-major exchange-buffer layout on one side of a one-pass plan (gfft_plan_set_tiles);
+        False if the plan's kernel cannot address it."""
+        rc = lib().gfft_plan_set_tiles(h, int(side), int(tile), int(tile_stride))
+        if rc == -2:
+            return False
+        check(rc)
+        return True
+
+    def plan_set_flat(self, h, body_width=0, tail_offset=0, tail_row_stride=0):
+        """Tiles over the flattened batch dims of a strided plan, optionally reading rows stored as
+        body + leftover columns (gfft_plan_set_flat)."""
+        rc = lib().gfft_plan_set_flat(h, int(body_width), int(tail_offset), int(tail_row_stride))
+        if rc == -2:
+            return False
+        check(rc)
+        return True
+
+    def plan_set_split_slabs(self, h, side, nblocks, rows_per_slab, tile):
+        """gfft_plan_set_split_slabs: uneven blocks of packed-real rows, slab by slab, tile-major."""
+        rc = lib().gfft_plan_set_split_slabs(h, int(side), int(nblocks), int(rows_per_slab), int(tile))
         if rc == -2:
             return False
         check(rc)

@@ -709,16 +709,26 @@ __device__ __forceinline__ void mirror_pass(cx<real> *v, int t, void *col, cx<re
 // Uneven all-to-all blocks on the half-spectrum side of a packed-real row pass (FLAGS & 128, see
 // PassDesc::ub_*): element offset of entry e of row `row`.  The block of e comes from a chain of at
 // most seven compares against scalar boundaries; no divisions, no table look-ups.
-__device__ __forceinline__ int64_t uneven_offset(const PassDesc &d, unsigned row, int e) {
+__device__ __forceinline__ int64_t uneven_offset(const PassDesc &d, unsigned row, unsigned slab, unsigned srow, int e) {
   int start = 0, width = d.ub_start[1];
+  int64_t base = d.ub_base[0];
 #pragma unroll
   for (int b = 1; b < 8; ++b) {
     if (b < d.ub_p && e >= d.ub_start[b]) {
       start = d.ub_start[b];
       width = d.ub_start[b + 1] - d.ub_start[b];
+      base = d.ub_base[b];
     }
   }
-  return d.ub_rows * (int64_t)start + (int64_t)row * width + (e - start);
+  const int ee = e - start;
+  if (d.ub_n1 > 0) {
+    // slab-wise blocks: tile-major body + leftover columns (PassDesc::ub_n1)
+    const int lg = d.ub_tlg, bw = (width >> lg) << lg;
+    const int64_t s0 = base + (int64_t)slab * (d.ub_n1 * width);
+    if (ee < bw) return s0 + (int64_t)(ee >> lg) * (d.ub_n1 << lg) + ((int64_t)srow << lg) + (ee & ((1 << lg) - 1));
+    return s0 + d.ub_n1 * bw + (int64_t)srow * (width - bw) + (ee - bw);
+  }
+  return d.ub_rows * (int64_t)start + (int64_t)row * width + ee;
 }
 
 // FLAGS: 1 = non-temporal loads, 2 = non-temporal stores, 4 = skip the transform (access-pattern
@@ -758,11 +768,14 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   const real sy_in = d.conj_in ? (real)-1 : (real)1;
   const real sx_out = (real)(MODE == MODE_R2C_H ? 0.5 * d.scale : d.scale);   // (the Hermitian pass leaves 2 X)
   const real sy_out = d.conj_out ? -sx_out : sx_out;
-  const int64_t t_in = (int64_t)t * d.in_es, t_out = (int64_t)t * d.out_es;   // per thread
+  // per thread (tile-major lines, PassDesc::in_tlg / out_tlg: tile index and lane within the tile)
+  const int64_t t_in = (!COLS && d.in_tlg) ? (int64_t)(t >> d.in_tlg) * d.in_tS + (t & ((1 << d.in_tlg) - 1)) : (int64_t)t * d.in_es;
+  const int64_t t_out = (!COLS && d.out_tlg) ? (int64_t)(t >> d.out_tlg) * d.out_tS + (t & ((1 << d.out_tlg) - 1)) : (int64_t)t * d.out_es;
   // fused padding / truncation: distance between the two halves of the padded spectrum (uniform)
   const int64_t pad_shift_in = (FLAGS & 16) ? (int64_t)(d.n - d.tr_N) * d.in_es : 0;
   const int64_t pad_shift_out = (FLAGS & 16) ? (int64_t)(d.n - d.tr_N) * d.out_es : 0;
-  const int64_t q_in = (int64_t)NT * d.in_es, q_out = (int64_t)NT * d.out_es; // uniform steps
+  const int64_t q_in = (!COLS && d.in_tlg) ? (int64_t)(NT >> d.in_tlg) * d.in_tS : (int64_t)NT * d.in_es;     // uniform steps
+  const int64_t q_out = (!COLS && d.out_tlg) ? (int64_t)(NT >> d.out_tlg) * d.out_tS : (int64_t)NT * d.out_es;
 
   // Tile order.  Plain: tile = block + k*grid (adjacent tiles run at the same time on different
   // XCDs).  XCD-contiguous (d.swizzle, grid % 8 == 0): blocks are dealt to XCDs round-robin by
@@ -809,8 +822,17 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
       o = bm / mid;
       m = bm - o * mid;
     }
-    const int64_t in0 = (int64_t)o * d.in_os + (int64_t)m * d.in_ms + (int64_t)i * d.in_is;
-    const int64_t out0 = (int64_t)o * d.out_os + (int64_t)m * d.out_ms + (int64_t)i * d.out_is;
+    int64_t in0 = (int64_t)o * d.in_os + (int64_t)m * d.in_ms, out0 = (int64_t)o * d.out_os + (int64_t)m * d.out_ms;
+    if constexpr (COLS) {
+      // (tile-major columns of an exchange buffer, PassDesc::in_ilg / out_ilg; flat tiles over rows
+      // stored as body + leftover columns, PassDesc::fl_bw)
+      if (d.fl_bw && i >= (unsigned)d.fl_bw) in0 = (int64_t)o * d.in_os + d.fl_tail + (int64_t)m * d.fl_tail_ms + (i - (unsigned)d.fl_bw);
+      else in0 += d.in_ilg ? (int64_t)(i >> d.in_ilg) * d.in_iS + (i & ((1u << d.in_ilg) - 1)) : (int64_t)i * d.in_is;
+      out0 += d.out_ilg ? (int64_t)(i >> d.out_ilg) * d.out_iS + (i & ((1u << d.out_ilg) - 1)) : (int64_t)i * d.out_is;
+    } else {
+      in0 += (int64_t)i * d.in_is;
+      out0 += (int64_t)i * d.out_is;
+    }
     [[maybe_unused]] const unsigned row_ub = o * inner + i;     // FLAGS & 128: row of the exchange buffer
     cx<real> v[R];
     // Split layouts: thread slots e = t + q*NT advance by NT, and a block of the cut axis holds
@@ -834,7 +856,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
           } else if constexpr ((FLAGS & 64) != 0) v[q] = tile_load_pad<real, IOMODE>(d, in, in0, idx, pad_shift_in, tl + q * NT, sy_in);
           else v[q] = tile_load<real, IOMODE, false>(d, in, in0, idx, tl + q * NT, sy_in);
         } else if constexpr (MODE == MODE_C2R_H && (FLAGS & 128) != 0) {
-          v[q] = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, tl + q * NT)];
+          v[q] = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, o, i, tl + q * NT)];
         } else {
           v[q] = tile_load<real, IOMODE, (FLAGS & 1) != 0>(d, in, in0, idx, tl + q * NT, sy_in);
         }
@@ -863,7 +885,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
       cx<real> top = {0, 0};
       if (tl == 0) {
         if constexpr ((FLAGS & 128) != 0) {
-          if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, N)].x;
+          if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, o, i, N)].x;
         } else if constexpr (!(FLAGS & 64)) {
           if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[in0 + (int64_t)N * d.in_es].x;
         }
@@ -1007,7 +1029,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
           } else if constexpr (!(FLAGS & 64)) tile_store_trunc<real, IOMODE>(d, out, idx, pad_shift_out, tl + q * NT, v[q], sx_out, sy_out);
           else tile_store<real, IOMODE, false, false>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
         } else if constexpr (MODE == MODE_R2C_H && (FLAGS & 128) != 0) {
-          reinterpret_cast<cx<real> *>(out)[uneven_offset(d, row_ub, tl + q * NT)] = {v[q].x * sx_out, v[q].y * sy_out};
+          reinterpret_cast<cx<real> *>(out)[uneven_offset(d, row_ub, o, i, tl + q * NT)] = {v[q].x * sx_out, v[q].y * sy_out};
         } else {
           tile_store<real, IOMODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
         }
@@ -1020,7 +1042,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
       }
       if constexpr (MODE == MODE_R2C_H && (FLAGS & 128) != 0) {
         if (tl == 0)
-          reinterpret_cast<cx<real> *>(out)[uneven_offset(d, row_ub, N)] = {(z0.x - z0.y) * 2 * sx_out, 0};
+          reinterpret_cast<cx<real> *>(out)[uneven_offset(d, row_ub, o, i, N)] = {(z0.x - z0.y) * 2 * sx_out, 0};
       } else if constexpr (MODE == MODE_R2C_H && !(FLAGS & 16)) {
         // X[N] from thread 0, followed by d.out_pad zeros from its neighbours: one coalesced store
         // that completes the row's last 128-byte line when the output rows are pitched
@@ -1048,6 +1070,9 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
     const int lg = d.in_lgp > d.out_lgp ? d.in_lgp : d.out_lgp;
     if (((R >> lg) << lg) != R || MODE != MODE_C2C || BIGTW || (FLAGS & 16)) return hipErrorInvalidValue;
   }
+  // tile-major lines (ROWS): thread slots advance by NT entries = whole tiles
+  if (!COLS && ((d.in_tlg && (NT & ((1 << d.in_tlg) - 1))) || (d.out_tlg && (NT & ((1 << d.out_tlg) - 1)))))
+    return hipErrorInvalidValue;
   auto kern = fft_pow2_kernel<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE, BIGTW, RADS...>;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {

@@ -65,6 +65,28 @@ struct PassDesc {
   // an all-to-all send / receive buffer); 0 / 0 = natural layout
   int in_lgp, out_lgp;
   int64_t in_jump, out_jump;
+  // tile-major transform axis (ROWS mapping; exchange buffers laid out for the strided pass of the
+  // NEXT stage, whose tile of 2^tlg adjacent columns then is one contiguous run): entry e of a line sits
+  // (e >> tlg) * tS + (e & (2^tlg - 1)) elements from the line's base instead of e * es; 0 = off.
+  // Thread slots e = t + q NT advance by NT, a multiple of the tile width, so the step stays uniform.
+  int in_tlg, out_tlg;
+  int64_t in_tS, out_tS;
+  // tile-major COLUMNS (COLS mapping: the strided pass that reads / writes such a buffer): adjacent
+  // column i of a row of the batch sits (i >> ilg) * iS + (i & (2^ilg - 1)) elements from the row's base
+  // instead of i * is; 0 = off.  One shift-and-mask per lane and tile, nothing per element.
+  int in_ilg, out_ilg;
+  int64_t in_iS, out_iS;
+  // flat tiles (see `flat`) over rows stored as a BODY of fl_bw columns plus the remaining columns as
+  // a narrow array of their own (odd-width half spectra in exchange buffers: 513 = 512 + 1): on the
+  // INPUT side column i >= fl_bw of row m is read from fl_tail + m * fl_tail_ms + (i - fl_bw).  0 = off.
+  int64_t fl_bw, fl_tail, fl_tail_ms;
+  // Uneven blocks stored slab by slab (ub_n1 > 0; gfft_plan_set_split_slabs): the rows of the batch are
+  // (slab o, row i) with ub_n1 rows per slab; block b of a slab is its w_b entries as a tile-major body
+  // -- [tile][row][2^ub_tlg], (w_b >> ub_tlg) tiles -- followed by the leftover columns [row][w_b mod
+  // 2^ub_tlg]; the slabs of one block lie back to back from element ub_base[b].
+  int ub_tlg;
+  int64_t ub_n1;
+  int64_t ub_base[8];
   // MODE_R2R in the register kernels (DCT / DST kinds as one complex transform of the logical
   // length n = 2 r2r_n, see plan.cpp plan_r2r_line): the load reads REAL entry j = e - r2r_pos0
   // (zero outside [0, r2r_n)) times r2r_pre[j]; the store writes the REAL value

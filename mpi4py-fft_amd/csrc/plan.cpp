@@ -73,6 +73,7 @@ struct Options {
   int debug_flat = 0;        // gfft_debug_pass: tiles over the flattened (mid, inner) index
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
+  int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
   int64_t fused3_min_bytes = 32 << 20;
   Options() {
     if (const char *s = getenv("GFFT_GRID_CAP")) grid_cap = atoi(s);
@@ -189,6 +190,10 @@ struct Pass {
   bool has_full = false;
   PassDesc full{};
   int64_t data_inner = 0;            // columns of d.inner that carry data (0 = all): byte accounting
+  // guru plans: blocks of the transformed axis per side and the distance between their starts
+  // (gfft_plan_set_tiles re-derives the block jumps from them)
+  int blocks[2] = {1, 1};
+  int64_t bstride[2] = {0, 0};
 };
 
 bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
@@ -1105,6 +1110,9 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "real_half")) opts().real_half = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
+  else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
+  else if (!strcmp(key, "debug_tile_side")) opts().debug_tile_side = value;
+  else if (!strcmp(key, "debug_tile_stride")) opts().debug_tile_stride = value;
   else if (!strcmp(key, "ws_skew_kib")) opts().ws_skew_kib = value < 0 ? 0 : value;
   else if (!strcmp(key, "profile")) opts().profile = value;
   else if (!strcmp(key, "xcd_swizzle")) opts().xcd_swizzle = value;
@@ -1548,6 +1556,8 @@ int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_i
   auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
   if (in_blocks > 1) { d.in_lgp = lg2(in_blocks); d.in_jump = in_block_stride - (n / in_blocks) * dim->is; }
   if (out_blocks > 1) { d.out_lgp = lg2(out_blocks); d.out_jump = out_block_stride - (n / out_blocks) * dim->os; }
+  p.blocks[0] = in_blocks;   p.bstride[0] = in_block_stride;
+  p.blocks[1] = out_blocks;  p.bstride[1] = out_block_stride;
   rc = get_twiddles(n, precision, &d.tw);
   if (rc) { delete pl; return rc; }
   pl->passes.push_back(p);
@@ -1555,6 +1565,95 @@ int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_i
   pl->bytes = batch * (double)n * 4.0 * precision;
   *plan = pl;
   ++g_live_plans;
+  return GFFT_OK;
+}
+
+
+/* threads per line (NT = n / R) of the power-of-two ROW kernels, as the tables in fft_pow2_f64.hip /
+ * fft_pow2_f32.hip instantiate them (default variants); launch_pow2_one re-checks at launch */
+static int pow2_rows_nt(int64_t n, int precision) {
+  if (!is_pow2(n) || n < 16 || n > 4096) return 0;
+  if (n <= 32) return 4;
+  if (n == 64) return 8;
+  if (n == 128) return 16;
+  if (n == 256) return precision == 8 ? 32 : 16;
+  if (n <= 1024) return 64;
+  return (int)(n / 16);
+}
+
+/* Tile-major layouts of exchange buffers (see include/gfft.h). */
+int gfft_plan_set_tiles(gfft_plan pl, int side, int tile, int64_t tile_stride) {
+  if (!pl) return fail(GFFT_ERR_INVALID, "null plan");
+  if (side != 0 && side != 1) return fail(GFFT_ERR_INVALID, "side must be 0 (input) or 1 (output)");
+  if (pl->passes.size() != 1 || pl->fused3) return fail(GFFT_ERR_UNSUPPORTED, "tile-major layouts: single-pass plans only");
+  Pass &p = pl->passes[0];
+  if (p.kind != PK_FFT || !p.regk || p.d.mode != MODE_C2C || p.d.tw_hi || p.d.tr_dir)
+    return fail(GFFT_ERR_UNSUPPORTED, "tile-major layouts: plain complex register-kernel passes only");
+  int lg = 0;
+  while ((1 << lg) < tile) ++lg;
+  if (tile < 0 || (tile > 0 && ((1 << lg) != tile || tile < 2 || tile_stride < tile)))
+    return fail(GFFT_ERR_INVALID, "tile must be a power of two >= 2 (0 switches the layout off)");
+  PassDesc &d = p.d;
+  if (p.cols) {
+    // the adjacent columns (innermost batch dim) are tile-major
+    if (side == 0) { d.in_ilg = tile ? lg : 0; d.in_iS = tile ? tile_stride : 0; }
+    else { d.out_ilg = tile ? lg : 0; d.out_iS = tile ? tile_stride : 0; }
+    return GFFT_OK;
+  }
+  // ROWS: the transformed axis itself is tile-major; thread slots advance by NT entries, which must be
+  // whole tiles, and blocks must be whole tiles too
+  const int64_t n = d.n;
+  const int nb = p.blocks[side];
+  if (tile) {
+    const int nt = pow2_rows_nt(n, pl->precision);
+    if (!nt || nt % tile || (n / nb) % tile)
+      return fail(GFFT_ERR_UNSUPPORTED, "tile-major rows: the line's thread layout does not advance by whole tiles");
+  }
+  const int64_t es = 1;
+  const int64_t per = n / nb;
+  const int64_t span = tile ? (per / tile) * tile_stride : per * es;     // what one block advances the address by
+  const int64_t jump = nb > 1 ? p.bstride[side] - span : 0;
+  if (side == 0) { d.in_tlg = tile ? lg : 0; d.in_tS = tile ? tile_stride : 0; d.in_jump = jump; }
+  else { d.out_tlg = tile ? lg : 0; d.out_tS = tile ? tile_stride : 0; d.out_jump = jump; }
+  return GFFT_OK;
+}
+
+int gfft_plan_set_flat(gfft_plan pl, int64_t body_width, int64_t tail_offset, int64_t tail_row_stride) {
+  if (!pl) return fail(GFFT_ERR_INVALID, "null plan");
+  if (pl->passes.size() != 1 || pl->fused3) return fail(GFFT_ERR_UNSUPPORTED, "flat tiles: single-pass plans only");
+  Pass &p = pl->passes[0];
+  if (p.kind != PK_FFT || !p.regk || !p.cols || p.d.mode != MODE_C2C || p.d.tw_hi || p.d.tr_dir)
+    return fail(GFFT_ERR_UNSUPPORTED, "flat tiles: plain complex strided register-kernel passes only");
+  if (body_width < 0 || body_width > p.d.inner) return fail(GFFT_ERR_INVALID, "body width must lie in 0 .. columns per row");
+  p.d.flat = 1;
+  p.d.fl_bw = (body_width > 0 && body_width < p.d.inner) ? body_width : 0;
+  p.d.fl_tail = tail_offset;
+  p.d.fl_tail_ms = tail_row_stride;
+  return GFFT_OK;
+}
+
+int gfft_plan_set_split_slabs(gfft_plan pl, int side, int nblocks, int64_t rows_per_slab, int tile) {
+  if (!pl) return fail(GFFT_ERR_INVALID, "null plan");
+  if (pl->passes.size() != 1 || pl->axes.size() != 1 || pl->fused3)
+    return fail(GFFT_ERR_UNSUPPORTED, "split layouts fuse into single-pass plans only");
+  Pass &p = pl->passes[0];
+  if (!((p.d.mode == MODE_R2C_H && side == 1) || (p.d.mode == MODE_C2R_H && side == 0)))
+    return fail(GFFT_ERR_UNSUPPORTED, "slab-wise split: the half-spectrum side of packed-real rows only");
+  if (p.d.tr_dir || p.d.mid != 1 || p.d.inner != 1) return fail(GFFT_ERR_UNSUPPORTED, "slab-wise split: plain packed-real rows only");
+  int lg = 0;
+  while ((1 << lg) < tile) ++lg;
+  if (tile < 2 || (1 << lg) != tile) return fail(GFFT_ERR_INVALID, "tile must be a power of two >= 2");
+  if (rows_per_slab < 1 || p.d.batch % rows_per_slab) return fail(GFFT_ERR_INVALID, "rows per slab must divide the number of rows");
+  int rc = gfft_plan_set_split(pl, side, nblocks);
+  if (rc || nblocks == 1) return rc;
+  PassDesc &d = p.d;
+  // rows of the batch as (slab, row in slab): the kernel's (o, i) indices
+  d.inner = rows_per_slab;
+  d.in_is = d.in_os;   d.in_os *= rows_per_slab;
+  d.out_is = d.out_os; d.out_os *= rows_per_slab;
+  d.ub_n1 = rows_per_slab;
+  d.ub_tlg = lg;
+  for (int b = 0; b < 8; ++b) d.ub_base[b] = b < nblocks ? d.ub_rows * (int64_t)d.ub_start[b] : 0;
   return GFFT_OK;
 }
 
@@ -1755,6 +1854,8 @@ int gfft_debug_pass(const int64_t *geom, int precision, int cols, int variant, i
   d.scale = 1.0;
   d.flat = opts().debug_flat;
   d.swizzle = opts().xcd_swizzle > 0 ? 1 : 0;
+  if (!cols && (opts().debug_tile_side & 1)) { d.in_tlg = opts().debug_tile_lg; d.in_tS = opts().debug_tile_stride; }
+  if (!cols && (opts().debug_tile_side & 2)) { d.out_tlg = opts().debug_tile_lg; d.out_tS = opts().debug_tile_stride; }
   rc = get_twiddles(d.n, precision, &d.tw);
   if (rc) return rc;
   hipError_t e = precision == 8 ? launch_pow2_f64(d, cols != 0, variant, d_in, d_out, (hipStream_t)stream)

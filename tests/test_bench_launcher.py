@@ -27,16 +27,11 @@ def _run(script, nranks, size, extra_env=None, extra_args=()):
 
 
 def _launch(cmd, env, timeout):
-    """Up to three attempts: the launcher picks a free rendezvous port and releases it before torchrun
-    binds it, which another process on a busy test box can win; and a rank that leaves through the
-    deadline (os._exit) while its peer is still inside a gloo call has been seen to take the peer
-    down with a connection error about once in thirty runs.  A run counts when it exits 0 AND rank 0
-    printed its one line."""
-    for attempt in range(3):
-        res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
-        if res.returncode == 0 and sum(l.startswith('{') for l in res.stdout.splitlines()) == 1:
-            break
-    return res
+    """ONE attempt (round 2 allowed three: the launcher used to pick a port, release it and let
+    torchrun re-bind it, and ranks left through the deadline each on their own; now the rendezvous
+    is torchrun's stand-alone one and every rank leaves through bench.Guard, rank 0 last --
+    profiles/r03_launcher_loop.txt has the 30-in-a-row log)."""
+    return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
 
 
 def _check_line(out, nranks, size):
@@ -84,6 +79,40 @@ def test_bench_keeps_the_headline_when_an_extra_hangs():
     assert len(out_lines) == 1
     out = json.loads(out_lines[0])
     assert out['value'] > 0 and 'deadline' in out['extras_error']
+
+
+def test_bench_prints_a_diagnostic_line_when_the_headline_fails_on_one_rank():
+    """Rank 1 raises before the headline exists while rank 0 is inside the first collective: rank 0
+    still prints ONE line -- no value, the error, the wire's diagnostics -- and the job exits 0."""
+    env = dict(os.environ, GFFT_DIST_BACKEND='gloo', OMP_NUM_THREADS='1', GFFT_BENCH_TEST_FAIL='headline:1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'tests', 'bench_host_runner.py'), '--gpus', '2', '--size', '16',
+           '--no-cpu', '--steps', '1', '--warmup', '0']
+    res = _launch(cmd, env, 300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['value'] is None and out['n_gpus'] == 2 and out['metric'] == 'pfft_3d_c2c_16cubed_fp64_gflops'
+    assert 'rank 1' in out['error'] and 'injected failure' in out['error']
+    d = out['diagnostics']
+    assert 'env' in d and d['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') == '0' and 'torch' in d
+
+
+def test_bench_headline_deadline_prints_a_line():
+    """Initialisation / headline that never finishes (a hung RCCL bootstrap): the line still comes."""
+    env = dict(os.environ, GFFT_DIST_BACKEND='gloo', OMP_NUM_THREADS='1', GFFT_BENCH_TEST_HANG='headline')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'tests', 'bench_host_runner.py'), '--gpus', '2', '--size', '16',
+           '--no-cpu', '--steps', '1', '--warmup', '0', '--headline-deadline', '15']
+    res = _launch(cmd, env, 300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['value'] is None and 'deadline of 15 s' in out['error'] and "'headline'" in out['error']
 
 
 @pytest.mark.gpu
