@@ -700,8 +700,8 @@ def run(args, guard, state):
         # loses the ones after it)
         variants = [] if args.no_tune else [('measured routes', dict(wire='torch')),
                                            ('pipelined on torch.distributed', dict(wire='overlap', exchange='direct')),
-                                           ('pipelined', dict(wire='auto', exchange='direct')),
-                                           ('pipelined routed', dict(wire='auto', exchange='relay'))]
+                                           ('pipelined', dict(wire='native', exchange='direct')),
+                                           ('pipelined routed', dict(wire='native', exchange='relay'))]
         for label, kw in variants:
             phase(label)
             try:

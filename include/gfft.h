@@ -152,9 +152,13 @@ int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_i
  *   planned strides plus its remaining columns at tail_offset + row * tail_row_stride (elements from
  *   the outermost batch index's base) -- the layout a neighbouring stage writes with two plans.
  * gfft_plan_set_split_slabs: gfft_plan_set_split for the half-spectrum side of packed-real rows, the
- *   rows taken as slabs of `rows_per_slab`: block b of slab s is stored as a tile-major body
- *   [tile][row][`tile` entries] followed by its leftover entries [row][w_b mod tile]; a block's slabs
- *   lie back to back, the blocks one after the other (same message sizes as gfft_plan_set_split). */
+ *   rows taken as slabs of `rows_per_slab`: block b of slab s is stored as its rows cut to the body
+ *   columns (w_b rounded down to whole `tile` entries; `tile` = 256 bytes of complex values), [row][body],
+ *   followed by the leftover columns [row][w_b mod tile]; a block's slabs lie back to back, the blocks
+ *   one after the other (same message sizes as gfft_plan_set_split).  Rows of the 513-wide block of a
+ *   2048-point real axis are then 512 entries = whole 128-byte lines, for this plan's stores and for
+ *   the strided plan that reads them.  (Tile-major bodies -- what complex row plans write for free --
+ *   cost the packed-real kernels 18-25 % in per-entry address arithmetic, profiles/r03_stage_probe*.txt.) */
 int gfft_plan_set_tiles(gfft_plan plan, int side, int tile, int64_t tile_stride);
 int gfft_plan_set_flat(gfft_plan plan, int64_t body_width, int64_t tail_offset, int64_t tail_row_stride);
 int gfft_plan_set_split_slabs(gfft_plan plan, int side, int nblocks, int64_t rows_per_slab, int tile);

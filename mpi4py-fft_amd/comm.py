@@ -120,18 +120,36 @@ class NativeWire:
 
     @classmethod
     def create(cls, comm):
+        """COLLECTIVE over `comm`, and failure-safe as a collective: every rank first probes whether
+        libgfft can bind an RCCL library and the flags are gathered, so either all ranks go on to the
+        id exchange or all raise together; the id travels as (status, id) -- a rank 0 that cannot
+        produce one still takes part in the broadcast and everybody raises."""
         import ctypes
         from . import _lib
         key = comm.wire_key()
         w = cls._world.get(key)
         if w is None:
             L = _lib.lib()
+            info = ctypes.create_string_buffer(512)
+            mine = L.gfft_rccl_info(info, 512)
+            detail = '' if mine == 0 else (L.gfft_exchange_last_error() or b'').decode(errors='replace')
+            flags = comm.allgather_obj((int(mine), detail))
+            bad = [(r, d) for r, (rc, d) in enumerate(flags) if rc != 0]
+            if bad:
+                raise _lib.GfftError('libgfft cannot bind RCCL on rank(s) %s: %s' % ([r for r, _ in bad], bad[0][1]))
             buf = ctypes.create_string_buffer(128)
-            if comm.Get_rank() == 0:
-                _lib.check_wire(L.gfft_comm_get_unique_id(buf))
-            ident = comm.bcast(buf.raw, root=0)
+            rc = L.gfft_comm_get_unique_id(buf) if comm.Get_rank() == 0 else 0
+            rc, ident = comm.bcast((int(rc), buf.raw), root=0)
+            if rc != 0:
+                raise _lib.GfftError('gfft_comm_get_unique_id failed on rank 0 (status %d)' % rc)
             h = ctypes.c_void_p()
-            _lib.check_wire(L.gfft_comm_create(ctypes.byref(h), ctypes.c_char_p(ident), comm.Get_size(), comm.Get_rank()))
+            mine = L.gfft_comm_create(ctypes.byref(h), ctypes.c_char_p(ident), comm.Get_size(), comm.Get_rank())
+            # (a rank whose ncclCommInitRank fails has left the others inside theirs: RCCL's own
+            # bootstrap timeout ends that; what can be agreed on afterwards is that nobody uses the wire)
+            oks = comm.allgather_obj(int(mine))
+            if any(oks):
+                _lib.check_wire(mine)
+                raise _lib.GfftError('gfft_comm_create failed on rank(s) %s' % [r for r, v in enumerate(oks) if v])
             w = cls._world[key] = cls(h, comm.Get_rank(), comm.Get_size(), key)
         return w
 
@@ -393,6 +411,156 @@ class _CartView(Comm):
 
     def barrier(self):
         self._parent.barrier()
+
+
+class MpiComm(Comm):
+    """An mpi4py intra-communicator as the reference's callers pass it (mpifft.py:202-204,
+    pencil.py:64-93: ``PFFT(MPI.COMM_WORLD, ...)``).  MPI carries what it carries in the reference --
+    rank / size queries, the Cartesian topology (``Create_cart`` / ``Sub``), small objects
+    (``bcast`` / ``allgather``) -- and the device buffers of the global redistributions travel on
+    libgfft's own RCCL communicators (C ABI gfft_comm_* / gfft_alltoallv / gfft_sendrecv), whose
+    128-byte unique id is broadcast over MPI: nothing here needs torch.distributed.
+
+    Duck-typed: anything with ``Get_rank, Get_size, bcast, Barrier, Create_cart, Sub`` (and
+    ``allgather`` or ``gather``) qualifies, so the thread-rank MPI emulation of oracle/make_golden.py
+    stands in for mpi4py where it is not installed (tests/test_gpu_mpicomm.py)."""
+    backend = 'nccl'                 # what the wire is: RCCL (pencil.Transfer / relay.py ask)
+
+    def __init__(self, mpi, parent=None, members=None):
+        self._mpi = mpi
+        self._size, self._rank = int(mpi.Get_size()), int(mpi.Get_rank())
+        # ranks of the ROOT communicator (the one the user passed), in this communicator's rank order
+        self._root = parent._root if parent is not None else self
+        self._ranks = tuple(members) if members is not None else tuple(range(self._size))
+        self._wire = None
+        self.relay_parent = None
+        try:
+            if mpi.Get_topology() == getattr(_mpi_consts(mpi), 'CART', CART):
+                dims = None
+                if hasattr(mpi, 'Get_topo'):
+                    dims = tuple(mpi.Get_topo()[0])
+                elif getattr(mpi, '_topo', None) is not None:
+                    dims = tuple(mpi._topo[0])
+                if dims is not None:
+                    self._topo = (dims, tuple(int(c) for c in np.unravel_index(self._rank, dims)))
+        except Exception:
+            pass
+
+    def Get_size(self):
+        return self._size
+
+    def Get_rank(self):
+        return self._rank
+
+    def Is_inter(self):
+        return bool(self._mpi.Is_inter())
+
+    def Free(self):
+        pass                              # the user's communicator is the user's; sub-communicators go with it
+
+    def wire_key(self):
+        return ('mpi', id(self._root._mpi), self._ranks, self._root._rank)
+
+    def __eq__(self, other):
+        if isinstance(other, MpiComm):
+            return self._root is other._root and self._ranks == other._ranks
+        return isinstance(other, Comm) and self._size == 1 and other.Get_size() == 1
+
+    def __hash__(self):
+        return hash(self._ranks)
+
+    # -- small objects: MPI itself
+    def bcast(self, obj, root=0):
+        return self._mpi.bcast(obj, root=root)
+
+    def allgather_obj(self, obj):
+        if hasattr(self._mpi, 'allgather'):
+            return list(self._mpi.allgather(obj))
+        return self._mpi.bcast(self._mpi.gather(obj, root=0), root=0)
+
+    def allreduce_max(self, x):
+        return max(self.allgather_obj(x))
+
+    def barrier(self):
+        self._mpi.Barrier()
+
+    Barrier = barrier
+
+    # -- topology: MPI's, every sub-communicator with its RCCL twin
+    def Create_cart(self, dims, periods=None, reorder=False):
+        dims = tuple(int(d) for d in dims)
+        assert int(np.prod(dims)) == self._size, (dims, self._size)
+        # (reorder=False: the row-major rank order of SURVEY.md Appendix A; the RCCL ranks follow it)
+        cart = MpiComm(self._mpi.Create_cart(list(dims), periods=[False] * len(dims), reorder=False),
+                       parent=self, members=self._ranks)
+        cart._topo = (dims, tuple(int(c) for c in np.unravel_index(self._rank, dims)))
+        return cart
+
+    def Sub(self, remdims):
+        """MPI_Cart_sub plus the matching ncclCommSplit: COLLECTIVE over this Cartesian communicator,
+        like the MPI call itself (pencil.py:80-88 calls it once per axis on every rank)."""
+        remdims = [bool(r) for r in remdims]
+        dims, me = self._topo
+        sub_mpi = self._mpi.Sub(remdims)
+        members = tuple(self._ranks[int(np.ravel_multi_index(c, dims))]
+                        for c in np.ndindex(*dims) if all(remdims[i] or c[i] == me[i] for i in range(len(dims))))
+        color = int(np.ravel_multi_index([0 if remdims[i] else me[i] for i in range(len(dims))], dims))
+        key = int(np.ravel_multi_index([me[i] for i in range(len(dims)) if remdims[i]] or [0],
+                                       [dims[i] for i in range(len(dims)) if remdims[i]] or [1]))
+        wire = None
+        if self._size > 1:
+            local = tuple(self._ranks.index(r) for r in members)
+            wire = self._native().split(color, key, local)          # every rank of the grid, same order
+        if len(members) == 1:
+            return COMM_SELF
+        sub = MpiComm(sub_mpi, parent=self, members=members)
+        assert sub.Get_rank() == key, (sub.Get_rank(), key)
+        sub._wire = wire
+        sub.relay_parent = self
+        return sub
+
+    def _native(self):
+        if self._wire is None:
+            self._wire = NativeWire.create(self)
+        return self._wire
+
+    # -- device buffers: RCCL through the C ABI, on the caller's current stream
+    def alltoall(self, send, recv, send_counts, recv_counts):
+        if self._size == 1:
+            recv.copy_(send)
+            return
+        import ctypes
+        from . import _lib
+        i64 = lambda v: (ctypes.c_int64 * len(v))(*[int(x) for x in v])
+        sc, rc = [int(c) for c in send_counts], [int(c) for c in recv_counts]
+        sd = [sum(sc[:j]) for j in range(len(sc))]
+        rd = [sum(rc[:j]) for j in range(len(rc))]
+        _lib.check_wire(_lib.lib().gfft_alltoallv(self._native().handle, send.data_ptr(), i64(sc), i64(sd), recv.data_ptr(),
+                                                  i64(rc), i64(rd), send.element_size(), _lib.current_stream()))
+
+    def p2p(self, sends, recvs):
+        from . import _lib
+        st = _lib.current_stream()
+        self._native().sendrecv([(t.data_ptr(), t.numel() * t.element_size(), peer) for t, peer in sends],
+                                [(t.data_ptr(), t.numel() * t.element_size(), peer) for t, peer in recvs],
+                                st.value or 0)
+
+
+def _mpi_consts(mpi):
+    """The module that holds CART / UNDEFINED for this communicator object (mpi4py.MPI, or its stand-in)."""
+    import sys
+    mod = sys.modules.get(type(mpi).__module__)
+    return mod if mod is not None and hasattr(mod, 'CART') else sys.modules.get('mpi4py.MPI', None)
+
+
+def adapt(comm):
+    """What PFFT / Subcomm accept as `comm`: this module's communicators as they are, an mpi4py
+    (-like) intra-communicator wrapped in MpiComm."""
+    if isinstance(comm, Comm):
+        return comm
+    if all(hasattr(comm, a) for a in ('Get_rank', 'Get_size', 'bcast', 'Create_cart')):
+        return MpiComm(comm)
+    raise TypeError('not a communicator: %r' % (comm,))
 
 
 def init_distributed(backend=None):

@@ -722,11 +722,11 @@ __device__ __forceinline__ int64_t uneven_offset(const PassDesc &d, unsigned row
   }
   const int ee = e - start;
   if (d.ub_n1 > 0) {
-    // slab-wise blocks: tile-major body + leftover columns (PassDesc::ub_n1)
-    const int lg = d.ub_tlg, bw = (width >> lg) << lg;
-    const int64_t s0 = base + (int64_t)slab * (d.ub_n1 * width);
-    if (ee < bw) return s0 + (int64_t)(ee >> lg) * (d.ub_n1 << lg) + ((int64_t)srow << lg) + (ee & ((1 << lg) - 1));
-    return s0 + d.ub_n1 * bw + (int64_t)srow * (width - bw) + (ee - bw);
+    // slab-wise blocks: rows of the body columns, then rows of the leftover columns (PassDesc::ub_n1);
+    // 32-bit arithmetic (gfft_plan_set_split_slabs checks the buffer's size)
+    const int lg = d.ub_tlg, bw = (width >> lg) << lg, n1 = (int)d.ub_n1;
+    const int s0 = (int)base + (int)slab * (n1 * width);
+    return ee < bw ? s0 + (int)srow * bw + ee : s0 + n1 * bw + (int)srow * (width - bw) + (ee - bw);
   }
   return d.ub_rows * (int64_t)start + (int64_t)row * width + ee;
 }

@@ -81,9 +81,10 @@ struct PassDesc {
   // INPUT side column i >= fl_bw of row m is read from fl_tail + m * fl_tail_ms + (i - fl_bw).  0 = off.
   int64_t fl_bw, fl_tail, fl_tail_ms;
   // Uneven blocks stored slab by slab (ub_n1 > 0; gfft_plan_set_split_slabs): the rows of the batch are
-  // (slab o, row i) with ub_n1 rows per slab; block b of a slab is its w_b entries as a tile-major body
-  // -- [tile][row][2^ub_tlg], (w_b >> ub_tlg) tiles -- followed by the leftover columns [row][w_b mod
-  // 2^ub_tlg]; the slabs of one block lie back to back from element ub_base[b].
+  // (slab o, row i) with ub_n1 rows per slab; block b of a slab is its rows cut to the BODY columns
+  // -- w_b rounded down to whole 2^ub_tlg entries, so that every row is whole 128-byte lines -- [row][body],
+  // followed by the leftover columns [row][w_b - body]; the slabs of one block lie back to back from
+  // element ub_base[b].
   int ub_tlg;
   int64_t ub_n1;
   int64_t ub_base[8];

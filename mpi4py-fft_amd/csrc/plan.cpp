@@ -1644,6 +1644,8 @@ int gfft_plan_set_split_slabs(gfft_plan pl, int side, int nblocks, int64_t rows_
   while ((1 << lg) < tile) ++lg;
   if (tile < 2 || (1 << lg) != tile) return fail(GFFT_ERR_INVALID, "tile must be a power of two >= 2");
   if (rows_per_slab < 1 || p.d.batch % rows_per_slab) return fail(GFFT_ERR_INVALID, "rows per slab must divide the number of rows");
+  // (the kernels address this layout with 32-bit element offsets)
+  if ((double)p.d.batch * ((double)p.d.n + 1.0) >= 2147483648.0) return fail(GFFT_ERR_UNSUPPORTED, "slab-wise split: buffer beyond 2^31 entries");
   int rc = gfft_plan_set_split(pl, side, nblocks);
   if (rc || nblocks == 1) return rc;
   PassDesc &d = p.d;

@@ -80,6 +80,36 @@ class FileBase(object):
         self.f = None
         self.filename = filename
         self.domain = domain
+        self._pending_create = None
+
+    def _init_file(self, mode, comm, create):
+        """Creation / truncation is COLLECTIVE, as the reference's constructor is (its ranks open the
+        file together through MPI-IO, h5py_file.py:31-40 / nc_file.py:36-44): exactly one rank creates
+        or truncates, and nobody writes before it has.  Every rank doing it on its own -- round 2 --
+        let a rank that arrived late truncate what rank 0 had already written.
+          * `comm` given: rank 0 of it creates now, then a barrier;
+          * one process in the world: create now;
+          * otherwise the file is created at the first write(), by rank 0 of the written array's grid
+            at the head of the turn-taking loop (the constructor does not know the grid)."""
+        from . import comm as _comm
+        if mode == 'r':
+            return
+        want = (lambda: mode == 'w' or not os.path.exists(self.filename))
+        if comm is not None and comm.Get_size() > 1:
+            if comm.Get_rank() == 0 and want():
+                create()
+            comm.barrier()
+        elif comm is not None or _comm.world().Get_size() == 1:
+            if want():
+                create()
+        else:
+            self._pending_create = (mode, create)
+
+    def _create_if_pending(self, first):
+        """Head of a turn-taking loop: the first rank of the grid creates the file if that is still due."""
+        pc, self._pending_create = self._pending_create, None
+        if pc is not None and first and (pc[0] == 'w' or not os.path.exists(self.filename)):
+            pc[1]()
 
     # ---- container hooks ---------------------------------------------------------------------------
     @staticmethod
@@ -107,6 +137,7 @@ class FileBase(object):
         """Run body() on every rank of `comm`, one rank at a time in rank order, each inside its own
         open / close of the file (the reference's collective open under MPI-IO)."""
         if comm is None or comm.Get_size() == 1:
+            self._create_if_pending(True)
             self.open(mode)
             try:
                 return body()
@@ -115,6 +146,7 @@ class FileBase(object):
         out = None
         for r in range(comm.Get_size()):
             if r == comm.Get_rank():
+                self._create_if_pending(r == 0)
                 self.open(mode)
                 try:
                     out = body()
@@ -218,12 +250,11 @@ class FileBase(object):
 
 class HDF5File(FileBase):
     """HDF5 snapshots in the reference's layout (h5py_file.py:9-152).  ``mode``: r / w / a."""
-    def __init__(self, h5name, domain=None, mode='a', **kw):
+    def __init__(self, h5name, domain=None, mode='a', comm=None, **kw):
         FileBase.__init__(self, h5name, domain=domain)
         self._h5py = self._import()
         self._kw = kw
-        if mode == 'w' or (mode == 'a' and not os.path.exists(h5name)):
-            self._h5py.File(h5name, 'w', **kw).close()      # every rank may do this: same empty file
+        self._init_file(mode, comm, lambda: self._h5py.File(h5name, 'w', **kw).close())
 
     @staticmethod
     def _import():
@@ -323,7 +354,7 @@ class NCFile(FileBase):
     _AXES = 'xyzrst'
     _COMP = 'ijk'
 
-    def __init__(self, ncname, domain=None, mode='a', clobber=True, **kw):
+    def __init__(self, ncname, domain=None, mode='a', clobber=True, comm=None, **kw):
         FileBase.__init__(self, ncname, domain=domain)
         try:
             import netCDF4
@@ -331,8 +362,7 @@ class NCFile(FileBase):
         except ImportError:
             self._nc4 = None
         self.dims = None
-        if mode == 'w' or (mode == 'a' and not os.path.exists(ncname)):
-            self._create()
+        self._init_file(mode, comm, self._create)
 
     # NOTE on the scipy container: mode 'a' loads the file and rewrites it on close; fine for
     # snapshots of a few GB, use netCDF4 / HDF5File beyond that.

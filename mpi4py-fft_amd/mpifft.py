@@ -178,11 +178,10 @@ class PFFT:
         sub-communicator), 'relay' (two rounds over all xGMI links of the grid, relay.py) or
         'auto' (time both at the first call and keep the faster).  Default: the GFFT_RELAY
         environment switch, else 'auto'.
-    wire : 'native' = chunked redistributions overlapped with the serial transforms on libgfft's
-        own RCCL communicators (pipeline.py); 'overlap' = the same pipeline on asynchronous
-        torch.distributed all-to-alls; 'torch' = the staged path on torch.distributed's collectives.
-        Default: GFFT_WIRE, else 'auto' (native when the grid runs on RCCL, 'overlap' if libgfft
-        cannot bind an RCCL library).
+    wire : 'overlap' = chunked redistributions overlapped with the serial transforms (pipeline.py)
+        on asynchronous torch.distributed all-to-alls; 'native' = the same pipeline on libgfft's own
+        RCCL communicators (opt-in); 'torch' = the staged path on torch.distributed's collectives.
+        Default: GFFT_WIRE, else 'auto' ('overlap' when the grid runs on RCCL).
     fuse : single-GPU transforms run as one all-axes plan (default True)
     fuse_pack : serial transforms write / read the exchange buffers directly (default True)
     """
@@ -258,10 +257,12 @@ class PFFT:
             self.pencil[::-1], fused_bck, None if self.pipeline is None else (self.pipeline, False))
 
     def _plan_pipeline(self, wire, exchange=None):
-        """The chunked, stream-overlapped form of this transform on libgfft's own RCCL communicators
-        (pipeline.py), or None: `wire` = 'native' asks for it, 'torch' keeps the staged path on
-        torch.distributed's collectives, None reads GFFT_WIRE (default 'auto': native when the
-        grid's wire is RCCL).  Collective over the grid (communicator split)."""
+        """The chunked, stream-overlapped form of this transform (pipeline.py), or None.  `wire`:
+        'overlap' = on torch.distributed's asynchronous all-to-alls, 'native' = on libgfft's own RCCL
+        communicators (C ABI gfft_comm_* / gfft_sendrecv), 'torch' = none (the staged path).  None
+        reads GFFT_WIRE, default 'auto' = 'overlap' on an RCCL grid: the native wire has only ever met
+        a stand-in RCCL and a world of one, so it stays opt-in until a real multi-GPU run has
+        validated it.  Collective over the grid."""
         mode = (os.environ.get('GFFT_WIRE', 'auto') if wire is None else str(wire)).lower()
         if mode in ('torch', 'staged', '0', 'off'):
             return None
@@ -271,25 +272,38 @@ class PFFT:
             return None
         from . import pipeline
 
-        def agreed(pipe):
-            # all ranks of the grid run the pipelined form or none does (a rank whose local shape
-            # makes one of its stage plans impossible must not leave the others waiting for it)
-            if all(parent.allgather_obj(pipe is not None)):
-                pipe.plan_relays()
-                return pipe
-            if pipe is not None:
+        def agreed(build):
+            # Every rank of the grid runs the pipelined form, on the same buffer layouts and chunk
+            # counts, or none does: a rank whose local shape makes one of its stage plans impossible
+            # must not leave the others waiting, and layouts decide message sizes.
+            pipe = build(None)
+            sigs = parent.allgather_obj(None if pipe is None else pipe.signature())
+            if any(s is None for s in sigs):
+                if pipe is not None:
+                    pipe.destroy()
+                return None
+            if len(set(sigs)) > 1:
+                # disagreement (a rank could not take the aligned layout): everybody back to C order
                 pipe.destroy()
-            return None
-        if mode == 'overlap':
-            # the chunked pipeline on torch.distributed's own collectives (asynchronous all_to_all)
-            return agreed(pipeline.Pipeline.build(self, _comm.torch_wires(self.subcomm), 'direct'))
-        try:
-            wires = _comm.native_wires(self.subcomm)
-        except Exception:
-            if mode == 'native':
-                raise
-            return agreed(pipeline.Pipeline.build(self, _comm.torch_wires(self.subcomm), 'direct'))
-        return agreed(pipeline.Pipeline.build(self, wires, exchange))
+                pipe = build('c-order')
+                sigs = parent.allgather_obj(None if pipe is None else pipe.signature())
+                if any(s is None for s in sigs) or len(set(sigs)) > 1:
+                    if pipe is not None:
+                        pipe.destroy()
+                    return None
+            pipe.plan_relays()
+            return pipe
+        if mode == 'native':
+            wires, err = None, None
+            try:
+                wires = _comm.native_wires(self.subcomm)
+            except Exception as e:          # (native_wires itself fails on every rank or on none)
+                err = e
+            if wires is None:
+                raise err
+            return agreed(lambda lay: pipeline.Pipeline.build(self, wires, exchange, lay))
+        # 'overlap' / 'auto': the chunked pipeline on torch.distributed's own collectives
+        return agreed(lambda lay: pipeline.Pipeline.build(self, _comm.torch_wires(self.subcomm), 'direct', lay))
 
     # ---- planning steps (what mpifft.py:202-347 decides, one decision per helper) ---------------
     @staticmethod

@@ -37,6 +37,7 @@ class Subcomm(tuple):
            ``Compute_dims``; e.g. ``[0, 0, 1]`` distributes the first two axes.
     """
     def __new__(cls, comm, dims=None, reorder=True):
+        comm = _comm.adapt(comm)           # an mpi4py communicator, as the reference's callers pass
         assert not comm.Is_inter()
         if comm.Get_topology() == _comm.CART:
             assert comm.Get_dim() > 0

@@ -137,6 +137,9 @@ class _Stage:
         else:
             self.step_in = self.step_out = 0
 
+    def execute(self, eng, c, pin, pout, scale):
+        eng.execute_ptr(self.plan, pin + c * self.step_in, pout + c * self.step_out, scale)
+
     def destroy(self):
         if self.plan is not None:
             _lib.engine().plan_destroy(self.plan)
@@ -151,6 +154,9 @@ class _WholeStage:
         self.nchunks, self.iter_side, self.step_in, self.step_out = 1, None, 0, 0
         self.lay_in = self.lay_out = type('Side', (), dict(K=1, p=1))()
 
+    def execute(self, eng, c, pin, pout, scale):
+        eng.execute_ptr(self.plan, pin, pout, scale)
+
     def destroy(self):
         self.plan = None           # owned by the PFFT's stage object
 
@@ -161,18 +167,21 @@ class _RealRows:
     chunk-major exchange buffer of UNEVEN blocks that gfft_plan_set_split addresses (n/2 + 1
     entries dealt to p ranks by the block rule).  `forward`: real natural -> buffer, else buffer ->
     real natural."""
-    def __init__(self, shape, p, K, forward, precision):
+    def __init__(self, shape, p, K, forward, precision, tile=0):
         n0, n1, n = (int(v) for v in shape)
         nh = n // 2 + 1
         rows = (n0 // K) * n1
         eng = _lib.engine()
         self.plan = None
+        # tile > 0: the blocks slab by slab, tile-major (gfft_plan_set_split_slabs; _Aligned below)
+        split = (lambda h, side: eng.plan_set_split_slabs(h, side, p, n1, tile)) if tile else \
+            (lambda h, side: eng.plan_set_split(h, side, p))
         if forward:
             h = eng.plan_create((rows, n), (rows, nh), (1,), _lib.R2C, precision)
-            ok = eng.plan_set_split(h, 1, p)
+            ok = split(h, 1)
         else:
             h = eng.plan_create((rows, nh), (rows, n), (1,), _lib.C2R, precision)
-            ok = eng.plan_set_split(h, 0, p)
+            ok = split(h, 0)
         if not ok:
             eng.plan_destroy(h)
             return
@@ -186,10 +195,289 @@ class _RealRows:
         natural = type('Side', (), dict(K=1, p=1))()
         self.lay_in, self.lay_out = (natural, side) if forward else (side, natural)
 
+    def execute(self, eng, c, pin, pout, scale):
+        eng.execute_ptr(self.plan, pin + c * self.step_in, pout + c * self.step_out, scale)
+
     def destroy(self):
         if self.plan is not None:
             _lib.engine().plan_destroy(self.plan)
             self.plan = None
+
+
+def _pitch(elems, isz):
+    """Distance, in elements, between consecutive slabs of an exchange buffer that the receiving stage
+    walks ALONG the slabs (its transformed axis): whole 128-byte lines, and 256 bytes off any multiple
+    of 2 KiB -- strided passes over power-of-two pitches alias onto few HBM channels (what the
+    single-GPU schedule's workspace pitch is for, plan.cpp plan_fused3; C4 on 8 GPUs, stage 2:
+    1.00 -> 0.83 ms, tools/stage_layout_probe.py).  The padding travels: 256 bytes per slab."""
+    line = max(1, 128 // isz)
+    E = -(-int(elems) // line) * line
+    if (E * isz) % 2048 == 0:
+        E += 256 // isz
+    return E
+
+
+class _Steps:
+    """A stage as explicit launches: steps[c] = [(plan, input byte offset, output byte offset)] for
+    chunk c of the side the stage iterates over (its input side where that is chunked)."""
+    def __init__(self, iter_side, K_in, K_out, p_in, p_out):
+        self.iter_side = iter_side
+        self.steps, self._plans = [], []
+        self.lay_in = type('Side', (), dict(K=K_in, p=p_in))()
+        self.lay_out = type('Side', (), dict(K=K_out, p=p_out))()
+        self.plan = True                    # falsy once a launch could not be planned
+
+    @property
+    def nchunks(self):
+        return len(self.steps)
+
+    def own(self, h):
+        if h is None or h is False:
+            self.plan = None
+        else:
+            self._plans.append(h)
+        return h
+
+    def execute(self, eng, c, pin, pout, scale):
+        for h, oi, oo in self.steps[c]:
+            eng.execute_ptr(h, pin + oi, pout + oo, scale)
+
+    def destroy(self):
+        for h in self._plans:
+            _lib.engine().plan_destroy(h)
+        self._plans, self.steps, self.plan = [], [], None
+
+
+class _Aligned:
+    """Line-aligned exchange buffers for the standard chain (axis 2 rows -> T0 -> axis 1 -> T1 -> axis 0).
+
+    The arrays between the stages of a distributed transform are internal, so their layout is free
+    (caller-visible arrays keep the reference's C order, pencil.py:347-354).  Measured on the stage
+    shapes of configs C4 / C5 on 8 GPUs (tools/stage_layout_probe.py, rows_tile_probe.py):
+
+    T0 (rows stage -> strided stage): TILE-MAJOR slabs.  Per slab i0 of a (chunk, peer) message the w
+      columns of the receiver are [tile][row i1][256 bytes of columns] followed by the leftover columns
+      [row][w mod tile].  The strided stage's tile of adjacent columns is then one contiguous run
+      (c64 n = 2048: 2.02 -> 1.83 ms, c128 n = 1024: 0.87 -> 0.81 ms) and 513-wide half-spectrum blocks
+      cost nothing (512 + 1); the row stage stores 256-byte pieces (c128 0.792 -> 0.793 ms, c64 +3 ... 6 %).
+    T1 (strided stage -> strided stage along the slabs): per slab i0 the rows [i1][body columns]
+      followed by [i1][leftover columns], slabs _pitch() apart.  Body rows are whole 128-byte lines, so
+      the sender's stores are aligned whatever the width, and the far-axis stage no longer walks a
+      power-of-two stride.  Where rows have leftover columns the last forward stage runs flat tiles
+      over the caller's natural output (aligned stores) and gathers body / leftover per lane
+      (gfft_plan_set_flat).
+    Message sizes are those of the C-order buffers plus the slab padding of T1."""
+
+    def __init__(self, pipe, stages, plan, real0):
+        self.ok = False
+        eng = _lib.engine()
+        prec, isz = pipe.precision, pipe.isz
+        TW, LW = 256 // isz, 128 // isz
+        if len(stages) != 3 or [tuple(x.axes) for x in stages] != [(2,), (1,), (0,)]:
+            return
+        if not all(hasattr(eng, a) for a in ('plan_set_tiles', 'plan_set_flat')):
+            return
+        e0, e1 = plan
+        p0, p1 = e0['p'], e1['p']
+        K0, K1 = e0.get('K', 1), e1.get('K', 1)
+        sh0 = tuple(int(v) for v in stages[0].forward.input_array.shape)
+        sh1 = tuple(int(v) for v in stages[1].forward.input_array.shape)
+        sh2 = tuple(int(v) for v in stages[2].forward.input_array.shape)
+        N0, N1 = sh0[0], sh0[1]
+        M1, W = sh1[1], sh1[2]
+        M0, N1b = sh2[0], sh2[1]
+        NH = int(stages[0].forward.output_array.shape[2])          # spectral entries along axis 2 on this rank's row
+        if p0 > 1 and (M1 != p0 * N1 or N0 % K0):
+            return
+        if p1 > 1 and (M0 != p1 * N0 or M1 != p1 * N1b):
+            return
+        if p1 > 1 and K1 > 1 and (W % K1 or (W // K1) % TW):
+            return                                                 # chunks of T1 are whole tiles wide
+        N0c, Wq = N0 // K0, W // K1
+        self.p0, self.p1, self.K0, self.K1 = p0, p1, K0, K1
+        # ---- geometry of T0 as the strided stage sees it (elements)
+        bw0, tw0 = W - W % TW, W % TW
+        BS0 = N0c * N1 * W                      # one (chunk, peer) message
+        CS0 = p0 * BS0                          # one chunk region on the strided stage's side
+        # ---- geometry of T1
+        bw1, tw1 = Wq - Wq % TW, Wq % TW            # (the same split as T0's: a stage between the two sees one body)
+        E = _pitch(N1b * Wq, isz)
+        BS1 = N0 * E
+        CS1 = p1 * BS1
+        self.E = E
+        self.fwd, self.bwd = [None] * 3, [None] * 3
+        mk = lambda it, Ki, Ko, pi, po: _Steps(it, Ki, Ko, pi, po)
+
+        def guru(st, kind, n, sin, sout, dims, ncols):
+            """One strided launch: sides = dict(es, blocks, bstride, tile)."""
+            h = st.own(eng.plan_create_guru(prec, kind, (n, sin['es'], sout['es']), list(dims) + [(ncols, 1, 1)],
+                                            sin['blocks'], sin['bstride'], sout['blocks'], sout['bstride']))
+            for side, sd in ((0, sin), (1, sout)):
+                if h and sd.get('tile'):
+                    if not eng.plan_set_tiles(h, side, sd['tile'][0], sd['tile'][1]):
+                        st.plan = None
+            return h
+
+        # ------------------------------------------------------------------ stage 0 (rows, axis 2)
+        if p0 > 1:
+            f, b = mk('out', 1, K0, 1, p0), mk('in', K0, 1, p0, 1)
+            if real0:
+                n = int(sh0[2])
+                rf = _RealRows(sh0, p0, K0, True, prec, TW)
+                rb = _RealRows(sh0, p0, K0, False, prec, TW)
+                if rf.plan is None or rb.plan is None:
+                    rf.destroy()
+                    rb.destroy()
+                    return
+                f, b = rf, rb
+            else:
+                N2 = int(sh0[2])
+                w = N2 // p0
+                if N2 % p0 or w % TW:
+                    return
+                hf = f.own(eng.plan_create_guru(prec, -1, (N2, 1, 1), [(1, 0, 0), (N0c, N1 * N2, N1 * w), (N1, N2, TW)],
+                                                1, 0, p0, N0c * N1 * w))
+                hb = b.own(eng.plan_create_guru(prec, +1, (N2, 1, 1), [(1, 0, 0), (N0c, N1 * w, N1 * N2), (N1, TW, N2)],
+                                                p0, N0c * N1 * w, 1, 0))
+                if not (hf and hb and eng.plan_set_tiles(hf, 1, TW, N1 * TW) and eng.plan_set_tiles(hb, 0, TW, N1 * TW)):
+                    f.destroy()
+                    b.destroy()
+                    return
+                step = N0c * N1 * N2 * isz
+                f.steps = [[(hf, q * step, q * step)] for q in range(K0)]
+                b.steps = [[(hb, q * step, q * step)] for q in range(K0)]
+            self.fwd[0], self.bwd[0] = f, b
+        # (p0 == 1: the caller keeps the natural-layout stage it already has)
+
+        # ------------------------------------------------------------------ sides of the strided stages
+        def t0_side(body):          # stage 1's view of T0
+            if real0:               # rows of the body columns (gfft_plan_set_split_slabs), then the leftover ones
+                return dict(es=bw0 if body else tw0, blocks=p0, bstride=BS0, tile=None, off=0 if body else N1 * bw0, g=N1 * W)
+            return dict(es=TW if body else tw0, blocks=p0, bstride=BS0, tile=(TW, N1 * TW) if body else None,
+                        off=0 if body else N1 * bw0, g=N1 * W)
+
+        def t1_side1(body):         # stage 1's view of T1: axis 1 cut into p1 blocks, slabs i0 E apart
+            return dict(es=bw1 if body else tw1, blocks=p1, bstride=BS1, tile=None, off=0 if body else N1b * bw1, g=E)
+
+        def t1_side2(body):         # stage 2's view of T1: axis 0 = (peer, slab), rows i1 inside a slab
+            return dict(es=E, blocks=p1, bstride=BS1, tile=None, off=0 if body else N1b * bw1, g=bw1 if body else tw1)
+
+        def nat_side(shape, ax, g, col0):
+            st = _cstrides(shape)
+            return dict(es=st[ax], blocks=1, bstride=0, tile=None, off=col0, g=st[g])
+
+        # ------------------------------------------------------------------ stage 1 (axis 1)
+        s1f = s1b = None
+        if p0 > 1 or p1 > 1:
+            regions0 = [(True, bw0)] + ([(False, tw0)] if tw0 else [])          # columns of the whole width
+            regions1 = [(True, bw1)] + ([(False, tw1)] if tw1 else [])          # columns of one T1 chunk
+            if p0 > 1 and p1 > 1:
+                if K1 > 1 and tw1:
+                    return
+                s1f, s1b = mk('in', K0, K1, p0, p1), mk('in', K1, K0, p1, p0)
+                s1f.steps, s1b.steps = [[] for _ in range(K0)], [[] for _ in range(K1)]
+                # forward: one step per arriving T0 chunk; it fills its slabs in every T1 chunk
+                for body, nc in (regions0 if K1 == 1 else [(True, Wq)]):
+                    if not nc:
+                        continue
+                    a, c = t0_side(body), t1_side1(body)
+                    colq = ((Wq // TW) * N1 * TW if a['tile'] else Wq) if K1 > 1 else 0       # where T1's chunk q starts in a T0 row
+                    dims = [(N0c, a['g'], c['g']), (K1, colq, CS1 if K1 > 1 else 0)]
+                    hf = guru(s1f, -1, M1, a, c, dims, nc)
+                    # backward: one step per arriving T1 chunk; it fills its columns in every T0 chunk
+                    dims = [(K0, N0c * c['g'], CS0), (N0c, c['g'], a['g'])]
+                    hb = guru(s1b, +1, M1, c, a, dims, nc)
+                    for q in range(K0):
+                        s1f.steps[q].append((hf, (q * CS0 + a['off']) * isz, (q * N0c * c['g'] + c['off']) * isz))
+                    for q in range(K1):
+                        s1b.steps[q].append((hb, (q * CS1 + c['off']) * isz,
+                                             (a['off'] + q * colq) * isz))
+            elif p0 > 1:
+                # T1 is local: the stage writes / reads the natural array it shares with stage 2
+                s1f, s1b = mk('in', K0, 1, p0, 1), mk('out', 1, K0, 1, p0)
+                s1f.steps, s1b.steps = [[] for _ in range(K0)], [[] for _ in range(K0)]
+                col = 0
+                for body, nc in regions0:
+                    if nc:
+                        a, c = t0_side(body), nat_side(sh1, 1, 0, col)
+                        hf = guru(s1f, -1, M1, a, c, [(1, 0, 0), (N0c, a['g'], c['g'])], nc)
+                        hb = guru(s1b, +1, M1, c, a, [(1, 0, 0), (N0c, c['g'], a['g'])], nc)
+                        for q in range(K0):
+                            s1f.steps[q].append((hf, (q * CS0 + a['off']) * isz, (q * N0c * c['g'] + c['off']) * isz))
+                            s1b.steps[q].append((hb, (q * N0c * c['g'] + c['off']) * isz, (q * CS0 + a['off']) * isz))
+                    col += nc
+            else:
+                # T0 is local: natural input, one step per T1 chunk on the way out, per arriving chunk back
+                s1f, s1b = mk('out', 1, K1, 1, p1), mk('in', K1, 1, p1, 1)
+                for q in range(K1):
+                    s1f.steps.append([])
+                    s1b.steps.append([])
+                col = 0
+                for body, nc in regions1:
+                    if nc:
+                        hf = hb = None
+                        for q in range(K1):
+                            a, c = nat_side(sh1, 1, 0, q * Wq + col), t1_side1(body)
+                            if hf is None:
+                                hf = guru(s1f, -1, M1, a, c, [(1, 0, 0), (N0, a['g'], c['g'])], nc)
+                                hb = guru(s1b, +1, M1, c, a, [(1, 0, 0), (N0, c['g'], a['g'])], nc)
+                            s1f.steps[q].append((hf, a['off'] * isz, (q * CS1 + c['off']) * isz))
+                            s1b.steps[q].append((hb, (q * CS1 + c['off']) * isz, a['off'] * isz))
+                    col += nc
+            self.fwd[1], self.bwd[1] = s1f, s1b
+
+        # ------------------------------------------------------------------ stage 2 (axis 0)
+        if p1 > 1:
+            s2f, s2b = mk('in', K1, 1, p1, 1), mk('out', 1, K1, 1, p1)
+            for q in range(K1):
+                s2f.steps.append([])
+                s2b.steps.append([])
+            flat = tw1 > 0 and K1 == 1
+            if flat:
+                # forward: flat tiles over the natural output rows (aligned stores whatever the width),
+                # body / leftover columns gathered per lane on the input side
+                a, c = t1_side2(bw1 > 0), nat_side(sh2, 0, 1, 0)       # (no body at all: the leftover rows are the rows)
+                hf = s2f.own(eng.plan_create_guru(prec, -1, (M0, a['es'], c['es']), [(1, 0, 0), (N1b, a['g'], c['g']), (W, 1, 1)],
+                                                  p1, BS1, 1, 0))
+                if not (hf and eng.plan_set_flat(hf, bw1, N1b * bw1, tw1)):
+                    s2f.plan = None
+                s2f.steps[0].append((hf, 0, 0))
+            col = 0
+            for body, nc in [(True, bw1)] + ([(False, tw1)] if tw1 else []):
+                if nc:
+                    hf = hb = None
+                    for q in range(K1):
+                        a, c = t1_side2(body), nat_side(sh2, 0, 1, q * Wq + col)
+                        if hb is None:
+                            if not flat:
+                                hf = guru(s2f, -1, M0, a, c, [(1, 0, 0), (N1b, a['g'], c['g'])], nc)
+                            hb = guru(s2b, +1, M0, c, a, [(1, 0, 0), (N1b, c['g'], a['g'])], nc)
+                        if not flat:
+                            s2f.steps[q].append((hf, (q * CS1 + a['off']) * isz, c['off'] * isz))
+                        s2b.steps[q].append((hb, c['off'] * isz, (q * CS1 + a['off']) * isz))
+                col += nc
+            self.fwd[2], self.bwd[2] = s2f, s2b
+
+        made = [s for s in self.fwd + self.bwd if s is not None]
+        if any(s.plan is None for s in made):
+            for s in made:
+                s.destroy()
+            return
+        # ---- exchange descriptions (bytes): A = the earlier stage's side, B = the later stage's
+        if p0 > 1:
+            if e0.get('uneven'):
+                rows = N0c * N1
+                e0['A'] = dict(chunk=rows * sum(e0['widths']) * isz, sizes=[rows * w * isz for w in e0['widths']])
+            else:
+                e0['A'] = dict(chunk=N0c * N1 * NH * isz, sizes=[N0c * N1 * (NH // p0) * isz] * p0)
+            e0['B'] = dict(chunk=CS0 * isz, sizes=[BS0 * isz] * p0)
+        if p1 > 1:
+            e1['A'] = dict(chunk=CS1 * isz, sizes=[BS1 * isz] * p1)
+            e1['B'] = dict(chunk=CS1 * isz, sizes=[BS1 * isz] * p1)
+            # what a rank whose local width is `w` sends per peer (routed exchanges need every rank's sizes)
+            e1['block_bytes'] = lambda w, N0=N0, N1b=N1b, K1=K1: N0 * _pitch(N1b * (w // K1), isz) * isz
+            self.t1_elems = K1 * CS1
+        self.ok = True
 
 
 class Pipeline:
@@ -199,8 +487,10 @@ class Pipeline:
     MIN_WIDTH = 16
 
     @classmethod
-    def build(cls, pfft, wires, exchange=None):
-        """Local planning only (no communication); `plan_relays` afterwards is collective."""
+    def build(cls, pfft, wires, exchange=None, layout=None):
+        """Local planning only (no communication); `plan_relays` afterwards is collective.
+        `layout`: 'aligned' (default; GFFT_PIPE_LAYOUT overrides) = the line-aligned exchange buffers
+        of _Aligned where the chain qualifies, 'c-order' = C-order blocks everywhere."""
         import torch
         stages, transfers = pfft.xfftn, pfft.transfer
         if not transfers or not (torch.cuda.is_available() or _lib.engine().name != 'hip'):
@@ -275,39 +565,57 @@ class Pipeline:
         for i in range(L):
             if i < L - 1 and plan[i]['p'] > 1 and self.out_buf[i].data_ptr() == self.in_buf[i].data_ptr():
                 self.out_buf[i] = torch.empty_like(self.in_buf[i])       # in-place stage: own send buffer
+        # line-aligned exchange buffers for the standard chain (_Aligned), else C-order ones
+        al = None
+        if (layout or os.environ.get('GFFT_PIPE_LAYOUT', 'aligned')) == 'aligned' and L == 3:
+            al = _Aligned(self, stages, plan, real0)
+            if not al.ok:
+                al = None
+        self.layout = 'aligned' if al is not None else 'c-order'
         # layouts
         lay_in, lay_out = [], []
         for i, x in enumerate(stages):
             shape, ax = tuple(x.forward.input_array.shape), x.axes[0]
-            if i > 0 and plan[i - 1]['p'] > 1:
+            if i > 0 and plan[i - 1]['p'] > 1 and al is None:
                 e = plan[i - 1]
                 lay_in.append(Layout(shape, ax, e['p'], e['f'], e['K']))
             else:
                 lay_in.append(Layout(shape))
-            if i < L - 1 and plan[i]['p'] > 1 and not plan[i]['uneven']:
+            if i < L - 1 and plan[i]['p'] > 1 and not plan[i]['uneven'] and al is None:
                 e = plan[i]
                 lay_out.append(Layout(shape, ax, e['p'], e['f'], e['K']))
             else:
                 lay_out.append(Layout(shape))            # (uneven: described by _RealRows / e['A'])
-        self.fwd = [_Stage(tuple(x.forward.input_array.shape), x.axes[0], lay_in[i], lay_out[i], -1, self.precision)
-                    for i, x in enumerate(stages) if not (real0 and i == 0)]
-        self.bwd = [_Stage(tuple(x.forward.input_array.shape), x.axes[0], lay_out[i], lay_in[i], +1, self.precision)
-                    for i, x in enumerate(stages) if not (real0 and i == 0)]
-        if real0 and plan[0]['p'] > 1:
-            shape0 = tuple(stages[0].forward.input_array.shape)
-            self.fwd.insert(0, _RealRows(shape0, plan[0]['p'], plan[0]['K'], True, self.precision))
-            self.bwd.insert(0, _RealRows(shape0, plan[0]['p'], plan[0]['K'], False, self.precision))
-        elif real0:
-            # local first redistribution (slab-like grids): the real stage keeps its natural plan
-            self.fwd.insert(0, _WholeStage(stages[0].fwd._plan))
-            self.bwd.insert(0, _WholeStage(stages[0].bck._plan))
+
+        def cstage(i, x, kind):
+            li, lo = (lay_in[i], lay_out[i]) if kind < 0 else (lay_out[i], lay_in[i])
+            return _Stage(tuple(x.forward.input_array.shape), x.axes[0], li, lo, kind, self.precision)
+        if al is not None:
+            # stages next to a LOCAL redistribution keep natural layouts on that side (built above as such)
+            self.fwd = [al.fwd[i] if al.fwd[i] is not None else
+                        (_WholeStage(stages[0].fwd._plan) if (real0 and i == 0) else cstage(i, x, -1))
+                        for i, x in enumerate(stages)]
+            self.bwd = [al.bwd[i] if al.bwd[i] is not None else
+                        (_WholeStage(stages[0].bck._plan) if (real0 and i == 0) else cstage(i, x, +1))
+                        for i, x in enumerate(stages)]
+        else:
+            self.fwd = [cstage(i, x, -1) for i, x in enumerate(stages) if not (real0 and i == 0)]
+            self.bwd = [cstage(i, x, +1) for i, x in enumerate(stages) if not (real0 and i == 0)]
+            if real0 and plan[0]['p'] > 1:
+                shape0 = tuple(stages[0].forward.input_array.shape)
+                self.fwd.insert(0, _RealRows(shape0, plan[0]['p'], plan[0]['K'], True, self.precision))
+                self.bwd.insert(0, _RealRows(shape0, plan[0]['p'], plan[0]['K'], False, self.precision))
+            elif real0:
+                # local first redistribution (slab-like grids): the real stage keeps its natural plan
+                self.fwd.insert(0, _WholeStage(stages[0].fwd._plan))
+                self.bwd.insert(0, _WholeStage(stages[0].bck._plan))
         if any(s.plan is None for s in self.fwd + self.bwd):
             self.destroy()
             return None
         # per redistribution: bytes of one chunk region and of the per-peer messages, on the side of
         # the earlier stage (A) and of the later one (B); forward sends A -> B, backward B -> A
         for i, e in enumerate(plan):
-            if e['p'] == 1:
+            if e['p'] == 1 or al is not None:
                 continue
             lb = lay_in[i + 1]
             e['B'] = dict(chunk=lb.chunk * isz, sizes=[lb.block * isz] * e['p'])
@@ -318,6 +626,11 @@ class Pipeline:
             else:
                 la = lay_out[i]
                 e['A'] = dict(chunk=la.chunk * isz, sizes=[la.block * isz] * e['p'])
+        if al is not None and plan[1]['p'] > 1:
+            # T1's slabs carry padding: buffers of their own where the stage arrays are too small
+            for bufs, k in ((self.out_buf, 1), (self.in_buf, 2)):
+                if bufs[k].numel() < al.t1_elems:
+                    bufs[k] = torch.empty(al.t1_elems, dtype=bufs[k].dtype, device=bufs[k].device)
         self.M = [x.M for x in stages]
         self.comm_stream = _streams()[1]
         self._events = {}
@@ -326,6 +639,10 @@ class Pipeline:
         # is collective over the grid, build is not and may return None on single ranks)
         self._want_relays = str(exchange).lower() in ('relay', '1', 'on')
         return self
+
+    def signature(self):
+        """What every rank of the grid must have decided alike for the exchanges to pair up."""
+        return (self.layout, tuple((e['p'], e.get('K', 1), e.get('f')) for e in self.tplan))
 
     def plan_relays(self):
         if self._want_relays:
@@ -368,7 +685,9 @@ class Pipeline:
             for a in range(W):
                 coords = list(np.unravel_index(a, dims))
                 va = coords[g]
-                if wide:
+                if wide and 'block_bytes' in e:
+                    rows_b = e['block_bytes'](e0['widths'][coords[g0]]) // scalar
+                elif wide:
                     rows_b = e['B']['sizes'][0] // scalar // w_me * e0['widths'][coords[g0]]
                 members = []
                 for v in range(dims[g]):
@@ -399,7 +718,7 @@ class Pipeline:
 
     def describe(self):
         return [dict(ranks=e['p'], free_axis=e.get('f'), chunks=e.get('K', 1),
-                     route='relay' if e.get('relay') else 'direct') for e in self.tplan]
+                     route='relay' if e.get('relay') else 'direct', layout=getattr(self, 'layout', 'c-order')) for e in self.tplan]
 
     def run(self, forward, src=None, dst=None, normalize=None):
         """One transform.  `src` / `dst`: tensors of the planned input / output layout to read /
@@ -439,7 +758,7 @@ class Pipeline:
                 elif arrives and c == 0:
                     for cc in range(st.lay_in.K):                                # walks its output: needs it all
                         self._arrived(compute, tag, pos - 1, cc)
-                eng.execute_ptr(st.plan, pin + c * st.step_in, pout + c * st.step_out, scale)
+                st.execute(eng, c, pin, pout, scale)
                 if st.iter_side == 'out':
                     # chunk c of the send buffer is complete: put it on the wire
                     self._exchange(tag, pos, c, t_next, pout, forward, i, compute, cs, cs_raw)

@@ -55,7 +55,11 @@ def main():
     pipeline.Pipeline.MIN_CHUNK_BYTES = 0
     pipeline.Pipeline.MIN_WIDTH = 2
     os.environ['GFFT_RELAY'] = '0'
-    for shape, dt, kw in (((32, 16, 64), 'D', {}), ((16, 32, 32), 'F', {}), ((32, 32, 16), 'D', dict(grid=(-1,)))):
+    # (the last three take the line-aligned exchange buffers of pipeline._Aligned: tile-major T0, pitched T1)
+    for shape, dt, kw, layout in (((32, 16, 64), 'D', {}, None), ((16, 32, 32), 'F', {}, None),
+                                  ((32, 32, 16), 'D', dict(grid=(-1,)), None),
+                                  ((16, 32, 256), 'D', {}, 'aligned'), ((32, 16, 256), 'F', {}, 'aligned'),
+                                  ((32, 32, 64), 'D', dict(grid=(-1,)), 'aligned')):
         if any(n % 8 for n in shape) and P == 8:
             continue
         ref = O.OPFFT(P, shape, dtype=dt, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
@@ -63,6 +67,7 @@ def main():
         want = ref.forward(ref.scatter(G))[r]
         piped = PFFT(world, shape, dtype=dt, wire='overlap', **kw)
         assert piped.pipeline is not None, (shape, kw)
+        assert layout is None or piped.pipeline.layout == layout, (shape, dt, kw, piped.pipeline.describe())
         u = newDistArray(piped, False)
         u[...] = G[piped.local_slice(False)]
         uh = np.asarray(piped.forward(u))

@@ -86,25 +86,68 @@ class HostEngine:
                     howmany=[tuple(int(x) for x in d) for d in howmany], inb=(in_blocks, in_block_stride),
                     outb=(out_blocks, out_block_stride))
 
+    def plan_set_tiles(self, h, side, tile, tile_stride):
+        """gfft_plan_set_tiles: the transformed axis (plans along a contiguous axis) or the adjacent
+        columns (strided plans) of one side are tile-major."""
+        if not h.get('guru') or tile & (tile - 1):
+            return False
+        n, es_in, es_out = h['dim']
+        rows = es_in == 1 and es_out == 1
+        nb = (h['inb'] if side == 0 else h['outb'])[0]
+        if rows and tile and ((n // nb) % tile or n < 128):
+            return False
+        h.setdefault('tiles', {})[side] = (int(tile), int(tile_stride)) if tile else None
+        return True
+
+    def plan_set_flat(self, h, body_width=0, tail_offset=0, tail_row_stride=0):
+        if not h.get('guru'):
+            return False
+        h['flat'] = (int(body_width), int(tail_offset), int(tail_row_stride))
+        return True
+
     def execute_ptr(self, h, ptr_in, ptr_out, scale, stream=None):
         import ctypes
         n, es_in, es_out = h['dim']
         cdt = np.complex128 if h['precision'] == 8 else np.complex64
         isz = np.dtype(cdt).itemsize
+        rows = es_in == 1 and es_out == 1
+        hm = list(h['howmany'])
+        while len(hm) < 3:
+            hm.insert(0, (1, 0, 0))
+        (no, o_i, o_o), (nm, m_i, m_o), (ni, i_i, i_o) = hm
+        flat = h.get('flat')
 
-        def view(ptr, es, blocks, which):
-            nb, bs = blocks
+        def offsets(which):
+            """element offsets [o][m][i][e] of one side"""
+            es = es_in if which == 0 else es_out
+            nb, bs = h['inb'] if which == 0 else h['outb']
+            so, sm, si = (o_i, m_i, i_i) if which == 0 else (o_o, m_o, i_o)
+            tl = (h.get('tiles') or {}).get(which)
+            e = np.arange(n)
             per = n // nb
-            shape = [d[0] for d in h['howmany']] + [nb, per]
-            strides = [d[which] for d in h['howmany']] + [bs if nb > 1 else per * es, es]
-            extent = 1 + sum((sz - 1) * abs(st) for sz, st in zip(shape, strides))
-            flat = np.frombuffer((ctypes.c_char * (extent * isz)).from_address(ptr), dtype=cdt)
-            return np.lib.stride_tricks.as_strided(flat, shape=shape, strides=[st * isz for st in strides])
-        vin = view(ptr_in, es_in, h['inb'], 1)
-        vout = view(ptr_out, es_out, h['outb'], 2)
-        lines = np.ascontiguousarray(vin).reshape(vin.shape[:-2] + (n,))
+            eb, ew = e // per, e % per
+            if rows and tl:
+                line = eb * (bs if nb > 1 else 0) + (ew // tl[0]) * tl[1] + ew % tl[0]
+                if nb == 1:
+                    line = (e // tl[0]) * tl[1] + e % tl[0]
+            else:
+                line = eb * bs + ew * es if nb > 1 else e * es
+            i = np.arange(ni)
+            col = ((i // tl[0]) * tl[1] + i % tl[0]) if (tl and not rows) else i * si
+            off = (np.arange(no)[:, None, None, None] * so + np.arange(nm)[None, :, None, None] * sm
+                   + col[None, None, :, None] + line[None, None, None, :])
+            if which == 0 and flat and flat[0]:
+                bw, toff, tms = flat
+                tail = (np.arange(no)[:, None, None, None] * so + toff + np.arange(nm)[None, :, None, None] * tms
+                        + (i - bw)[None, None, :, None] + line[None, None, None, :])
+                off = np.where((i >= bw)[None, None, :, None], tail, off)
+            return off
+        oi, oo = offsets(0), offsets(1)
+        fin = np.frombuffer((ctypes.c_char * ((int(oi.max()) + 1) * isz)).from_address(ptr_in), dtype=cdt)
+        fout = np.frombuffer((ctypes.c_char * ((int(oo.max()) + 1) * isz)).from_address(ptr_out), dtype=cdt)
+        lines = fin[oi]
         r = np.fft.fft(lines, axis=-1) if h['kind'] == -1 else np.fft.ifft(lines, axis=-1) * n
-        vout[...] = (r * scale).astype(cdt).reshape(vout.shape)
+        fout[oo] = (r * scale).astype(cdt)
 
     def plan_set_truncation(self, h, n_keep):
         return False

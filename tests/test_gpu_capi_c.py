@@ -17,3 +17,5 @@ def test_capi_demo_from_c(tmp_path):
                            '-L', lib, '-lgfft', '-lm', '-Wl,-rpath,' + lib])
     res = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert res.returncode == 0 and 'capi_demo OK' in res.stdout, res.stdout
+    # the GPU box HAS an RCCL: the exchange section must have run on it, not printed its 'skipped' line
+    assert 'exchange: RCCL bound from' in res.stdout and 'skipped' not in res.stdout, res.stdout

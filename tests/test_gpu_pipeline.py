@@ -75,6 +75,9 @@ def test_native_alltoallv_and_split_through_the_c_abi():
     (4, (64, 128, 64), dict(grid=(-1,))),          # slab: one redistribution over all ranks
     (8, (64, 64, 128), dict(grid=(-1,))),
     (4, (64, 64, 64), dict(axes=(1, 2, 0))),
+    (8, (32, 32, 1024), {}),                       # long enough rows for tile-major exchange buffers in fp32 too
+    (4, (32, 64, 512), {}),
+    (2, (32, 32, 512), {}),
 ])
 @pytest.mark.parametrize('dt', ['D', 'F'])
 def test_pipelined_transform_is_bit_identical_to_the_staged_one(P, shape, kw, dt, monkeypatch):
@@ -108,6 +111,8 @@ def test_pipelined_transform_is_bit_identical_to_the_staged_one(P, shape, kw, dt
     want = ref.forward(ref.scatter(G))
     for r, (a, b, c, ab, bb, bn, keep, info) in enumerate(res):
         assert any(e['chunks'] > 1 for e in info), info
+        if shape[2] >= 512:
+            assert all(e['layout'] == 'aligned' for e in info), info      # (pipeline._Aligned)
         assert np.array_equal(a, b) and np.array_equal(a, c), (P, shape, kw, r)
         assert np.array_equal(ab, bb)
         tol = cases.tol_for(dt)
@@ -145,8 +150,8 @@ def test_one_rank_without_a_pipeline_keeps_every_rank_on_the_staged_path(monkeyp
     monkeypatch.setattr(pipeline.Pipeline, 'MIN_WIDTH', 4)
     build = pipeline.Pipeline.build.__func__
 
-    def flaky(cls, pfft, wires, exchange=None):
-        pipe = build(cls, pfft, wires, exchange)
+    def flaky(cls, pfft, wires, exchange=None, layout=None):
+        pipe = build(cls, pfft, wires, exchange, layout)
         parent = next(c.relay_parent for c in pfft.subcomm if getattr(c, 'relay_parent', None) is not None)
         if pipe is not None and parent.Get_rank() == 1:
             pipe.destroy()
@@ -171,6 +176,40 @@ def test_one_rank_without_a_pipeline_keeps_every_rank_on_the_staged_path(monkeyp
     want = ref.forward(ref.scatter(G))
     for r, (piped, a, b, sl) in enumerate(res):
         assert not piped
+        assert np.abs(a - want[r]).max() <= 1e-12 * np.abs(want[r]).max()
+        assert np.allclose(b, G[sl], rtol=0, atol=1e-12)
+
+
+def test_one_rank_without_the_aligned_layout_sends_everybody_back_to_c_order(monkeypatch):
+    """Buffer layouts decide message sizes, so they are agreed on like the pipeline itself: a rank
+    that cannot take the line-aligned exchange buffers reverts the whole grid to C-order ones."""
+    from mpi4py_fft_amd import PFFT, newDistArray, pipeline
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_CHUNK_BYTES', 0)
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_WIDTH', 4)
+    build = pipeline.Pipeline.build.__func__
+
+    def picky(cls, pfft, wires, exchange=None, layout=None):
+        parent = next(c.relay_parent for c in pfft.subcomm if getattr(c, 'relay_parent', None) is not None)
+        return build(cls, pfft, wires, exchange, 'c-order' if parent.Get_rank() == 2 else layout)
+    monkeypatch.setattr(pipeline.Pipeline, 'build', classmethod(picky))
+    shape = (64, 64, 256)
+    G = O.rng_array(shape, 'D', 4)
+
+    def body(comm):
+        f = PFFT(comm, shape, dtype='D', wire='native', exchange='direct')
+        u = newDistArray(f, False)
+        u[...] = G[f.local_slice(False)]
+        a = np.asarray(f.forward(u)).copy()
+        b = np.asarray(f.backward()).copy()
+        lay = f.pipeline.layout
+        sl = f.local_slice(False)
+        f.destroy()
+        return lay, a, b, sl
+    res = cases.run_ranks(4, body)
+    ref = O.OPFFT(4, shape, dtype='D')
+    want = ref.forward(ref.scatter(G))
+    for r, (lay, a, b, sl) in enumerate(res):
+        assert lay == 'c-order'
         assert np.abs(a - want[r]).max() <= 1e-12 * np.abs(want[r]).max()
         assert np.allclose(b, G[sl], rtol=0, atol=1e-12)
 

@@ -182,3 +182,36 @@ def test_device_arrays_stream_to_netcdf_slab_by_slab(tmp_path, monkeypatch):
     assert np.array_equal(f.variables['u'].data[0], G)
     assert np.array_equal(f.variables['u_slice_7_slice'].data[0], G[:, 7, :])
     f.close()
+
+
+@pytest.mark.parametrize('how', ['comm', 'deferred'])
+def test_a_late_rank_cannot_truncate_what_rank_0_has_written(tmp_path, how, monkeypatch):
+    """File creation is collective (round 2 let every rank create / truncate on its own: a rank that
+    reached the constructor after rank 0 had written wiped rank 0's block).  `comm=`: rank 0 creates,
+    barrier.  Without it, in a multi-process world, creation waits for the first write(), where the
+    first rank of the array's grid does it at the head of the turn-taking loop."""
+    import time
+    from tests import thread_comm
+    from mpi4py_fft_amd import DistArray, Subcomm, NCFile
+    from mpi4py_fft_amd import comm as _comm
+    name = str(tmp_path / 'late.nc')
+    G = _global((8, 6, 4))
+    if how == 'deferred':
+        monkeypatch.setattr(_comm, 'world', lambda: type('W', (), {'Get_size': staticmethod(lambda: 2)})())
+
+    def body(c):
+        sub = Subcomm(c, [0, 1, 1])
+        u = _fill(DistArray((8, 6, 4), subcomm=sub, dtype=float), G)
+        if c.Get_rank() == 1:
+            time.sleep(0.5)                      # rank 0 is through its constructor -- and, round 2, its write
+        f = NCFile(name, mode='w', comm=c) if how == 'comm' else NCFile(name, mode='w')
+        f.write(0, {'u': [u]})
+        c.barrier()
+        back = DistArray((8, 6, 4), subcomm=sub, dtype=float)
+        f.read(back, 'u', step=0)
+        return np.abs(np.asarray(back) - np.asarray(u)).max()
+    assert max(thread_comm.run(2, body)) == 0.0
+    from scipy.io import netcdf_file
+    nc = netcdf_file(name, 'r', mmap=False)
+    assert np.array_equal(nc.variables['u'].data[0], G)
+    nc.close()
