@@ -30,7 +30,10 @@
  * in time must be on different streams; (3) the first
  * gfft_execute of the largest plan on a stream allocates, so run each plan once on the stream
  * before capturing it into a HIP graph -- after that gfft_execute and the pointwise entries only
- * enqueue kernels (no allocation, no synchronisation).
+ * enqueue kernels (no allocation, no synchronisation); (4) a workspace handed out during a capture is
+ * baked into the graph, so the library pins it: neither a larger plan arriving later nor the last plan
+ * being destroyed frees it -- only gfft_scratch_release() does, and the caller must not replay such a
+ * graph after calling it.
  */
 #ifndef GFFT_H
 #define GFFT_H
@@ -90,7 +93,7 @@ int gfft_plan_create_r2r(gfft_plan *plan, int ndims, const int64_t *sizes, int n
  * on it when it reads a caller's array in place (Transform.__call__). */
 int gfft_execute(gfft_plan plan, const void *d_in, void *d_out, double scale, void *stream);
 int gfft_plan_destroy(gfft_plan plan);
-int gfft_scratch_release(void);           /* frees the shared per-stream workspaces */
+int gfft_scratch_release(void);           /* frees the shared per-stream workspaces, pinned ones included */
 /* Fuse FFTBase._truncation_forward / _padding_backward (libfft.py:263-311) into a single-axis plan:
  * afterwards gfft_execute writes (forward kinds) / reads (backward kinds) the TRUNCATED array,
  * n_keep entries along the axis (N on a complex axis, N/2+1 on the real half-axis), with the
@@ -118,7 +121,9 @@ int gfft_plan_create_padded(gfft_plan *plan, const int64_t *padded, const int64_
  * nblocks is not a power of two <= 8 dividing the length.  Real transforms: the half-spectrum side
  * of an r2c (side 1) / c2r (side 0) plan along the contiguous last axis takes any nblocks <= 8 --
  * n/2 + 1 entries never split evenly, so the blocks follow the reference's block rule
- * (pencil.py:5-9) exactly as gfft_pack cuts them; other real plans return GFFT_ERR_UNSUPPORTED. */
+ * (pencil.py:5-9) exactly as gfft_pack cuts them; other real plans return GFFT_ERR_UNSUPPORTED.
+ * After gfft_plan_set_truncation the truncated side's blocks are blocks of the KEPT entries (complex
+ * axes: equal blocks of a power of two of them; the real half-axis: the block rule over n_keep). */
 int gfft_plan_set_split(gfft_plan plan, int side, int nblocks);
 /* One batched 1-D complex transform with explicit strides: the form fftw_planxfftn() hands to
  * fftw_plan_guru_dft (fftw_planxfftn.c:25-57) -- `dim` is the transformed axis, `howmany` up to
@@ -134,6 +139,17 @@ typedef struct { int64_t n, is, os; } gfft_iodim;
 int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_iodim *dim, int howmany_rank,
                           const gfft_iodim *howmany, int in_blocks, int64_t in_block_stride, int out_blocks,
                           int64_t out_block_stride);
+/* gfft_plan_create_guru with the 3/2-rule truncation (forward kind: on the store side) / zero padding
+ * (backward kind: on the load side) of libfft.py:263-311 fused in, as gfft_plan_set_truncation fuses it
+ * into natural plans: dim->n is the padded (transformed) length, `n_keep` the entries kept along the axis
+ * on the truncated side -- the output of a forward plan, the input of a backward one -- whose stride
+ * (dim->os / dim->is) and blocks then describe the TRUNCATED line: its blocks are equal blocks of the
+ * kept entries (a power of two of them each), what the stage of a padded distributed transform
+ * (mpifft.py:247-257 inflates the shape, :68-73 runs the chain) sends to / receives from its
+ * sub-communicator.  n_keep = 0 or n: no truncation (= gfft_plan_create_guru). */
+int gfft_plan_create_guru_padded(gfft_plan *plan, int precision, int kind, const gfft_iodim *dim, int64_t n_keep,
+                                 int howmany_rank, const gfft_iodim *howmany, int in_blocks, int64_t in_block_stride,
+                                 int out_blocks, int64_t out_block_stride);
 /* Layouts of INTERNAL exchange buffers (between two stages of a distributed transform; never of a
  * caller's array, which keeps the reference's C order, pencil.py:347-354).  All three act on one-pass
  * plans (gfft_plan_create_guru, or gfft_plan_create on one axis) and return GFFT_ERR_UNSUPPORTED,

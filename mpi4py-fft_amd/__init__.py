@@ -16,4 +16,4 @@ from .libfft import FFT
 from . import fftw
 from .fftw import fftlib
 from . import spectral
-from .io import HDF5File, NCFile
+from .io import HDF5File, NCFile, generate_xdmf

@@ -53,6 +53,8 @@ def _declare(lib):
         'gfft_plan_set_split': (c.c_int, [vp, c.c_int, c.c_int]),
         'gfft_plan_create_guru': (c.c_int, [c.POINTER(vp), c.c_int, c.c_int, c.POINTER(IoDim), c.c_int, c.POINTER(IoDim),
                                             c.c_int, c.c_int64, c.c_int, c.c_int64]),
+        'gfft_plan_create_guru_padded': (c.c_int, [c.POINTER(vp), c.c_int, c.c_int, c.POINTER(IoDim), c.c_int64, c.c_int,
+                                                   c.POINTER(IoDim), c.c_int, c.c_int64, c.c_int, c.c_int64]),
         'gfft_plan_set_tiles': (c.c_int, [vp, c.c_int, c.c_int, c.c_int64]),
         'gfft_plan_set_flat': (c.c_int, [vp, c.c_int64, c.c_int64, c.c_int64]),
         'gfft_plan_set_split_slabs': (c.c_int, [vp, c.c_int, c.c_int, c.c_int64, c.c_int]),
@@ -187,14 +189,15 @@ class HipEngine:
         return h
 
     def plan_create_guru(self, precision, kind, dim, howmany, in_blocks=1, in_block_stride=0, out_blocks=1,
-                         out_block_stride=0):
+                         out_block_stride=0, n_keep=0):
         """Strided batched 1-D plan (gfft_plan_create_guru); dim / howmany entries are (n, is, os).
-        None when the engine has no single-pass kernel for it."""
+        n_keep: entries kept on the truncated side of a fused 3/2-rule truncation / zero padding
+        (gfft_plan_create_guru_padded).  None when the engine has no single-pass kernel for it."""
         h = ctypes.c_void_p()
         hm = (IoDim * max(1, len(howmany)))(*[IoDim(*[int(x) for x in d]) for d in howmany])
-        rc = lib().gfft_plan_create_guru(ctypes.byref(h), int(precision), int(kind), ctypes.byref(IoDim(*[int(x) for x in dim])),
-                                         len(howmany), hm, int(in_blocks), int(in_block_stride), int(out_blocks),
-                                         int(out_block_stride))
+        rc = lib().gfft_plan_create_guru_padded(ctypes.byref(h), int(precision), int(kind), ctypes.byref(IoDim(*[int(x) for x in dim])),
+                                                int(n_keep), len(howmany), hm, int(in_blocks), int(in_block_stride),
+                                                int(out_blocks), int(out_block_stride))
         if rc == -2:
             return None
         check(rc)
@@ -300,6 +303,12 @@ class HipEngine:
         self.require_device(tarray)
         check(lib().gfft_unpack(tpacked.data_ptr(), tarray.data_ptr(), len(shape), _i64(shape), axis,
                                 nparts, itemsize, current_stream()))
+
+    def pack_ptr(self, ptr_array, ptr_packed, shape, axis, nparts, itemsize, unpack=False):
+        """gfft_pack / gfft_unpack on raw device addresses (sub-arrays of exchange buffers, pipeline.py)."""
+        fn = lib().gfft_unpack if unpack else lib().gfft_pack
+        a, b = (ptr_packed, ptr_array) if unpack else (ptr_array, ptr_packed)
+        check(fn(ctypes.c_void_p(a), ctypes.c_void_p(b), len(shape), _i64(shape), axis, nparts, itemsize, current_stream()))
 
     def truncate(self, tpadded, ttrunc, shape_padded, axis, n_trunc, is_real, precision, scale):
         self.require_device(tpadded)

@@ -209,6 +209,22 @@ class TorchWire:
                                          send[send_off: send_off + sum(send_sizes)], recv_sizes, send_sizes)
 
 
+    def exchange_placed(self, send, send_offs, send_sizes, recv, recv_offs, recv_sizes):
+        """The same exchange with every peer's message at its own byte offset (a side that is the natural
+        array of the stage behind it, pipeline._SlabStage): on RCCL one asynchronous list-form all-to-all
+        over views; elsewhere (gloo on development boxes has no list form) a synchronous batch of
+        point-to-point messages.  Returns the work handle, or None when already complete."""
+        outs = [recv[o: o + n] for o, n in zip(recv_offs, recv_sizes)]
+        ins = [send[o: o + n] for o, n in zip(send_offs, send_sizes)]
+        c = self._comm
+        if c.backend == 'nccl' and hasattr(c, 'alltoall_lists'):
+            return c.alltoall_lists(outs, ins)
+        me = self.rank
+        outs[me].copy_(ins[me])
+        c.p2p([(t, j) for j, t in enumerate(ins) if j != me], [(t, j) for j, t in enumerate(outs) if j != me])
+        return None
+
+
 def torch_wires(subcomm):
     """TorchWire (or None for single-rank axes) per entry of a Subcomm tuple."""
     return [TorchWire(c) if (c.Get_size() > 1 and hasattr(c, 'alltoall_views')) else None for c in subcomm]
@@ -348,6 +364,10 @@ class TorchComm(Comm):
         return self._dist.all_to_all_single(out, inp, [int(n) for n in out_sizes], [int(n) for n in in_sizes],
                                             group=self._pg, async_op=True)
 
+    def alltoall_lists(self, outs, ins):
+        """Asynchronous all-to-all between lists of 1-D views (one per peer); returns the work handle."""
+        return self._dist.all_to_all(list(outs), list(ins), group=self._pg, async_op=True)
+
     def alltoall_async(self, send, recv, send_counts, recv_counts):
         """Non-blocking variant: returns a handle with ``wait()``.  On the nccl backend the
         exchange runs on RCCL's own stream after the work already queued on the current stream;
@@ -426,8 +446,16 @@ class MpiComm(Comm):
     stands in for mpi4py where it is not installed (tests/test_gpu_mpicomm.py)."""
     backend = 'nccl'                 # what the wire is: RCCL (pencil.Transfer / relay.py ask)
 
+    _pinned = {}                      # id(user's communicator) -> the object itself, see wire_key
+
     def __init__(self, mpi, parent=None, members=None):
         self._mpi = mpi
+        if parent is None:
+            # The RCCL twin of a communicator is cached under id(mpi) (NativeWire._world): keep the object
+            # alive for as long as that entry can be hit, or a later communicator allocated at the same
+            # address would find the stale entry on SOME ranks only and skip a collective the others
+            # are waiting in (seen as a once-in-a-while hang of tests/test_gpu_mpicomm.py).
+            MpiComm._pinned[id(mpi)] = mpi
         self._size, self._rank = int(mpi.Get_size()), int(mpi.Get_rank())
         # ranks of the ROOT communicator (the one the user passed), in this communicator's rank order
         self._root = parent._root if parent is not None else self

@@ -590,7 +590,10 @@ __device__ __forceinline__ cx<real> tile_load_pad(const PassDesc &d, const void 
     const int h = d.tr_N >> 1;
     const bool lo = e <= h, hi = h > 0 && e >= d.n - h;
     const bool half = d.tr_even && (e == h || e == d.n - h);
-    v = reinterpret_cast<const cx<real> *>(in)[lo ? idx : (hi ? idx - shift : base)];
+    int64_t at = lo ? idx : (hi ? idx - shift : base);
+    // kept entries stored as equal blocks of an all-to-all buffer (PassDesc::tr_jump)
+    if (d.tr_jump && (lo || hi)) at += (int64_t)((lo ? e : e - (d.n - d.tr_N)) >> d.tr_lgper) * d.tr_jump;
+    v = reinterpret_cast<const cx<real> *>(in)[at];
     const real f = (lo || hi) ? (half ? (real)0.5 : (real)1) : (real)0;
     v.x *= f;
     v.y *= f * sy;
@@ -612,7 +615,11 @@ __device__ __forceinline__ void tile_store_trunc(const PassDesc &d, void *__rest
     const int h = d.tr_N >> 1;
     const bool lo = e <= h, hi = h > 0 && e >= d.n - h;
     if (d.tr_even && e == d.n - h) return;            // folded onto entry h by the kernel body
-    if (lo || hi) p[lo ? idx : idx - shift] = {v.x * sx, v.y * sy};
+    if (lo || hi) {
+      int64_t at = lo ? idx : idx - shift;
+      if (d.tr_jump) at += (int64_t)((lo ? e : e - (d.n - d.tr_N)) >> d.tr_lgper) * d.tr_jump;
+      p[at] = {v.x * sx, v.y * sy};
+    }
   }
 }
 
@@ -850,7 +857,8 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
             // entry of an even truncated length is a real Nyquist value taken at half weight
             const int e = tl + q * NT;
             const bool ok = e < d.tr_n, nyq = d.tr_even && e == d.tr_n - 1;
-            v[q] = reinterpret_cast<const cx<real> *>(in)[ok ? idx : in0];
+            if constexpr ((FLAGS & 128) != 0) v[q] = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, o, i, ok ? e : 0)];
+            else v[q] = reinterpret_cast<const cx<real> *>(in)[ok ? idx : in0];
             v[q].x *= ok ? (nyq ? (real)0.5 : (real)1) : (real)0;
             v[q].y *= (ok && !nyq) ? (real)1 : (real)0;
           } else if constexpr ((FLAGS & 64) != 0) v[q] = tile_load_pad<real, IOMODE>(d, in, in0, idx, pad_shift_in, tl + q * NT, sy_in);
@@ -884,7 +892,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
       // c2r does.
       cx<real> top = {0, 0};
       if (tl == 0) {
-        if constexpr ((FLAGS & 128) != 0) {
+        if constexpr ((FLAGS & 128) != 0 && !(FLAGS & 16)) {
           if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, o, i, N)].x;
         } else if constexpr (!(FLAGS & 64)) {
           if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[in0 + (int64_t)N * d.in_es].x;
@@ -1024,7 +1032,9 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
             const int e = tl + q * NT;
             if (e < d.tr_n) {
               const bool nyq = d.tr_even && e == d.tr_n - 1;
-              reinterpret_cast<cx<real> *>(out)[idx] = {v[q].x * (nyq ? 2 * sx_out : sx_out), nyq ? (real)0 : v[q].y * sy_out};
+              int64_t at = idx;
+              if constexpr ((FLAGS & 128) != 0) at = uneven_offset(d, row_ub, o, i, e);
+              reinterpret_cast<cx<real> *>(out)[at] = {v[q].x * (nyq ? 2 * sx_out : sx_out), nyq ? (real)0 : v[q].y * sy_out};
             }
           } else if constexpr (!(FLAGS & 64)) tile_store_trunc<real, IOMODE>(d, out, idx, pad_shift_out, tl + q * NT, v[q], sx_out, sy_out);
           else tile_store<real, IOMODE, false, false>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
@@ -1040,7 +1050,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
         }
         idx += step;
       }
-      if constexpr (MODE == MODE_R2C_H && (FLAGS & 128) != 0) {
+      if constexpr (MODE == MODE_R2C_H && (FLAGS & 128) != 0 && !(FLAGS & 16)) {
         if (tl == 0)
           reinterpret_cast<cx<real> *>(out)[uneven_offset(d, row_ub, o, i, N)] = {(z0.x - z0.y) * 2 * sx_out, 0};
       } else if constexpr (MODE == MODE_R2C_H && !(FLAGS & 16)) {
@@ -1068,7 +1078,10 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   // split layouts: whole thread slots per block, plain complex passes only
   if (d.in_lgp || d.out_lgp) {
     const int lg = d.in_lgp > d.out_lgp ? d.in_lgp : d.out_lgp;
-    if (((R >> lg) << lg) != R || MODE != MODE_C2C || BIGTW || (FLAGS & 16)) return hipErrorInvalidValue;
+    if (((R >> lg) << lg) != R || MODE != MODE_C2C || BIGTW) return hipErrorInvalidValue;
+    // (next to a fused truncation / padding the blocks sit on the PLAIN side only; the truncated side's
+    // are PassDesc::tr_jump)
+    if ((FLAGS & 16) && ((FLAGS & 64) ? d.in_lgp : d.out_lgp)) return hipErrorInvalidValue;
   }
   // tile-major lines (ROWS): thread slots advance by NT entries = whole tiles
   if (!COLS && ((d.in_tlg && (NT & ((1 << d.in_tlg) - 1))) || (d.out_tlg && (NT & ((1 << d.out_tlg) - 1)))))
@@ -1102,7 +1115,15 @@ hipError_t half_launch(const PassDesc &d, const void *in, void *out, hipStream_t
   static_assert(MODE == MODE_R2C_H || MODE == MODE_C2R_H, "packed-real modes");
   if (d.ub_p > 1 && d.tr_dir == 0)
     return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 128, MODE, false, RADS...>(d, in, out, s);
-  if (d.ub_p > 1) return hipErrorInvalidValue;
+  if (d.ub_p > 1) {
+    // ... of the KEPT entries of a truncated half spectrum (3/2-rule transforms on several ranks)
+    if constexpr (MODE == MODE_R2C_H) {
+      if (d.tr_dir == 1) return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 16 | 128, MODE, false, RADS...>(d, in, out, s);
+    } else {
+      if (d.tr_dir == 2) return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 16 | 64 | 128, MODE, false, RADS...>(d, in, out, s);
+    }
+    return hipErrorInvalidValue;
+  }
   if (d.tr_dir == 0) return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 0, MODE, false, RADS...>(d, in, out, s);
   if constexpr (MODE == MODE_R2C_H) {
     if (d.tr_dir == 1) return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 16, MODE, false, RADS...>(d, in, out, s);

@@ -34,6 +34,11 @@ struct PassDesc {
   int swizzle;    // XCD-contiguous tile order (speed only)
   // fused 3/2-rule adapters (register kernels): 0 none, 1 truncate on store, 2 zero-pad on load
   int tr_dir, tr_n, tr_N, tr_even;
+  // ... with the TRUNCATED side being an all-to-all buffer of 2^k equal blocks of the kept entries
+  // (complex axes; gfft_plan_set_split / gfft_plan_create_guru_padded): kept entry k of a line sits
+  // tr_jump * (k >> tr_lgper) elements beyond its place in a contiguous line.  tr_jump = 0: contiguous.
+  int tr_lgper;
+  int64_t tr_jump;
   int64_t batch;  // number of columns = outer * mid * inner
   int64_t mid, inner;
   // strided (COLS) passes over rows with padding columns: of the `inner` adjacent columns only the

@@ -236,8 +236,10 @@ size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // streams get their own.  Growing synchronises the stream once (earlier launches may still be
 // using the old buffer).
 struct ScratchPool {
+  struct Slot { void *p = nullptr; size_t n = 0; bool pinned = false; };
   std::mutex m;
-  std::map<std::pair<std::thread::id, hipStream_t>, std::pair<void *, size_t>> bufs;
+  std::map<std::pair<std::thread::id, hipStream_t>, Slot> bufs;
+  std::vector<void *> retired;      // buffers a captured graph may still use, replaced by larger ones
   int get(hipStream_t s, size_t bytes, void **out) {
     std::lock_guard<std::mutex> lock(m);
     const auto me = std::this_thread::get_id();
@@ -246,35 +248,50 @@ struct ScratchPool {
     if (cap != hipStreamCaptureStatusNone) {
       // No allocation inside a capture: the graph uses the buffer this thread's warm-up execution
       // grew (on whatever stream that ran), so replays must not overlap other executions of this
-      // thread -- the stream a graph is replayed on orders them.
+      // thread -- the stream a graph is replayed on orders them.  The buffer's address is now baked
+      // into the graph: it is PINNED -- never freed by growth or by the last plan going away, only
+      // by an explicit gfft_scratch_release().
       for (auto &kv : bufs)
-        if (kv.first.first == me && kv.second.second >= bytes) { *out = kv.second.first; return GFFT_OK; }
+        if (kv.first.first == me && kv.second.n >= bytes) { kv.second.pinned = true; *out = kv.second.p; return GFFT_OK; }
       return fail(GFFT_ERR_INVALID, "stream capture: execute the plan once before capturing it (its workspace is allocated at the first execution)");
     }
-    auto &b = bufs[{me, s}];
-    if (bytes > b.second) {
-      if (b.first) {
+    Slot &b = bufs[{me, s}];
+    if (bytes > b.n) {
+      if (b.p && b.pinned) {
+        retired.push_back(b.p);      // a captured graph holds this address: keep it alive
+      } else if (b.p) {
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipFree(b.first));
-        b = {nullptr, 0};
+        HIP_TRY(hipFree(b.p));
       }
+      b = Slot{};
       void *p = nullptr;
       hipError_t e = hipMalloc(&p, bytes);
       if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(GFFT_ERR_NOMEM, "scratch allocation failed"); }
       HIP_TRY(e);
-      b = {p, bytes};
+      b.p = p;
+      b.n = bytes;
     }
-    *out = b.first;
+    *out = b.p;
     return GFFT_OK;
   }
-  int release() {
+  // everything == false: the last plan of the process went away -- buffers no graph refers to are
+  // freed; true: gfft_scratch_release(), the caller vouches that no captured graph will be replayed
+  int release(bool everything) {
     std::lock_guard<std::mutex> lock(m);
-    for (auto &kv : bufs)
-      if (kv.second.first) {
-        (void)hipStreamSynchronize(kv.first.second);
-        (void)hipFree(kv.second.first);
+    // (one device-wide synchronisation: the stream handles in the keys may have been destroyed since)
+    if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+    for (auto it = bufs.begin(); it != bufs.end();) {
+      if (it->second.p && (everything || !it->second.pinned)) {
+        (void)hipFree(it->second.p);
+        it = bufs.erase(it);
+      } else {
+        ++it;
       }
-    bufs.clear();
+    }
+    if (everything) {
+      for (void *p : retired) (void)hipFree(p);
+      retired.clear();
+    }
     return GFFT_OK;
   }
 };
@@ -1466,8 +1483,9 @@ int gfft_plan_set_split(gfft_plan pl, int side, int nblocks) {
   if ((p.d.mode == MODE_R2C_H && side == 1) || (p.d.mode == MODE_C2R_H && side == 0)) {
     // packed-real rows: the half-spectrum side as an all-to-all buffer of UNEVEN blocks (the
     // n/2 + 1 entries never divide evenly; pencil.py:5-9 deals the remainder to the first ranks)
-    if (p.d.tr_dir || p.d.mid != 1 || p.d.inner != 1) return fail(GFFT_ERR_UNSUPPORTED, "split layout: plain packed-real rows only");
-    const int nh = p.d.n + 1;
+    if (p.d.mid != 1 || p.d.inner != 1) return fail(GFFT_ERR_UNSUPPORTED, "split layout: packed-real rows only");
+    // (with a fused truncation / zero padding the blocks are those of the KEPT entries)
+    const int nh = p.d.tr_dir ? p.d.tr_n : p.d.n + 1;
     if (nblocks < 1 || nblocks > 8 || nblocks > nh) return fail(GFFT_ERR_UNSUPPORTED, "split layout: at most 8 blocks");
     if (nblocks == 1) {
       p.d.ub_p = 0;
@@ -1480,12 +1498,26 @@ int gfft_plan_set_split(gfft_plan pl, int side, int nblocks) {
     p.d.ub_rows = p.d.batch;
     return GFFT_OK;
   }
-  if (p.kind != PK_FFT || !p.regk || p.d.mid != 1 || p.d.tw_hi || p.d.tr_dir || p.d.mode != MODE_C2C)
+  if (p.kind != PK_FFT || !p.regk || p.d.mid != 1 || p.d.tw_hi || p.d.mode != MODE_C2C)
     return fail(GFFT_ERR_UNSUPPORTED, "split layouts fuse into complex register-kernel passes only");
   const int64_t n = p.d.n, inner = p.d.inner, outer = p.d.batch / p.d.inner;
   int lg = 0;
   while ((1 << lg) < nblocks) ++lg;
   if (nblocks < 1 || (1 << lg) != nblocks) return fail(GFFT_ERR_UNSUPPORTED, "block count must be a power of two");
+  if (p.d.tr_dir && side == (p.d.tr_dir == 1 ? 1 : 0)) {
+    // the TRUNCATED side of a fused 3/2-rule truncation / zero padding: equal blocks of the kept
+    // entries, addressed per entry (PassDesc::tr_jump) -- no tie to the kernel's thread layout
+    const int64_t keep = p.d.tr_N;
+    if (nblocks > 8 || keep % nblocks) return fail(GFFT_ERR_UNSUPPORTED, "block count does not divide the kept length");
+    const int64_t per = keep / nblocks;
+    if (nblocks > 1 && !is_pow2(per)) return fail(GFFT_ERR_UNSUPPORTED, "kept entries per block must be a power of two");
+    int lgper = 0;
+    while (((int64_t)1 << lgper) < per) ++lgper;
+    p.d.tr_lgper = nblocks > 1 ? lgper : 0;
+    p.d.tr_jump = nblocks > 1 ? (outer - 1) * per * inner : 0;
+    (side == 0 ? p.d.in_os : p.d.out_os) = per * inner;
+    return GFFT_OK;
+  }
   // whole thread slots per block: R = 4 (n = 16), 8 or 16 (other powers of two), 12 / 20 (3^b 2^k / 5^c 2^k)
   const int max_blocks = is_pow2(n) ? (n >= 32 ? 8 : 4) : 4;
   if (nblocks > max_blocks || n % nblocks) return fail(GFFT_ERR_UNSUPPORTED, "block count not supported for this length");
@@ -1506,6 +1538,13 @@ int gfft_plan_set_split(gfft_plan pl, int side, int nblocks) {
 int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_iodim *dim, int howmany_rank,
                           const gfft_iodim *howmany, int in_blocks, int64_t in_block_stride, int out_blocks,
                           int64_t out_block_stride) {
+  return gfft_plan_create_guru_padded(plan, precision, kind, dim, 0, howmany_rank, howmany, in_blocks, in_block_stride,
+                                      out_blocks, out_block_stride);
+}
+
+int gfft_plan_create_guru_padded(gfft_plan *plan, int precision, int kind, const gfft_iodim *dim, int64_t n_keep,
+                                 int howmany_rank, const gfft_iodim *howmany, int in_blocks, int64_t in_block_stride,
+                                 int out_blocks, int64_t out_block_stride) {
   if (!plan || !dim || (howmany_rank > 0 && !howmany)) return fail(GFFT_ERR_INVALID, "null argument");
   *plan = nullptr;
   if (precision != GFFT_F32 && precision != GFFT_F64) return fail(GFFT_ERR_INVALID, "precision must be 4 or 8");
@@ -1524,12 +1563,17 @@ int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_i
   const double batch = (double)o.n * (double)m.n * (double)i.n;
   if (batch >= 2147483648.0) return fail(GFFT_ERR_UNSUPPORTED, "batch exceeds 2^31");
   const int64_t n = dim->n;
-  auto blocks_ok = [&](int nb) {
+  if (n_keep < 0 || n_keep > n) return fail(GFFT_ERR_INVALID, "bad kept length");
+  const bool trunc = n_keep > 0 && n_keep < n;
+  const int tr_side = kind == GFFT_C2C_FORWARD ? 1 : 0;           // the side that holds the kept entries
+  auto blocks_ok = [&](int nb, int side) {
     if (nb < 1 || (nb & (nb - 1))) return false;
+    if (trunc && side == tr_side)                                // equal power-of-two blocks of the kept entries
+      return nb <= 8 && n_keep % nb == 0 && (nb == 1 || is_pow2(n_keep / nb));
     const int max_blocks = is_pow2(n) ? (n >= 32 ? 8 : 4) : 4;    // whole thread slots per block (see gfft_plan_set_split)
     return nb <= max_blocks && n % nb == 0;
   };
-  if (!blocks_ok(in_blocks) || !blocks_ok(out_blocks)) return fail(GFFT_ERR_UNSUPPORTED, "block count not supported for this length");
+  if (!blocks_ok(in_blocks, 0) || !blocks_ok(out_blocks, 1)) return fail(GFFT_ERR_UNSUPPORTED, "block count not supported for this length");
   gfft_plan_s *pl = new gfft_plan_s;
   pl->ndims = 0;
   pl->kind = kind;
@@ -1554,15 +1598,28 @@ int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_i
   d.out_os = o.os; d.out_ms = m.os; d.out_is = i.os; d.out_es = dim->os;
   d.scale = 1.0;
   auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
-  if (in_blocks > 1) { d.in_lgp = lg2(in_blocks); d.in_jump = in_block_stride - (n / in_blocks) * dim->is; }
-  if (out_blocks > 1) { d.out_lgp = lg2(out_blocks); d.out_jump = out_block_stride - (n / out_blocks) * dim->os; }
+  if (in_blocks > 1 && !(trunc && tr_side == 0)) { d.in_lgp = lg2(in_blocks); d.in_jump = in_block_stride - (n / in_blocks) * dim->is; }
+  if (out_blocks > 1 && !(trunc && tr_side == 1)) { d.out_lgp = lg2(out_blocks); d.out_jump = out_block_stride - (n / out_blocks) * dim->os; }
+  if (trunc) {
+    // fused 3/2-rule truncation (forward: store side) / zero padding (backward: load side), as
+    // gfft_plan_set_truncation sets it on natural plans; blocks of the kept entries by PassDesc::tr_jump
+    d.tr_dir = tr_side == 1 ? 1 : 2;
+    d.tr_n = d.tr_N = (int)n_keep;
+    d.tr_even = (n_keep % 2 == 0) ? 1 : 0;
+    const int nb = tr_side == 1 ? out_blocks : in_blocks;
+    if (nb > 1) {
+      const int64_t per = n_keep / nb;
+      d.tr_lgper = lg2((int)per);
+      d.tr_jump = (tr_side == 1 ? out_block_stride - per * dim->os : in_block_stride - per * dim->is);
+    }
+  }
   p.blocks[0] = in_blocks;   p.bstride[0] = in_block_stride;
   p.blocks[1] = out_blocks;  p.bstride[1] = out_block_stride;
   rc = get_twiddles(n, precision, &d.tw);
   if (rc) { delete pl; return rc; }
   pl->passes.push_back(p);
   if (n > 1) pl->flops = 5.0 * (double)n * std::log2((double)n) * batch;
-  pl->bytes = batch * (double)n * 4.0 * precision;
+  pl->bytes = batch * (double)(n + (trunc ? n_keep : n)) * 2.0 * precision;
   *plan = pl;
   ++g_live_plans;
   return GFFT_OK;
@@ -1660,12 +1717,12 @@ int gfft_plan_set_split_slabs(gfft_plan pl, int side, int nblocks, int64_t rows_
 }
 
 /* free the shared scratch buffers (they are otherwise kept for the life of the process) */
-int gfft_scratch_release(void) { return scratch_pool().release(); }
+int gfft_scratch_release(void) { return scratch_pool().release(true); }
 
 int gfft_plan_destroy(gfft_plan pl) {
   if (!pl) return GFFT_OK;
   delete pl;
-  if (--g_live_plans == 0) (void)scratch_pool().release();
+  if (--g_live_plans == 0) (void)scratch_pool().release(false);
   return GFFT_OK;
 }
 

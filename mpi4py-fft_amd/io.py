@@ -438,8 +438,18 @@ class NCFile(FileBase):
         return var, (int(step),)
 
     def _existing(self, name, u, step):
-        t = self.f.variables['time']
-        have = np.asarray(t[:] if self._nc4 is not None else t.data)
-        hit = np.nonzero(have == step)[0]
-        it = int(hit[0]) if len(hit) else int(step)
-        return self._var(name), (it,)
+        # `step` indexes the RECORD directly, as the reference's read does (nc_file.py: `self.f[name][(step,) + s]`)
+        # -- write() is what maps a step value to a record through the `time` variable (nc_file.py:150-156),
+        # so the two agree for steps written in order 0, 1, 2, ... and differ, there as here, otherwise
+        return self._var(name), (int(step),)
+
+
+def generate_xdmf(h5filename, periodic=True, order='visit'):
+    """Name kept for scripts written against the reference (mpi4py_fft/__init__.py:26 exports it;
+    io/generate_xdmf.py writes XDMF visualisation metadata next to an HDF5 snapshot file).  Not rebuilt
+    here: it is pure host-side XML generation outside the PFFT hot path (DESIGN.md
+    section 7) -- the reference's own generator reads the files HDF5File writes (same dataset layout,
+    io/h5py_file.py:147-152) and can be used unchanged."""
+    raise NotImplementedError('generate_xdmf is not part of this package: run mpi4py_fft.io.generate_xdmf '
+                              'on the HDF5 file (the dataset layout is the reference\'s)')
+

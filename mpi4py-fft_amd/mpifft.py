@@ -233,7 +233,7 @@ class PFFT:
                 self._fuse_packs()
             # the route of every exchange (relay.py): collective over the grid, same order everywhere
         self.pipeline = None
-        if not local and padding is False and transforms is None:
+        if not local and transforms is None:
             self.pipeline = self._plan_pipeline(wire, exchange)
         if not local:
             # the staged path's routes (it stays available: stage_times, fall-back); timed only when
@@ -435,9 +435,9 @@ class PFFT:
                 continue
             for stage, axis, attr, io in ((self.xfftn[i], tr.axisA, 'packedA', (1, 0)),
                                           (self.xfftn[i + 1], tr.axisB, 'packedB', (0, 1))):
-                if (tuple(stage.axes) != (axis,) or stage._padded or not hasattr(stage.fwd, 'set_split')
-                        or not hasattr(stage.bck, 'set_split')):
-                    continue
+                if (tuple(stage.axes) != (axis,) or (stage._padded and not stage._fused_trunc)
+                        or not hasattr(stage.fwd, 'set_split') or not hasattr(stage.bck, 'set_split')):
+                    continue                  # (a 3/2-rule stage qualifies once its truncation is fused, libfft.FFT)
                 # an in-place stage (single-rank chain: input array == output array) reads and
                 # writes each tile at the same addresses; a packed side would break that.  Give
                 # such a stage its own output array (one more local array, one pack pass less).

@@ -91,7 +91,9 @@ class Layout:
 
 class _Stage:
     """One serial transform of the chain in one direction: guru plan + how to walk its chunks."""
-    def __init__(self, shape, axis, lay_in, lay_out, kind, precision):
+    def __init__(self, shape, axis, lay_in, lay_out, kind, precision, n_keep=0):
+        # `shape`: the stage's forward INPUT shape (shape[axis] = the transformed length); n_keep: entries
+        # kept along the axis on the truncated side of a padded stage (forward: output, backward: input)
         self.axis, self.lay_in, self.lay_out = axis, lay_in, lay_out
         nd = len(shape)
         # iterate over the chunks of the side that has them (input side first: data arrives in
@@ -127,7 +129,7 @@ class _Stage:
         if len(dims) <= 3:
             self.plan = _lib.engine().plan_create_guru(
                 precision, kind, (shape[axis], lay_in.stride[axis], lay_out.stride[axis]), dims,
-                lay_in.p, lay_in.block, lay_out.p, lay_out.block)
+                lay_in.p, lay_in.block, lay_out.p, lay_out.block, **(dict(n_keep=n_keep) if n_keep else {}))
         # byte offsets of chunk c on either side
         isz = 2 * precision
         if self.iter_side == 'in':
@@ -149,10 +151,13 @@ class _Stage:
 class _WholeStage:
     """A stage run as the staged path runs it: its own natural-layout plan on the whole local array
     (the real first stage of an r2c transform whose first redistribution is local)."""
-    def __init__(self, plan_handle):
+    def __init__(self, plan_handle, K_in=1, K_out=1):
+        # K_in / K_out: chunks of the exchange on its input / output side (it waits for all of them /
+        # sends them all once it is done: a stage that transforms the axis the chunks cut)
         self.plan = plan_handle
         self.nchunks, self.iter_side, self.step_in, self.step_out = 1, None, 0, 0
-        self.lay_in = self.lay_out = type('Side', (), dict(K=1, p=1))()
+        self.lay_in = type('Side', (), dict(K=K_in, p=1))()
+        self.lay_out = type('Side', (), dict(K=K_out, p=1))()
 
     def execute(self, eng, c, pin, pout, scale):
         eng.execute_ptr(self.plan, pin, pout, scale)
@@ -167,28 +172,29 @@ class _RealRows:
     chunk-major exchange buffer of UNEVEN blocks that gfft_plan_set_split addresses (n/2 + 1
     entries dealt to p ranks by the block rule).  `forward`: real natural -> buffer, else buffer ->
     real natural."""
-    def __init__(self, shape, p, K, forward, precision, tile=0):
+    def __init__(self, shape, p, K, forward, precision, tile=0, n_keep=0):
         n0, n1, n = (int(v) for v in shape)
         nh = n // 2 + 1
         rows = (n0 // K) * n1
         eng = _lib.engine()
         self.plan = None
+        keep = int(n_keep) if n_keep else nh          # entries kept of the half spectrum (3/2-rule stages)
         # tile > 0: the blocks slab by slab, tile-major (gfft_plan_set_split_slabs; _Aligned below)
         split = (lambda h, side: eng.plan_set_split_slabs(h, side, p, n1, tile)) if tile else \
             (lambda h, side: eng.plan_set_split(h, side, p))
         if forward:
             h = eng.plan_create((rows, n), (rows, nh), (1,), _lib.R2C, precision)
-            ok = split(h, 1)
+            ok = (keep == nh or eng.plan_set_truncation(h, keep)) and split(h, 1)
         else:
             h = eng.plan_create((rows, nh), (rows, n), (1,), _lib.C2R, precision)
-            ok = split(h, 0)
+            ok = (keep == nh or eng.plan_set_truncation(h, keep)) and split(h, 0)
         if not ok:
             eng.plan_destroy(h)
             return
         self.plan = h
         self.nchunks = K
         self.iter_side = 'out' if forward else 'in'
-        real_step, buf_step = rows * n * precision, rows * nh * 2 * precision
+        real_step, buf_step = rows * n * precision, rows * keep * 2 * precision
         self.step_in, self.step_out = (real_step, buf_step) if forward else (buf_step, real_step)
         # what run() asks of a stage's layouts
         side = type('Side', (), dict(K=K, p=p))()
@@ -202,6 +208,73 @@ class _RealRows:
         if self.plan is not None:
             _lib.engine().plan_destroy(self.plan)
             self.plan = None
+
+
+class _SlabStage:
+    """A MULTI-AXIS first stage inside the pipeline (collapse=True on slab-like grids: the leading serial
+    transform covers every undistributed axis, mpifft.py:299-306; last stage of the backward direction).
+    Its axes include the redistribution's free axis, so the chunks cut the one axis it leaves alone --
+    array axis 0, the axis the redistribution gathers: the stage's own multi-axis plan runs on slab c of
+    its rows into a staging slab, gfft_pack cuts that slab into the per-peer blocks of chunk c of the send
+    buffer ([chunk][peer][rows of the slab][...][block of axis a], the block rule's widths), and chunk c
+    goes on the wire while slab c + 1 is transformed.  Backward: chunk c arrives, gfft_unpack, the inverse
+    plan on slab c.  The stage on the far side transforms axis 0 itself and therefore handles the chunks
+    all at once (_WholeStage with K_in / K_out): the overlap is on this stage's side of the exchange."""
+    def __init__(self, stage, a, p, K, forward, precision):
+        import torch
+        eng = _lib.engine()
+        sin = tuple(int(v) for v in stage.forward.input_array.shape)
+        sout = tuple(int(v) for v in stage.forward.output_array.shape)
+        r = sin[0] // K
+        sub_in, self.sub_out = (r,) + sin[1:], (r,) + sout[1:]
+        real = np.dtype(stage.forward.input_array.dtype).kind == 'f'
+        self.plan = None
+        try:
+            if forward:
+                self.plan = eng.plan_create(sub_in, self.sub_out, stage.axes, _lib.R2C if real else _lib.C2C_FORWARD, precision)
+            else:
+                self.plan = eng.plan_create(self.sub_out, sub_in, stage.axes, _lib.C2R if real else _lib.C2C_BACKWARD, precision)
+        except _lib.GfftError:
+            return
+        self.forward, self.a, self.p = forward, a, p
+        self.isz = 2 * precision
+        self.nchunks = K
+        self.iter_side = 'out' if forward else 'in'
+        n_out = int(np.prod(self.sub_out, dtype=np.int64))
+        self.stage_buf = torch.empty(n_out * self.isz, dtype=torch.uint8, device=stage.forward.output_array.tensor.device)
+        phys_step = int(np.prod(sub_in, dtype=np.int64)) * (precision if real else 2 * precision)
+        buf_step = n_out * self.isz
+        self.step_in, self.step_out = (phys_step, buf_step) if forward else (buf_step, phys_step)
+        side = type('Side', (), dict(K=K, p=p))()
+        natural = type('Side', (), dict(K=1, p=1))()
+        self.lay_in, self.lay_out = (natural, side) if forward else (side, natural)
+
+    def execute(self, eng, c, pin, pout, scale):
+        stg = self.stage_buf.data_ptr()
+        if self.forward:
+            eng.execute_ptr(self.plan, pin + c * self.step_in, stg, scale)
+            eng.pack_ptr(stg, pout + c * self.step_out, self.sub_out, self.a, self.p, self.isz)
+        else:
+            eng.pack_ptr(stg, pin + c * self.step_in, self.sub_out, self.a, self.p, self.isz, unpack=True)
+            eng.execute_ptr(self.plan, stg, pout + c * self.step_out, scale)
+
+    def destroy(self):
+        if self.plan is not None:
+            _lib.engine().plan_destroy(self.plan)
+            self.plan = None
+
+
+def _places(desc, c):
+    """Byte offset of every peer's message of chunk c on one side of an exchange: chunk-major
+    ([chunk][peer], messages back to back) unless the side places them itself (`peer_stride`: the
+    natural array of a stage that transforms the gathered axis, _SlabStage's far side)."""
+    if 'peer_stride' in desc:
+        return [c * desc['chunk_stride'] + j * desc['peer_stride'] for j in range(len(desc['sizes']))]
+    out, off = [], c * desc['chunk']
+    for n in desc['sizes']:
+        out.append(off)
+        off += n
+    return out
 
 
 def _pitch(elems, isz):
@@ -275,6 +348,8 @@ class _Aligned:
         TW, LW = 256 // isz, 128 // isz
         if len(stages) != 3 or [tuple(x.axes) for x in stages] != [(2,), (1,), (0,)]:
             return
+        if any(x._padded for x in stages):
+            return                                                 # (truncating stages keep C-order buffers)
         if not all(hasattr(eng, a) for a in ('plan_set_tiles', 'plan_set_flat')):
             return
         e0, e1 = plan
@@ -500,15 +575,20 @@ class Pipeline:
             return None
         # an r2c transform: real rows along the last axis first, the rest of the chain complex
         real0 = np.dtype(stages[0].forward.input_array.dtype).kind == 'f'
+        if len(stages) == 2 and len(stages[0].axes) == 2:
+            return cls._build_slab(pfft, wires, dtype)
         for k, x in enumerate(stages):
-            if len(x.axes) != 1 or x._padded:
+            # (3/2-rule stages: their truncation / zero padding must be fused into the transform, libfft.FFT)
+            if len(x.axes) != 1 or (x._padded and not getattr(x, '_fused_trunc', False)):
                 return None
             if k == 0 and real0:
                 if x.axes[0] != 2 or np.dtype(x.forward.output_array.dtype) != dtype:
                     return None
                 continue
-            if np.dtype(x.forward.input_array.dtype) != dtype \
-                    or tuple(x.forward.input_array.shape) != tuple(x.forward.output_array.shape):
+            sin, sout = list(x.forward.input_array.shape), list(x.forward.output_array.shape)
+            if x._padded:
+                sin[x.axes[0]] = sout[x.axes[0]] = 0               # shapes differ along the transformed axis only
+            if np.dtype(x.forward.input_array.dtype) != dtype or sin != sout:
                 return None
         nd = 3
         isz = dtype.itemsize
@@ -581,15 +661,17 @@ class Pipeline:
                 lay_in.append(Layout(shape, ax, e['p'], e['f'], e['K']))
             else:
                 lay_in.append(Layout(shape))
+            oshape = tuple(x.forward.output_array.shape)         # (a truncating stage's output is shorter)
             if i < L - 1 and plan[i]['p'] > 1 and not plan[i]['uneven'] and al is None:
                 e = plan[i]
-                lay_out.append(Layout(shape, ax, e['p'], e['f'], e['K']))
+                lay_out.append(Layout(oshape, ax, e['p'], e['f'], e['K']))
             else:
-                lay_out.append(Layout(shape))            # (uneven: described by _RealRows / e['A'])
+                lay_out.append(Layout(oshape))           # (uneven: described by _RealRows / e['A'])
 
         def cstage(i, x, kind):
             li, lo = (lay_in[i], lay_out[i]) if kind < 0 else (lay_out[i], lay_in[i])
-            return _Stage(tuple(x.forward.input_array.shape), x.axes[0], li, lo, kind, self.precision)
+            keep = int(x.forward.output_array.shape[x.axes[0]]) if x._padded else 0
+            return _Stage(tuple(x.forward.input_array.shape), x.axes[0], li, lo, kind, self.precision, keep)
         if al is not None:
             # stages next to a LOCAL redistribution keep natural layouts on that side (built above as such)
             self.fwd = [al.fwd[i] if al.fwd[i] is not None else
@@ -603,8 +685,9 @@ class Pipeline:
             self.bwd = [cstage(i, x, +1) for i, x in enumerate(stages) if not (real0 and i == 0)]
             if real0 and plan[0]['p'] > 1:
                 shape0 = tuple(stages[0].forward.input_array.shape)
-                self.fwd.insert(0, _RealRows(shape0, plan[0]['p'], plan[0]['K'], True, self.precision))
-                self.bwd.insert(0, _RealRows(shape0, plan[0]['p'], plan[0]['K'], False, self.precision))
+                keep0 = int(stages[0].forward.output_array.shape[2]) if stages[0]._padded else 0
+                self.fwd.insert(0, _RealRows(shape0, plan[0]['p'], plan[0]['K'], True, self.precision, 0, keep0))
+                self.bwd.insert(0, _RealRows(shape0, plan[0]['p'], plan[0]['K'], False, self.precision, 0, keep0))
             elif real0:
                 # local first redistribution (slab-like grids): the real stage keeps its natural plan
                 self.fwd.insert(0, _WholeStage(stages[0].fwd._plan))
@@ -640,6 +723,62 @@ class Pipeline:
         self._want_relays = str(exchange).lower() in ('relay', '1', 'on')
         return self
 
+    @classmethod
+    def _build_slab(cls, pfft, wires, dtype):
+        """collapse=True on a slab-like grid: [2-axis serial transform] -> redistribution over all ranks ->
+        [axis 0] (mpifft.py:299-306).  See _SlabStage."""
+        stages, (t,) = pfft.xfftn, pfft.transfer
+        eng = _lib.engine()
+        s0, s1 = stages
+        if (not hasattr(eng, 'pack_ptr') or tuple(s1.axes) != (0,) or 0 in s0.axes or s0._padded or s1._padded
+                or tuple(s1.forward.input_array.shape) != tuple(s1.forward.output_array.shape)
+                or np.dtype(s0.forward.output_array.dtype) != dtype):
+            return None
+        p, a = t.comm.Get_size(), t.axisA
+        by_ranks = {tuple(c._ranks): w for c, w in zip(pfft.subcomm, wires) if w is not None}
+        wire = by_ranks.get(tuple(t.comm._ranks)) if p > 1 else None
+        if wire is None or wire.size != p or t.axisB != 0 or a != s0.axes[-1] or a == 0:
+            return None
+        if not wire.owns_stream and not hasattr(wire, 'exchange_placed'):
+            return None
+        sout0 = tuple(int(v) for v in s0.forward.output_array.shape)
+        sh1 = tuple(int(v) for v in s1.forward.input_array.shape)
+        N0l = sout0[0]
+        if sh1[0] != p * N0l:
+            return None                                     # axis 0 splits evenly: every rank cuts the same slabs
+        widths = [_blockdist(t.shape[a], p, r)[0] for r in range(p)]
+        w_me = sh1[a]
+        isz = dtype.itemsize
+        other = int(np.prod([sout0[d] for d in range(3) if d not in (0, a)], dtype=np.int64))
+        nbytes = N0l * other * max(widths) * isz
+        K = 1
+        for k in range(min(cls.CHUNKS, N0l), 1, -1):
+            if N0l % k == 0 and nbytes // k >= cls.MIN_CHUNK_BYTES:
+                K = k
+                break
+        self = cls()
+        self.pfft, self.dtype, self.isz = pfft, dtype, isz
+        self.precision = _lib.precision_of(dtype)
+        self.layout = 'c-order'
+        r = N0l // K
+        e = dict(p=p, wire=wire, f=0, K=K, a=a, b=0, comm=t.comm, uneven=False, widths=None, no_relay=True)
+        e['A'] = dict(chunk=r * other * sum(widths) * isz, sizes=[r * other * w * isz for w in widths])
+        e['B'] = dict(sizes=[r * other * w_me * isz] * p, chunk_stride=r * other * w_me * isz,
+                      peer_stride=N0l * other * w_me * isz)
+        self.tplan = [e]
+        self.out_buf = [x.forward.output_array.tensor for x in stages]
+        self.in_buf = [x.forward.input_array.tensor for x in stages]
+        self.fwd = [_SlabStage(s0, a, p, K, True, self.precision), _WholeStage(s1.fwd._plan, K_in=K)]
+        self.bwd = [_SlabStage(s0, a, p, K, False, self.precision), _WholeStage(s1.bck._plan, K_out=K)]
+        if any(st.plan is None for st in self.fwd + self.bwd):
+            self.destroy()
+            return None
+        self.M = [x.M for x in stages]
+        self.comm_stream = _streams()[1]
+        self._events, self._works = {}, {}
+        self._want_relays = False
+        return self
+
     def signature(self):
         """What every rank of the grid must have decided alike for the exchanges to pair up."""
         return (self.layout, tuple((e['p'], e.get('K', 1), e.get('f')) for e in self.tplan))
@@ -665,7 +804,7 @@ class Pipeline:
         pwire = None
         scalar = self.isz // 2
         for i, e in enumerate(self.tplan):
-            if e['p'] == 1 or _relay.policy(e['p'], W, 'nccl', 'auto') == 'off':
+            if e['p'] == 1 or e.get('no_relay') or _relay.policy(e['p'], W, 'nccl', 'auto') == 'off':
                 continue
             g = next(k for k, c in enumerate(pfft.subcomm) if c.Get_size() > 1 and tuple(c._ranks) == tuple(e['comm']._ranks))
             if pwire is None:
@@ -783,13 +922,17 @@ class Pipeline:
         j = i + 1 if forward else i - 1                       # the receiving stage
         recv_t = self.in_buf[j] if forward else self.out_buf[j]
         snd, rcv = (t['A'], t['B']) if forward else (t['B'], t['A'])
-        soff, roff = c * snd['chunk'], c * rcv['chunk']
+        splace, rplace = _places(snd, c), _places(rcv, c)
+        soff, roff = splace[0], rplace[0]
         wire = t['wire']
         K = t['K']
         if not wire.owns_stream:
             # torch.distributed orders the collective after the current (compute) stream by itself
             send_t = self.out_buf[i] if forward else self.in_buf[i]
-            self._works[(tag, pos, c)] = wire.exchange_chunk(_bytes(send_t), soff, snd['sizes'], _bytes(recv_t), roff, rcv['sizes'])
+            if 'peer_stride' in snd or 'peer_stride' in rcv:
+                self._works[(tag, pos, c)] = wire.exchange_placed(_bytes(send_t), splace, snd['sizes'], _bytes(recv_t), rplace, rcv['sizes'])
+            else:
+                self._works[(tag, pos, c)] = wire.exchange_chunk(_bytes(send_t), soff, snd['sizes'], _bytes(recv_t), roff, rcv['sizes'])
             return
         if record:
             ev = self._event((tag, 'k', pos, c))
@@ -798,12 +941,10 @@ class Pipeline:
         recv = recv_t.data_ptr()
         rl = t.get('relay')
         if rl is None:
-            sends, recvs, so, ro = [], [], soff, roff
+            sends, recvs = [], []
             for peer in range(t['p']):
-                sends.append((send_ptr + so, snd['sizes'][peer], peer))
-                recvs.append((recv + ro, rcv['sizes'][peer], peer))
-                so += snd['sizes'][peer]
-                ro += rcv['sizes'][peer]
+                sends.append((send_ptr + splace[peer], snd['sizes'][peer], peer))
+                recvs.append((recv + rplace[peer], rcv['sizes'][peer], peer))
             wire.sendrecv(sends, recvs, cs_raw)
             self._event((tag, 'x', pos, c)).record(cs)
             return

@@ -75,8 +75,10 @@ class HostEngine:
     # chunked pipeline (pipeline.py) drives; host memory here, so that its layouts, chunk offsets and
     # exchange plans can be checked over gloo without a GPU
     def plan_create_guru(self, precision, kind, dim, howmany, in_blocks=1, in_block_stride=0, out_blocks=1,
-                         out_block_stride=0):
+                         out_block_stride=0, n_keep=0):
         n = int(dim[0])
+        if n_keep and n_keep != n:                              # (fused truncation: GPU engine only)
+            return None
         if n & (n - 1) or n < 16 or len(howmany) > 3:          # acceptance of the register kernels, roughly
             return None
         for nb in (in_blocks, out_blocks):

@@ -130,7 +130,7 @@ def test_transforms_that_do_not_qualify_keep_the_staged_path(monkeypatch):
     def body(comm):
         out = []
         for shape, dt, kw in (((64, 64, 66), 'd', {}), ((48, 64, 60), 'D', {}),
-                              ((64, 64, 64), 'D', dict(padding=[1.5, 1.5, 1.5])), ((32, 32), 'D', {})):
+                              ((60, 64, 64), 'D', dict(padding=[1.5, 1.5, 1.5])), ((32, 32), 'D', {})):
             f = PFFT(comm, shape, dtype=dt, wire='native', **kw)
             out.append(f.pipeline is None)
             f.destroy()
@@ -285,6 +285,120 @@ def test_pipelined_r2c_transform(P, shape, dt, exchange, monkeypatch):
         if exchange == 'relay' and P > 2:
             assert any(e['route'] == 'relay' for e in info), info
         assert np.array_equal(a, b) and np.array_equal(a, c), (P, shape, dt, r)
+        assert np.array_equal(ab, bb) and np.array_equal(ab, bc)
+        assert np.abs(a - want[r]).max() <= cases.tol_for(dt) * np.abs(want[r]).max()
+
+
+@pytest.mark.parametrize('P,shape,pad', [
+    (4, (64, 64, 64), [1.5, 1.5, 1.5]),            # padded lengths 96 = 3 * 32: the R = 12 / 24 kernels
+    (8, (64, 64, 64), [1.5, 1.5, 1.5]),
+    (8, (128, 64, 256), [1.5, 1.5, 1.5]),
+    (4, (64, 128, 64), [1.5, 1.0, 1.5]),           # a plain stage between two truncating ones
+    (8, (64, 64, 128), [2.0, 2.0, 2.0]),           # power-of-two padded lengths
+    (2, (64, 64, 64), [1.5, 1.5, 1.5]),
+])
+@pytest.mark.parametrize('dt', ['D', 'F', 'd', 'f'])
+def test_pipelined_padded_transform(P, shape, pad, dt, monkeypatch):
+    """padding= (3/2-rule, mpifft.py:247-257, libfft.py:263-311) through the pipeline: every stage's
+    truncating store (forward) / zero-padding load (backward) is fused into its guru plan
+    (gfft_plan_create_guru_padded), the truncated side being the exchange buffer -- equal blocks of the
+    kept entries, or, behind the real first stage, the block rule's uneven blocks of the kept half
+    spectrum.  Same bits as the staged path, which now fuses its pack / unpack sides on padded axes too
+    (PFFT._fuse_packs), and as the staged path with pack / unpack kernels; within tolerance of the oracle."""
+    from mpi4py_fft_amd import PFFT, newDistArray, pipeline
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_CHUNK_BYTES', 0)
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_WIDTH', 4)
+    pshape = tuple(int(np.floor(n * f)) for n, f in zip(shape, pad))
+    G = O.rng_array(pshape, dt, 31)
+
+    def body(comm):
+        kernels = PFFT(comm, shape, dtype=dt, padding=list(pad), wire='torch', exchange='direct', fuse_pack=False)
+        staged = PFFT(comm, shape, dtype=dt, padding=list(pad), wire='torch', exchange='direct')
+        piped = PFFT(comm, shape, dtype=dt, padding=list(pad), wire='native', exchange='direct')
+        assert kernels.pipeline is None and staged.pipeline is None and piped.pipeline is not None
+        fused = [(t.packedA, t.packedB) for t in staged.transfer if t.comm.Get_size() > 1]
+        info = piped.pipeline.describe()
+        u = newDistArray(staged, False)
+        assert tuple(u.global_shape) == pshape
+        u[...] = G[staged.local_slice(False)]
+        k = np.asarray(kernels.forward(u)).copy()
+        a = np.asarray(staged.forward(u)).copy()
+        b = np.asarray(piped.forward(u)).copy()
+        out = newDistArray(piped, True)
+        piped.forward(u, out)
+        c = np.asarray(out).copy()
+        kb = np.asarray(kernels.backward()).copy()
+        ab = np.asarray(staged.backward()).copy()
+        bb = np.asarray(piped.backward()).copy()
+        back = newDistArray(piped, False)
+        piped.backward(out, back)
+        bc = np.asarray(back).copy()
+        for f in (kernels, staged, piped):
+            f.destroy()
+        return k, a, b, c, kb, ab, bb, bc, info, fused
+    res = cases.run_ranks(P, body)
+    ref = O.OPFFT(P, shape, dtype=dt, padding=list(pad))
+    want = ref.forward(ref.scatter(G))
+    for r, (k, a, b, c, kb, ab, bb, bc, info, fused) in enumerate(res):
+        assert any(e['chunks'] > 1 for e in info), info
+        assert all(fa and fb for fa, fb in fused), fused          # no pack / unpack kernel left on padded axes
+        assert np.array_equal(a, b) and np.array_equal(a, c), (P, shape, pad, dt, r)
+        assert np.array_equal(ab, bb) and np.array_equal(ab, bc)
+        # (pack / unpack kernels instead of fused sides: other instantiations of the transform kernels,
+        # whose multiply-adds the compiler may contract differently -- last-bit agreement)
+        eps = 1e-13 if dt in 'dD' else 1e-5
+        assert np.abs(k - a).max() <= eps * np.abs(a).max() and np.abs(kb - ab).max() <= eps * np.abs(ab).max()
+        assert np.abs(a - want[r]).max() <= cases.tol_for(dt) * np.abs(want[r]).max()
+
+
+@pytest.mark.parametrize('P,shape,kw', [
+    (4, (64, 64, 64), dict(grid=(-1,), collapse=True)),          # slab: stages [(1, 2) as one 2-D transform] -> [0]
+    (8, (64, 48, 64), dict(grid=(-1,), collapse=True)),
+    (8, (128, 64, 256), dict(grid=(-1,), collapse=True)),
+    (4, (64, 36, 50), dict(grid=(-1,), collapse=True)),          # lengths without register kernels, uneven blocks
+    (4, (64, 64, 64), dict(collapse=True)),                      # pencil grid: nothing collapses, the plain chain
+    (8, (64, 64, 128), dict(collapse=True)),
+])
+@pytest.mark.parametrize('dt', ['D', 'd', 'f'])
+def test_pipelined_collapsed_transform(P, shape, kw, dt, monkeypatch):
+    """collapse=True (mpifft.py:299-306) through the pipeline.  On slab grids the leading serial transform
+    covers both undistributed axes, the redistribution's free axis among them: the stage then runs slab by
+    slab along array axis 0 and chunk c of the exchange leaves while slab c + 1 is transformed
+    (pipeline._SlabStage).  Same bits as the staged path, within tolerance of the oracle."""
+    from mpi4py_fft_amd import PFFT, newDistArray, pipeline
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_CHUNK_BYTES', 0)
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_WIDTH', 4)
+    G = O.rng_array(shape, dt, 41)
+
+    def body(comm):
+        staged = PFFT(comm, shape, dtype=dt, wire='torch', exchange='direct', **kw)
+        piped = PFFT(comm, shape, dtype=dt, wire='native', exchange='direct', **kw)
+        assert staged.pipeline is None and piped.pipeline is not None
+        info, axes = piped.pipeline.describe(), piped.axes
+        u = newDistArray(staged, False)
+        u[...] = G[staged.local_slice(False)]
+        a = np.asarray(staged.forward(u)).copy()
+        b = np.asarray(piped.forward(u)).copy()
+        out = newDistArray(piped, True)
+        piped.forward(u, out)
+        c = np.asarray(out).copy()
+        ab = np.asarray(staged.backward()).copy()
+        bb = np.asarray(piped.backward()).copy()
+        back = newDistArray(piped, False)
+        piped.backward(out, back)
+        bc = np.asarray(back).copy()
+        b2 = np.asarray(piped.forward(u)).copy()
+        staged.destroy()
+        piped.destroy()
+        return a, b, c, ab, bb, bc, b2, info, axes
+    res = cases.run_ranks(P, body)
+    ref = O.OPFFT(P, shape, dtype=dt, **kw)
+    want = ref.forward(ref.scatter(G))
+    for r, (a, b, c, ab, bb, bc, b2, info, axes) in enumerate(res):
+        assert any(e['chunks'] > 1 for e in info), info
+        if 'grid' in kw:
+            assert len(axes) == 2 and tuple(axes[1]) == (1, 2), axes
+        assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, b2), (P, shape, kw, dt, r)
         assert np.array_equal(ab, bb) and np.array_equal(ab, bc)
         assert np.abs(a - want[r]).max() <= cases.tol_for(dt) * np.abs(want[r]).max()
 

@@ -472,8 +472,11 @@ def test_packed_real_rows_address_uneven_exchange_blocks(n, dt):
         eng.pack(want.tensor, packed_want.tensor, (6, 5, nh), 2, p, np.dtype(cdt).itemsize)
         plan = fftw.rfftn(a, axes=(2,), output_array=zeros((6, 5, nh), cdt))
         assert plan.set_split(1, p)
-        got = plan.execute_scaled(a, plan.output_array, 0.25)
-        assert np.array_equal(np.asarray(got), np.asarray(packed_want)), (n, dt, p, 'r2c store')
+        got = np.asarray(plan.execute_scaled(a, plan.output_array, 0.25))
+        # (two instantiations of the kernel -- natural and uneven-block store --: the compiler may contract
+        # multiply-adds differently, so values agree to the last bit or two, positions exactly)
+        pw = np.asarray(packed_want)
+        assert np.abs(got - pw).max() <= (1e-14 if dt == 'd' else 1e-6) * np.abs(pw).max(), (n, dt, p, 'r2c store')
         plan.destroy()
         # c2r reading the same buffer gives what it gives on the natural half spectrum
         back_nat = fftw.irfftn(want, s=(n,), axes=(2,), output_array=zeros(shape, dt))
