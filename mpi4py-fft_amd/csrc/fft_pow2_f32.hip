@@ -2,6 +2,11 @@
 // reference, setup.py:93-111).  A complex64 is 8 bytes, so R = 16 costs the registers R = 8
 // costs in fp64, and 16 adjacent columns make the 128-byte segment.
 #include "fft_pow2_impl.h"
+#ifdef GFFT_VARIANTS
+#define GFFT_HAS_VARIANTS 1
+#else
+#define GFFT_HAS_VARIANTS 0
+#endif
 
 namespace gfft {
 
@@ -36,7 +41,7 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 2048: return P32F(2048, 16, 8, true, true, 4, 32, 16, 16, 8);
       case 4096: return P32F(4096, 16, 4, true, true, 4, 32, 16, 16, 16);
     }
-  } else if (d.mode == MODE_C2C && d.tr_dir && !d.tw_hi && (d.n == 512 || (variant == 7 && d.n >= 1024))) {
+  } else if (d.mode == MODE_C2C && d.tr_dir && !d.tw_hi && (d.n == 512 || (GFFT_HAS_VARIANTS && variant == 7 && d.n >= 1024))) {
     // complex strided passes with fused truncation (store side) / zero padding (load side) on the
     // 256-byte tiles of the plain passes below.  n = 512 compiles clean (100 / 82 VGPRs).  From
     // n = 1024 the R = 32 plans fit 128 VGPRs only with 9-16 registers of scratch (145 before the
@@ -48,9 +53,11 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
                  : launch_pow2_one<float, N, R, T, true, true, 1, 16 | 64, MODE_C2C, false, __VA_ARGS__>(d, in, out, s))
     switch (d.n) {
       case 512: return P32T(512, 16, 32, 16, 8, 4);
+#ifdef GFFT_VARIANTS   // (variant 7 only: measured slower, see above)
       case 1024: return P32T(1024, 32, 32, 16, 16, 4);
       case 2048: return P32T(2048, 32, 16, 16, 16, 8);
       case 4096: return P32T(4096, 32, 8, 16, 16, 16);
+#endif
     }
 #undef P32T
   } else if (d.mode != MODE_C2C || d.tw_hi || d.tr_dir || d.out_es == 1 || d.in_es == 1) {
@@ -90,12 +97,16 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 256:
         switch (variant) {
           default: return P32F(256, 8, 32, true, false, 1, 8, 8, 8, 4);
+#ifdef GFFT_VARIANTS
           case 1: return P32(256, 16, 16, true, false, 1, 16, 16);
+#endif
         }
       case 512:
         switch (variant) {
           default: return P32F(512, 16, 32, true, true, 1, 8, 16, 8, 4);
+#ifdef GFFT_VARIANTS
           case 1: return P32(512, 8, 16, true, true, 1, 8, 8, 8);
+#endif
           case 2: return P32F(512, 16, 16, true, true, 4, 8, 16, 8, 4);           // A/B as for n = 1024: 0.95 / 1.26 ms against 0.91 / 1.04
         }
       // n >= 1024: R = 32 elements per thread (the 64 data VGPRs R = 16 costs in fp64) doubles the
@@ -105,8 +116,10 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 1024:
         switch (variant) {
           default: return P32F(1024, 32, 32, true, true, 1, 8, 16, 16, 4);
+#ifdef GFFT_VARIANTS
           case 1: return P32(1024, 16, 16, true, true, 1, 16, 16, 4);
           case 8: return P32F(1024, 32, 32, true, true, 1, 8 | 256, 16, 16, 4);   // A/B: line not pinned before the stores
+#endif
           // A/B: two 512-thread workgroups per CU (one computes while the other loads) on 128-byte
           // segments: 1024^3 c64 axis 1 3.60 ms (default 3.58), axis 0 5.38 (4.43) -- segment width wins.
           // Re-measured after the 4-byte LDS bank rule (tools/variant_probe_f32.py; this variant's T = 16
@@ -114,20 +127,26 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
           // natural rows near 3.50 (3.53) / far 4.94 (4.15) -- ahead by 2-4 % only where both sides are
           // pitched, behind by 19 % on natural far strides: still not the default.
           case 2: return P32F(1024, 32, 16, true, true, 4, 8, 16, 16, 4);
+#ifdef GFFT_VARIANTS
           // A/B: two radix-32 stages = ONE exchange instead of two (LDS cycles and barriers halved), but the
           // 32-point butterfly with its 31 stage twiddles does not fit 128 VGPRs at 1024 threads
           // (116 B of scratch per lane): pitched near 4.33 ms against 3.61, far 5.18 against 4.02
           case 3: return P32F(1024, 32, 32, true, true, 1, 8, 32, 32);
+#endif
         }
       case 2048:
         switch (variant) {
           default: return P32F(2048, 32, 16, true, true, 1, 8, 16, 16, 8);
+#ifdef GFFT_VARIANTS
           case 1: return P32(2048, 16, 8, true, true, 4, 16, 16, 8);
+#endif
         }
       case 4096:
         switch (variant) {
           default: return P32F(4096, 32, 8, true, true, 1, 8, 16, 16, 16);
+#ifdef GFFT_VARIANTS
           case 1: return P32(4096, 16, 4, true, true, 4, 16, 16, 16);
+#endif
         }
     }
   }

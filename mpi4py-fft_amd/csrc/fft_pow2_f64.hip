@@ -32,14 +32,16 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
         if (d.tr_dir && variant == 0) return P64(1024, 8, 2, false, 1, 8, 8, 8, 2);
         switch (variant) {
           default: return P64(1024, 16, 4, false, 1, 16, 16, 4);   // 4 rows / 256 threads, 2 exchanges
+#ifdef GFFT_VARIANTS   // measured alternatives (make VARIANTS=1): not in the shipped library
           case 1: return P64(1024, 8, 1, false, 1, 8, 8, 8, 2);
           case 2: return P64(1024, 16, 1, false, 1, 16, 16, 4);
-          case 3: return P64(1024, 8, 2, false, 1, 8, 8, 8, 2);
           case 4: return P64F(1024, 8, 2, false, 1, 3, 8, 8, 8, 2);      // nt loads+stores
           case 5: return P64F(1024, 8, 2, false, 1, 4, 8, 8, 8, 2);      // access pattern only
           case 6: return P64F(1024, 8, 2, false, 1, 7, 8, 8, 8, 2);      // access pattern, nt
           case 7: return P64F(1024, 8, 2, false, 1, 1, 8, 8, 8, 2);      // nt loads
           case 8: return P64F(1024, 8, 2, false, 1, 2, 8, 8, 8, 2);      // nt stores
+#endif
+          case 3: return P64(1024, 8, 2, false, 1, 8, 8, 8, 2);   // (= the lean plan the fused truncation / padding uses: no extra kernels)
         }
       case 2048: return P64(2048, 16, 2, false, 1, 16, 16, 8);
       case 4096: return P64(4096, 16, 1, false, 1, 16, 16, 16);
@@ -94,11 +96,14 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
       case 512:
         switch (variant) {
           default: return P64F(512, 8, 16, true, 1, 8, 8, 8, 8);
+#ifdef GFFT_VARIANTS
           case 1: return P64F(512, 8, 8, true, 1, 8, 8, 8, 8);
+#endif
         }
       case 1024:
         switch (variant) {
           default: return P64F(1024, 16, 16, true, 4, 8, 16, 16, 4);  // 256-B segments, 1024 threads, <=128 VGPRs
+#ifdef GFFT_VARIANTS
           case 1: return P64F(1024, 8, 8, true, 1, 8, 8, 8, 8, 2);    // 128-B segments, 1024 threads, 86 VGPRs
           case 2: return P64F(1024, 16, 8, true, 1, 8, 16, 16, 4);    // 512 threads, ~134 VGPRs: 1 tile/CU
           case 3: return P64F(1024, 16, 8, true, 4, 8, 16, 16, 4);    // capped at 128 VGPRs: 2 tiles/CU
@@ -109,6 +114,7 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
           case 12: return P64F(1024, 16, 16, true, 4, 8, 8, 8, 8, 2);
           case 13: return P64F(1024, 16, 16, true, 4, 8 | 2, 16, 16, 4);   // non-temporal stores
           case 14: return P64F(1024, 16, 16, true, 4, 8 | 3, 16, 16, 4);   // non-temporal loads and stores
+#endif
         }
       case 2048: return P64F(2048, 16, 8, true, 4, 8, 16, 16, 8);
       case 4096: return P64F(4096, 16, 4, true, 4, 8, 16, 16, 16);

@@ -1111,8 +1111,26 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
 // packed-real row plans (fft_real_*.hip): plain, with the truncating store (forward, 3/2-rule) or
 // with the zero-padding load (backward), by d.tr_dir
 template <typename real, int MODE, int N, int R, int T, bool SPLIT, int... RADS>
+hipError_t half_launch_all(const PassDesc &d, const void *in, void *out, hipStream_t s);
+#ifdef GFFT_VARIANTS
+constexpr bool kFusedPadMix5 = true;
+#else
+constexpr bool kFusedPadMix5 = false;     // make VARIANTS=1 builds them (plan.cpp fused_pad_ok mirrors this)
+#endif
+template <typename real, int MODE, int N, int R, int T, bool SPLIT, int... RADS>
 hipError_t half_launch(const PassDesc &d, const void *in, void *out, hipStream_t s) {
   static_assert(MODE == MODE_R2C_H || MODE == MODE_C2R_H, "packed-real modes");
+  if constexpr (R == 20 && !kFusedPadMix5) {
+    // 5^c 2^k lengths: plain and uneven-block kernels only
+    if (d.tr_dir) return hipErrorInvalidValue;
+    if (d.ub_p > 1) return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 128, MODE, false, RADS...>(d, in, out, s);
+    return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 0, MODE, false, RADS...>(d, in, out, s);
+  } else {
+    return half_launch_all<real, MODE, N, R, T, SPLIT, RADS...>(d, in, out, s);
+  }
+}
+template <typename real, int MODE, int N, int R, int T, bool SPLIT, int... RADS>
+hipError_t half_launch_all(const PassDesc &d, const void *in, void *out, hipStream_t s) {
   if (d.ub_p > 1 && d.tr_dir == 0)
     return launch_pow2_one<real, N, R, T, false, SPLIT, 1, 128, MODE, false, RADS...>(d, in, out, s);
   if (d.ub_p > 1) {
@@ -1134,8 +1152,17 @@ hipError_t half_launch(const PassDesc &d, const void *in, void *out, hipStream_t
 }
 
 // runtime (mode, four-step twiddle) -> instantiation
-template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int... RADS>
+// TABLE_FLAGS = kernel FLAGS, plus 512: this table entry is never picked for a four-step pass (the
+// caller's condition excludes d.tw_hi), so its four-step-twiddle kernel is not instantiated; plus 1024: no
+// fused truncation / zero-padding kernels for this entry (plan.cpp fused_pad_ok keeps such plans on the
+// separate gfft_truncate / gfft_pad kernels)
+template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int TABLE_FLAGS, int... RADS>
 hipError_t launch_pow2_inst(const PassDesc &d, const void *in, void *out, hipStream_t s) {
+  constexpr int FLAGS = TABLE_FLAGS & ~(512 | 1024);
+  constexpr bool BIG_OK = COLS && !(TABLE_FLAGS & 512);     // (four-step passes always run strided, plan.cpp plan_fourstep)
+  if constexpr ((TABLE_FLAGS & 1024) != 0) {
+    if (d.tr_dir) return hipErrorInvalidValue;
+  }
   // FLAGS & 8: complex-to-complex, no four-step twiddle (fewer instantiations of fat configurations)
   if constexpr ((FLAGS & 32) != 0) {
     // transposing store: complex strided pass, with or without the four-step twiddle
@@ -1147,13 +1174,18 @@ hipError_t launch_pow2_inst(const PassDesc &d, const void *in, void *out, hipStr
     return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, false, RADS...>(d, in, out, s);
   } else {
     if (d.tw_hi) {
-      if (d.mode != MODE_C2C) return hipErrorInvalidValue;
-      return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, true, RADS...>(d, in, out, s);
+      if constexpr (!BIG_OK) return hipErrorInvalidValue;
+      else {
+        if (d.mode != MODE_C2C) return hipErrorInvalidValue;
+        return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, true, RADS...>(d, in, out, s);
+      }
     }
-    if (d.tr_dir == 1 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2C, false, RADS...>(d, in, out, s);
-    if (d.tr_dir == 1 && d.mode == MODE_R2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_R2C, false, RADS...>(d, in, out, s);
-    if (d.tr_dir == 2 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16 | 64, MODE_C2C, false, RADS...>(d, in, out, s);
-    if (d.tr_dir == 2 && d.mode == MODE_C2R) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16 | 64, MODE_C2R, false, RADS...>(d, in, out, s);
+    if constexpr (!(TABLE_FLAGS & 1024)) {
+      if (d.tr_dir == 1 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_C2C, false, RADS...>(d, in, out, s);
+      if (d.tr_dir == 1 && d.mode == MODE_R2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16, MODE_R2C, false, RADS...>(d, in, out, s);
+      if (d.tr_dir == 2 && d.mode == MODE_C2C) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16 | 64, MODE_C2C, false, RADS...>(d, in, out, s);
+      if (d.tr_dir == 2 && d.mode == MODE_C2R) return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, 16 | 64, MODE_C2R, false, RADS...>(d, in, out, s);
+    }
     if (d.tr_dir) return hipErrorInvalidValue;
     switch (d.mode) {
       case MODE_C2C: return launch_pow2_one<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE_C2C, false, RADS...>(d, in, out, s);

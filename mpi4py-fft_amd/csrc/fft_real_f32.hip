@@ -26,20 +26,26 @@ static hipError_t launch_half_f32(const PassDesc &d, int variant, const void *in
         default:
           if (MODE == MODE_C2R_H) return H32(MODE, 512, 8, 4, 8, 8, 8);
           return H32(MODE, 512, 16, 8, 16, 8, 4);
+#ifdef GFFT_VARIANTS
         case 2: return H32(MODE, 512, 8, 8, 8, 8, 8);
         case 3: return H32(MODE, 512, 8, 1, 8, 8, 8);
+#endif
       }
     case 1024:
       switch (variant) {
         default: return H32(MODE, 1024, 16, 1, 16, 16, 4);
+#ifdef GFFT_VARIANTS
         case 2: return H32(MODE, 1024, 16, 4, 16, 16, 4);
         case 3: return H32(MODE, 1024, 8, 4, 8, 8, 8, 2);
+#endif
       }
     case 2048:
       switch (variant) {
         default: return H32(MODE, 2048, 16, 1, 16, 16, 8);
+#ifdef GFFT_VARIANTS
         case 2: return H32(MODE, 2048, 16, 2, 16, 16, 8);
         case 3: return H32(MODE, 2048, 8, 2, 8, 8, 8, 4);
+#endif
       }
     case 4096: return H32(MODE, 4096, 16, 1, 16, 16, 16);
   }

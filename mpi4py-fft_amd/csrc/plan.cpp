@@ -206,6 +206,19 @@ bool regk_ok(int64_t n, int precision) {
   return precision == 8 ? pow2_supported_f64((int)n) : pow2_supported_f32((int)n);
 }
 
+// lengths whose kernels carry the fused 3/2-rule truncation / zero-padding adapters: every register-kernel
+// length except 5^c 2^k, whose adapters only a `make VARIANTS=1` library instantiates (fft_pow2_impl.h
+// TABLE_FLAGS & 1024, kFusedPadMix5) -- plans on those lengths keep the separate gfft_truncate / gfft_pad
+// kernels.  `n_axis`: transformed length of a complex axis, or the COMPLEX length (half) of a packed-real row.
+bool fused_pad_ok(int64_t n_axis) {
+#ifdef GFFT_VARIANTS
+  (void)n_axis;
+  return true;
+#else
+  return !(n_axis <= 4096 && mix5_supported((int)n_axis));
+#endif
+}
+
 bool factorize(int64_t n, Factors *f, int max_prime) {
   f->count = 0;
   auto push = [&](int r) { if (f->count < 24) f->r[f->count++] = r; };
@@ -1244,7 +1257,9 @@ int gfft_plan_create_padded(gfft_plan *plan, const int64_t *padded, const int64_
   // the all-axes schedule needs one register-kernel pass per axis (packed-real rows on a real axis)
   if (!opts().fused3) return fail(GFFT_ERR_UNSUPPORTED, "fused 3-D plans are switched off");
   for (int i = 0; i < 3; ++i)
-    if (!regk_ok(padded[i], precision)) return fail(GFFT_ERR_UNSUPPORTED, "padded length without a single-pass kernel");
+    if (!regk_ok(padded[i], precision) || (kept[i] < (i == 2 && real ? padded[i] / 2 + 1 : padded[i]) &&
+                                           !fused_pad_ok(i == 2 && real ? padded[i] / 2 : padded[i])))
+      return fail(GFFT_ERR_UNSUPPORTED, "padded length without a single-pass kernel");
   if (real && !(opts().real_half && padded[2] % 2 == 0 &&
                 (real_half_supported((int)(padded[2] / 2)) || real_half_mix_supported((int)(padded[2] / 2)))))
     return fail(GFFT_ERR_UNSUPPORTED, "real axis without a packed-real row kernel");
@@ -1435,6 +1450,7 @@ int gfft_plan_set_truncation(gfft_plan pl, int64_t n_keep) {
     const int64_t full_h = (int64_t)p.d.n + 1;
     if (n_keep < 1 || n_keep > full_h) return fail(GFFT_ERR_INVALID, "bad truncated length");
     if (n_keep == full_h) return GFFT_OK;        // nothing to cut: the plain plan is the answer
+    if (!fused_pad_ok(p.d.n)) return fail(GFFT_ERR_UNSUPPORTED, "no fused truncation kernels for this length in this build");
     const bool fwd_h = p.d.mode == MODE_R2C_H;
     const double lines_h = (double)p.d.batch, esz_h = 2.0 * pl->precision;
     if (fwd_h) { p.d.tr_dir = 1; p.d.out_os = n_keep; } else { p.d.tr_dir = 2; p.d.in_os = n_keep; }
@@ -1443,7 +1459,7 @@ int gfft_plan_set_truncation(gfft_plan pl, int64_t n_keep) {
     p.d.tr_even = (n_keep % 2 == 0) ? 1 : 0;
     return GFFT_OK;
   }
-  if (p.kind != PK_FFT || !p.regk || p.d.mid != 1 || p.d.tw_hi)
+  if (p.kind != PK_FFT || !p.regk || p.d.mid != 1 || p.d.tw_hi || !fused_pad_ok(p.d.n))
     return fail(GFFT_ERR_UNSUPPORTED, "truncation fuses into register-kernel passes only");
   const int axis = pl->axes[0];
   const bool fwd = pl->kind == GFFT_C2C_FORWARD || pl->kind == GFFT_R2C;
@@ -1565,6 +1581,7 @@ int gfft_plan_create_guru_padded(gfft_plan *plan, int precision, int kind, const
   const int64_t n = dim->n;
   if (n_keep < 0 || n_keep > n) return fail(GFFT_ERR_INVALID, "bad kept length");
   const bool trunc = n_keep > 0 && n_keep < n;
+  if (trunc && !fused_pad_ok(n)) return fail(GFFT_ERR_UNSUPPORTED, "no fused truncation kernels for this length in this build");
   const int tr_side = kind == GFFT_C2C_FORWARD ? 1 : 0;           // the side that holds the kept entries
   auto blocks_ok = [&](int nb, int side) {
     if (nb < 1 || (nb & (nb - 1))) return false;

