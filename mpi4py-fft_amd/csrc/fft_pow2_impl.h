@@ -738,6 +738,32 @@ __device__ __forceinline__ int64_t uneven_offset(const PassDesc &d, unsigned row
   return d.ub_rows * (int64_t)start + (int64_t)row * width + ee;
 }
 
+template <int T, bool COLS, bool BIGTW>
+__device__ __host__ __forceinline__ unsigned pow2_ntiles(const PassDesc &d) {
+  const unsigned batch = (unsigned)d.batch, inner = (unsigned)d.inner, mid = (unsigned)d.mid;
+  const unsigned flat_cols = mid * inner;
+  if (COLS && !BIGTW) return (d.flat ? batch / flat_cols : batch / inner) * (((d.flat ? flat_cols : inner) + T - 1) / T);
+  return (batch + T - 1) / T;
+}
+
+// Complex values at SYSTEM scope through raw buffer accesses (cache policy sc0 | sc1): element offsets
+// are 32-bit, i.e. the hand-off buffer a tile addresses stays below 4 GiB (one plane of a fused pair)
+struct SysBuf {
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ explicit SysBuf(const void *base)
+      : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000)) {}
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  template <typename real> __device__ __forceinline__ cx<real> ld(int64_t elem) const {
+    if constexpr (sizeof(real) == 8) return __builtin_bit_cast(cx<real>, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)elem * 16u, 0, 17));
+    else return __builtin_bit_cast(cx<real>, __builtin_amdgcn_raw_buffer_load_b64(r, (unsigned)elem * 8u, 0, 17));
+  }
+  template <typename real> __device__ __forceinline__ void st(int64_t elem, cx<real> v) const {
+    if constexpr (sizeof(real) == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (unsigned)elem * 16u, 0, 17);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, (unsigned)elem * 8u, 0, 17);
+  }
+};
+
 // FLAGS: 1 = non-temporal loads, 2 = non-temporal stores, 4 = skip the transform (access-pattern
 // probe), 8 = c2c only, 16 = fused truncation / padding adapters (d.tr_dir: 1 store, 2 load),
 // 32 = transposing store (strided kernels whose OUTPUT is contiguous along the transform axis:
@@ -745,9 +771,15 @@ __device__ __forceinline__ int64_t uneven_offset(const PassDesc &d, unsigned row
 // (backward direction) instead of the truncating STORE (a run-time direction switch inside the load
 // loop serialises the loads), 128 = packed-real rows whose half-spectrum side is an all-to-all buffer
 // of uneven blocks
-template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int MODE, bool BIGTW, int... RADS>
-__global__ void __launch_bounds__(T *(N / R), MINW)
-fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
+// The pass over tiles  xcd_base + k,  k = k_first, k_first + k_step, ... < k_end  (the kernel below walks
+// its share of all tiles; the fused two-pass kernel, fft_fused2_kernel, hands it one tile per ticket).
+// FLAGS & 2048 / 4096: the output / input array is a hand-off buffer between workgroups of ONE launch
+// (fused kernels): stored with / loaded at SYSTEM scope (sc0 sc1: written through to the memory side,
+// never served from a possibly stale L2 line), plain complex accesses only; see fft_fused2_kernel.
+template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int FLAGS, int MODE, bool BIGTW, int... RADS>
+__device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restrict__ in, void *__restrict__ out,
+                                          unsigned char *smem, unsigned k_first, unsigned k_step, unsigned k_end,
+                                          unsigned xcd_base) {
   static_assert(SPLIT || sizeof(real) == 4, "fp64 exchanges split planes");
   constexpr int NT = N / R;
   constexpr int WORD = SPLIT ? sizeof(real) : 2 * sizeof(real);
@@ -756,7 +788,8 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   constexpr bool HALF = MODE == MODE_R2C_H || MODE == MODE_C2R_H;
   constexpr int IOMODE = HALF ? MODE_C2C : MODE;
   static_assert(!HALF || (!COLS && !BIGTW && !(FLAGS & 32)), "packed-real modes: contiguous axis only");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(!(FLAGS & (2048 | 4096)) || (MODE == MODE_C2C && !(FLAGS & 16)), "hand-off buffers: plain complex passes");
+  [[maybe_unused]] const SysBuf sys_in(in), sys_out(out);
   const cx<real> *tw = reinterpret_cast<const cx<real> *>(d.tw);
   const int tid = threadIdx.x;
   const int c = COLS ? (tid % T) : (tid / NT);
@@ -784,16 +817,8 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   const int64_t q_in = (!COLS && d.in_tlg) ? (int64_t)(NT >> d.in_tlg) * d.in_tS : (int64_t)NT * d.in_es;     // uniform steps
   const int64_t q_out = (!COLS && d.out_tlg) ? (int64_t)(NT >> d.out_tlg) * d.out_tS : (int64_t)NT * d.out_es;
 
-  // Tile order.  Plain: tile = block + k*grid (adjacent tiles run at the same time on different
-  // XCDs).  XCD-contiguous (d.swizzle, grid % 8 == 0): blocks are dealt to XCDs round-robin by
-  // the dispatcher (block b -> XCD b % 8), so XCD x walks its own contiguous eighth of the tiles:
-  // neighbouring column chunks then share one L2, which merges their partial cache lines when
-  // rows are not line aligned (e.g. 513-wide half spectra).  Placement only affects speed.
-  const unsigned per_xcd = (ntiles + 7) / 8;
-  const unsigned kstep = d.swizzle ? gridDim.x / 8 : gridDim.x;
-  const unsigned kend = d.swizzle ? per_xcd : ntiles;
-  for (unsigned k = d.swizzle ? blockIdx.x / 8 : blockIdx.x; k < kend; k += kstep) {
-    const unsigned tile = d.swizzle ? (blockIdx.x % 8) * per_xcd + k : k;
+  for (unsigned k = k_first; k < k_end; k += k_step) {
+    const unsigned tile = xcd_base + k;
     if (tile >= ntiles) continue;
     // The thread's row index, laundered once per tile: everything derived from it inside the loop
     // (twiddle-table offsets k*step, LDS slots, mirrored c2r offsets) is loop invariant, and
@@ -865,6 +890,9 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
           else v[q] = tile_load<real, IOMODE, false>(d, in, in0, idx, tl + q * NT, sy_in);
         } else if constexpr (MODE == MODE_C2R_H && (FLAGS & 128) != 0) {
           v[q] = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, o, i, tl + q * NT)];
+        } else if constexpr ((FLAGS & 4096) != 0) {
+          v[q] = sys_in.template ld<real>(idx);
+          v[q].y *= sy_in;
         } else {
           v[q] = tile_load<real, IOMODE, (FLAGS & 1) != 0>(d, in, in0, idx, tl + q * NT, sy_in);
         }
@@ -1016,7 +1044,8 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
                       (int64_t)t2 * d.out_es;
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-          stc<real, false>(reinterpret_cast<cx<real> *>(out) + idx, v[q]);
+          if constexpr ((FLAGS & 2048) != 0) sys_out.template st<real>(idx, v[q]);
+          else stc<real, false>(reinterpret_cast<cx<real> *>(out) + idx, v[q]);
           idx += q_out;
         }
       }
@@ -1040,6 +1069,9 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
           else tile_store<real, IOMODE, false, false>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
         } else if constexpr (MODE == MODE_R2C_H && (FLAGS & 128) != 0) {
           reinterpret_cast<cx<real> *>(out)[uneven_offset(d, row_ub, o, i, tl + q * NT)] = {v[q].x * sx_out, v[q].y * sy_out};
+        } else if constexpr ((FLAGS & 2048) != 0) {
+          static_assert(!(FLAGS & 2048) || !BIGTW || (FLAGS & 32), "hand-off store: no per-element four-step twiddle");
+          sys_out.template st<real>(idx, cx<real>{v[q].x * sx_out, v[q].y * sy_out});
         } else {
           tile_store<real, IOMODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
         }
@@ -1062,6 +1094,165 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
       }
     }
   }
+}
+
+template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int MODE, bool BIGTW, int... RADS>
+__global__ void __launch_bounds__(T *(N / R), MINW)
+fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // Tile order.  Plain: tile = block + k*grid (adjacent tiles run at the same time on different
+  // XCDs).  XCD-contiguous (d.swizzle, grid % 8 == 0): blocks are dealt to XCDs round-robin by
+  // the dispatcher (block b -> XCD b % 8), so XCD x walks its own contiguous eighth of the tiles:
+  // neighbouring column chunks then share one L2, which merges their partial cache lines when
+  // rows are not line aligned (e.g. 513-wide half spectra).  Placement only affects speed.
+  const unsigned ntiles = pow2_ntiles<T, COLS, BIGTW>(d);
+  const unsigned per_xcd = (ntiles + 7) / 8;
+  const unsigned kstep = d.swizzle ? gridDim.x / 8 : gridDim.x;
+  const unsigned kend = d.swizzle ? per_xcd : ntiles;
+  pow2_body<real, N, R, T, COLS, SPLIT, FLAGS, MODE, BIGTW, RADS...>(
+      d, in, out, smem, d.swizzle ? blockIdx.x / 8 : blockIdx.x, kstep, kend, d.swizzle ? (blockIdx.x % 8) * per_xcd : 0u);
+}
+
+// ---- two dependent passes in ONE persistent launch, handed over through the Infinity Cache -----------
+// Two passes A -> B over an array far larger than the 256 MiB Infinity Cache normally cost 4 array-sized
+// HBM transfers (A reads, A writes, B reads, B writes), and running them slab by slab as separate launches
+// loses in launch tails what the cache gives back.  Here both run inside one launch of
+// one workgroup per CU.  The work is cut into PLANES -- a plane is a set of A tiles whose output is exactly
+// the input of a set of B tiles (an i1-plane of a 3-D array for [rows along axis 2] -> [columns along axis
+// 0]; one signal of a four-step transform) -- and A writes plane p into slot p % ring of a small ring buffer
+// (ring x 16 MiB at 1024^2 complex128) that B reads back while it is still in the Infinity Cache: the
+// intermediate array never travels to HBM and back.  Workgroups draw TICKETS from a global counter; the
+// ticket order A(0) .. A(lag-1), B(0), A(lag), B(1), A(lag+1), ... makes every ticket wait only for lower
+// tickets (B(p): all A tiles of plane p stored; A(p): all B tiles of plane p - ring done, the slot is free),
+// so the launch cannot deadlock whatever the number of resident workgroups.
+// Coherence between workgroups on different XCDs (whose L2s are not coherent within a launch) is per access:
+// A stores the hand-off data at system scope (written through the L2), waits for the acknowledgements and
+// only then raises the plane's counter; B spins on the counter with device-scope loads and reads the slot
+// at system scope (FLAGS 2048 / 4096 of pow2_body).  Whole-L2 write-backs / invalidates (what an acquire /
+// release pair compiles to) measured 2x SLOWER than two launches; this form 1.3-1.4x faster on a copy pair
+// (tools/probes/mall_ring_probe.hip, profiles/r03_mall_ring_probe_*.txt).
+// (struct FusedDesc: gfft_internal.h)
+
+template <typename real_, int N, int R, int T, bool COLS, bool SPLIT, int FLAGS, int MODE, bool BIGTW, int... RADS>
+struct PassCfg {
+  typedef real_ real;
+  static constexpr int threads = T * (N / R);
+  static constexpr size_t lds = (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real_) == 4)>::CS * (SPLIT ? sizeof(real_) : 2 * sizeof(real_));
+  static __device__ __forceinline__ void tile(const PassDesc &d, const void *in, void *out, unsigned char *smem, unsigned t) {
+    pow2_body<real_, N, R, T, COLS, SPLIT, FLAGS, MODE, BIGTW, RADS...>(d, in, out, smem, t, 1u, t + 1u, 0u);
+  }
+  static unsigned ntiles(const PassDesc &d) { return pow2_ntiles<T, COLS, BIGTW>(d); }
+};
+
+// (Everything one thread does on behalf of its workgroup -- drawing a ticket, polling a counter, raising
+// one -- sits behind a WAVE-uniform scalar branch, `first lane of this wave is thread 0`, with the lane
+// condition nested inside.  Written as a bare `if (threadIdx.x == 0)` in a loop whose body holds barriers,
+// the compiler's control-flow structurizer is free to make lane 0 LEAVE the loop for its atomic while the
+// other 63 lanes of its wave run on to the next barrier -- they then never see the new ticket: the first
+// version of this kernel hung exactly so, with the barriers of the tile code in the loop.)
+__device__ __forceinline__ bool wave_of_thread0() { return __builtin_amdgcn_readfirstlane(threadIdx.x) == 0; }
+
+__device__ __forceinline__ void fused_wait(const unsigned *flag, unsigned want, unsigned *watchdog, unsigned limit) {
+  if (wave_of_thread0()) {
+    if (threadIdx.x == 0) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > limit) { atomicAdd(watchdog, 1u); break; }     // (never hang a device: wrong results instead)
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// (workgroups of <= 512 threads: two per CU -- one computes while the other loads / stores --, which the
+// register budget must allow: at most 128 VGPRs, i.e. 4 waves per SIMD)
+template <typename A, typename B>
+__global__ void __launch_bounds__(A::threads, A::threads <= 512 ? 4 : 1)
+fft_fused2_kernel(PassDesc dA, PassDesc dB, FusedDesc f, const void *__restrict__ in, void *__restrict__ ring, void *__restrict__ out) {
+  static_assert(A::threads == B::threads, "both passes of a fused pair run on one workgroup shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ unsigned tk[2];          // the ticket being worked on and the next one, drawn a tile ahead
+  unsigned *done_a = f.ctr + 16, *done_b = f.ctr + 16 + f.planes;
+  const unsigned ta = (unsigned)f.tiles_a, tb = (unsigned)f.tiles_b, per_pair = ta + tb;
+  const unsigned head = (unsigned)f.lag * ta, pairs = (unsigned)(f.planes - f.lag);
+  const unsigned total = (unsigned)f.planes * per_pair;
+  // The next ticket is drawn while the current tile is being worked on (the atomic's round trip, ~2 us,
+  // would otherwise sit between two tiles with the CU idle).  A workgroup then holds two tickets, the
+  // lower one in work: the lowest unfinished ticket of the launch is still always in work somewhere, so
+  // the no-deadlock argument stands.
+  if (wave_of_thread0()) {
+    if (threadIdx.x == 0) tk[0] = atomicAdd(&f.ctr[0], 1u);
+  }
+  for (unsigned it = 0;; ++it) {
+    __syncthreads();
+    const unsigned k = __builtin_amdgcn_readfirstlane(tk[it & 1]);
+    if (k >= total) break;
+    if (wave_of_thread0()) {
+      if (threadIdx.x == 0) tk[(it + 1) & 1] = atomicAdd(&f.ctr[0], 1u);
+    }
+    bool is_a;
+    unsigned p, t;
+    if (k < head) {
+      is_a = true; p = k / ta; t = k - p * ta;
+    } else {
+      const unsigned k2 = k - head;
+      if (k2 < pairs * per_pair) {
+        const unsigned j = k2 / per_pair, r = k2 - j * per_pair;
+        if (r < tb) { is_a = false; p = j; t = r; } else { is_a = true; p = j + (unsigned)f.lag; t = r - tb; }
+      } else {
+        const unsigned k3 = k2 - pairs * per_pair, j = k3 / tb;
+        is_a = false; p = pairs + j; t = k3 - j * tb;
+      }
+    }
+    char *slot = static_cast<char *>(ring) + (size_t)(p % (unsigned)f.ring) * f.slot_bytes;
+    if (f.debug == 2) continue;
+    if (is_a) {
+      if (p >= (unsigned)f.ring) fused_wait(&done_b[p - f.ring], tb, &f.ctr[1], f.spin_limit);
+      if (f.debug != 3 && f.debug != 5) A::tile(dA, static_cast<const char *>(in) + (size_t)p * f.a_in_plane, slot, smem, t);
+      __builtin_amdgcn_s_waitcnt(0);         // every write-through store of this wave acknowledged ...
+      __syncthreads();                       // ... of every wave of the tile
+      if (wave_of_thread0()) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&done_a[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      fused_wait(&done_a[p], ta, &f.ctr[1], f.spin_limit);
+      if (f.debug != 3 && f.debug != 4) B::tile(dB, slot, static_cast<char *>(out) + (size_t)p * f.b_out_plane, smem, t);
+      __syncthreads();
+      if (wave_of_thread0()) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&done_b[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+template <typename A, typename B>
+hipError_t launch_fused2(const PassDesc &dA, const PassDesc &dB, const FusedDesc &f, const void *in, void *ring, void *out,
+                         hipStream_t s) {
+  constexpr size_t lds = A::lds > B::lds ? A::lds : B::lds;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  if (f.lag < 1 || f.ring <= f.lag || f.planes < 1 || f.tiles_a != (int)A::ntiles(dA) || f.tiles_b != (int)B::ntiles(dB))
+    return hipErrorInvalidValue;
+  auto kern = fft_fused2_kernel<A, B>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+      cus = 256;
+  }
+  hipError_t e = hipMemsetAsync(f.ctr, 0, (size_t)(16 + 2 * f.planes) * sizeof(unsigned), s);
+  if (e != hipSuccess) return e;
+  // as many workgroups as fit the CUs at once (the exchange tile of a 1024-thread workgroup fills the LDS,
+  // two 512-thread ones share it): persistent, tickets do the load balancing
+  const int per_cu = (A::threads <= 512 && 2 * lds + 1024 <= 160 * 1024) ? 2 : 1;
+  hipLaunchKernelGGL(kern, dim3(cus * per_cu), dim3(A::threads), lds, s, dA, dB, f, in, ring, out);
+  return hipGetLastError();
 }
 
 // ---- launch helpers ------------------------------------------------------------------------

@@ -150,6 +150,23 @@ bool pow2_r2r_supported(int n);
 hipError_t launch_pow2_r2r_f64(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
 hipError_t launch_pow2_r2r_f32(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
 int pow2_grid_cap();
+// two dependent fp64 passes fused into one persistent launch (fft_fused_f64.hip; fft_pow2_impl.h
+// fft_fused2_kernel).  kind: FUSED_ROWS_COLS = [rows, n] -> [strided, n], FUSED_COLS_ROWS the reverse,
+// FUSED_FOURSTEP = the two passes of a four-step transform of length n * n
+struct FusedDesc {
+  int planes, tiles_a, tiles_b, ring, lag;
+  int64_t a_in_plane, b_out_plane;   // BYTES from one plane to the next on A's input / B's output side
+  int64_t slot_bytes;
+  unsigned debug;                    // developer aid (GFFT_FUSE2_DEBUG): 2 tickets only, 3 + waits, 4 + A tiles, 5 + B tiles instead
+  unsigned spin_limit;               // polls of a counter before a waiting workgroup gives up (never hang a device)
+  unsigned *ctr;                     // [0] ticket, [1] watchdog, [16 + p] A tiles of plane p stored, [16 + planes + p] B tiles done
+};
+enum FusedKind { FUSED_ROWS_COLS = 0, FUSED_COLS_ROWS = 1, FUSED_FOURSTEP = 2 };
+bool fused2_supported(int kind, int precision, int n_a, int n_b);
+// variant: 1 = 16 lines per tile, one 1024-thread workgroup per CU; 2 = 8 lines, two 512-thread workgroups per CU
+hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, const FusedDesc &f, const void *in,
+                             void *ring, void *out, hipStream_t s);
+int fused2_tiles(int kind, int variant, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b);
 // packed-real row kernels (fft_real_*.hip): d.n = complex length = half the real length
 bool real_half_supported(int n_complex);
 hipError_t launch_real_half_f64(const PassDesc &d, int variant, const void *in, void *out, hipStream_t s);

@@ -72,6 +72,9 @@ struct Options {
   int real_half = 1;         // contiguous real lines as half-length complex transforms (fft_real_*.hip)
   int debug_flat = 0;        // gfft_debug_pass: tiles over the flattened (mid, inner) index
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
+  int fuse2 = 1;             // pass pairs in one persistent launch, handed over through the Infinity Cache (fft_fused_f64.hip)
+  int fuse2_ring = 8, fuse2_lag = 4;
+  int fuse2_kinds = 6;       // which pairs (bit = FusedKind): measured per kind, see make_fused2
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
   int64_t fused3_min_bytes = 32 << 20;
@@ -83,6 +86,10 @@ struct Options {
     if (const char *s = getenv("GFFT_FUSED3")) fused3 = atoi(s);
     if (const char *s = getenv("GFFT_REAL_HALF")) real_half = atoi(s);
     if (const char *s = getenv("GFFT_XCD_SWIZZLE")) xcd_swizzle = atoi(s);
+    if (const char *s = getenv("GFFT_FUSE2")) fuse2 = atoi(s);
+    if (const char *s = getenv("GFFT_FUSE2_RING")) fuse2_ring = atoi(s);
+    if (const char *s = getenv("GFFT_FUSE2_LAG")) fuse2_lag = atoi(s);
+    if (const char *s = getenv("GFFT_FUSE2_KINDS")) fuse2_kinds = atoi(s);
   }
 };
 Options &opts() {
@@ -171,9 +178,10 @@ int get_bigtw(int64_t big_n, int precision, BigTw *out) {
 //        of a multi-axis c2r (so the caller's input is never written)
 //   FS   the transposed intermediate of a four-step axis
 //   AUX  the embedding buffer of a Bluestein / real-as-complex axis
-enum Buf { BUF_IN = 0, BUF_OUT = 1, BUF_WS = 2, BUF_FS = 3, BUF_AUX = 4, BUF_COUNT = 5 };
+//   RING the hand-off ring (+ its counters) of a fused pass pair (PK_FUSED2)
+enum Buf { BUF_IN = 0, BUF_OUT = 1, BUF_WS = 2, BUF_FS = 3, BUF_AUX = 4, BUF_RING = 5, BUF_COUNT = 6 };
 
-enum PassKind { PK_FFT = 0, PK_EMBED, PK_MULB, PK_EXTRACT };
+enum PassKind { PK_FFT = 0, PK_EMBED, PK_MULB, PK_EXTRACT, PK_FUSED2 };
 
 struct Pass {
   PassKind kind = PK_FFT;
@@ -194,7 +202,18 @@ struct Pass {
   // (gfft_plan_set_tiles re-derives the block jumps from them)
   int blocks[2] = {1, 1};
   int64_t bstride[2] = {0, 0};
+  // PK_FUSED2: `d` = pass A on ONE plane, `d2` = pass B on one plane, `fused` = the planes (fft_pow2_impl.h
+  // fft_fused2_kernel); fused.ctr and the ring's address are filled in at execution
+  PassDesc d2{};
+  FusedDesc fused{};
+  int fused_kind = 0, fused_variant = 1;
+  double bytes2 = 0;                 // algorithmic bytes of pass B (gfft_plan_pass_info reports A + B)
 };
+
+// Turn two consecutive passes A -> B into one fused launch when a kernel pair exists: dA / dB are the passes
+// cut down to one plane, the plane strides say where plane p starts on A's input and B's output side.
+bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const PassDesc &dA, const PassDesc &dB, int planes,
+                 int64_t a_in_plane, int64_t b_out_plane, int64_t slot_bytes, Pass *out);
 
 bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 
@@ -322,7 +341,7 @@ struct gfft_plan_s {
   std::vector<int64_t> sizes_in, sizes_out;
   std::vector<int> axes;
   std::vector<Pass> passes;
-  size_t region_bytes[BUF_COUNT] = {0, 0, 0, 0, 0};   // WS / FS / AUX sizes
+  size_t region_bytes[BUF_COUNT] = {0, 0, 0, 0, 0, 0};   // WS / FS / AUX / RING sizes
   double flops = 0, bytes = 0;
   int variant_rows = 0, variant_cols = 0, xcd_swizzle = 0;
   bool fused3 = false;
@@ -334,6 +353,41 @@ namespace {
 
 void need(gfft_plan_s *pl, int buf, size_t bytes) {
   if (bytes > pl->region_bytes[buf]) pl->region_bytes[buf] = bytes;
+}
+
+bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const PassDesc &dA, const PassDesc &dB, int planes,
+                 int64_t a_in_plane, int64_t b_out_plane, int64_t slot_bytes, Pass *out) {
+  const int ring = opts().fuse2_ring, lag = opts().fuse2_lag;
+  if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1) || planes < 2 * ring || lag < 1 || ring <= lag) return false;
+  if (!fused2_supported(kind, pl->precision, dA.n, dB.n)) return false;
+  int ta = 0, tb = 0;
+  const int variant = opts().fuse2 == 2 ? 2 : 1;
+  if (fused2_tiles(kind, variant, dA, dB, &ta, &tb) || ta < 1 || tb < 1) return false;
+  // (hand-off accesses carry 32-bit byte offsets inside a slot; tickets are 32-bit)
+  if (slot_bytes >= ((int64_t)1 << 31) || (double)planes * (ta + tb) >= 4.0e9) return false;
+  Pass f = a;
+  f.kind = PK_FUSED2;
+  f.fused_kind = kind;
+  f.fused_variant = variant;
+  f.d = dA;
+  f.d2 = dB;
+  f.src = a.src;
+  f.dst = b.dst;
+  f.carries_scale = false;
+  f.fused.planes = planes;
+  f.fused.tiles_a = ta;
+  f.fused.tiles_b = tb;
+  f.fused.ring = ring;
+  f.fused.lag = lag;
+  f.fused.a_in_plane = a_in_plane;
+  f.fused.b_out_plane = b_out_plane;
+  f.fused.slot_bytes = (int64_t)align256((size_t)slot_bytes);
+  f.fused.ctr = nullptr;
+  f.fused.spin_limit = 1u << 24;
+  f.fused.debug = 0;
+  need(pl, BUF_RING, (size_t)ring * (size_t)f.fused.slot_bytes + align256((size_t)(16 + 2 * planes) * sizeof(unsigned)));
+  *out = f;
+  return true;
 }
 
 // A batch of 1-D lines: array [outer][nin -> nout][inner] (row-major), logical length n.
@@ -436,6 +490,18 @@ int plan_fourstep(gfft_plan_s *pl, const Line &L, int64_t n1, int64_t n2) {
     }
     rc = get_twiddles(m, prec, &q->d.tw);
     if (rc) return rc;
+  }
+  // Both passes in one persistent launch, a signal's intermediate handed over inside the Infinity Cache
+  // (FUSED_FOURSTEP): plane = one signal, slot = its [n2][S2] intermediate.
+  if (a.regk && b.regk && inner == 1 && outer < ((int64_t)1 << 30)) {
+    PassDesc dA = a.d, dB = b.d;
+    dA.batch = n2;           // (o, i2, i) with o = 0
+    dB.batch = n1;
+    Pass f;
+    if (make_fused2(pl, FUSED_FOURSTEP, a, b, dA, dB, (int)outer, n * esz, n * esz, n2 * S2 * esz, &f)) {
+      pl->passes.push_back(f);
+      return GFFT_OK;
+    }
   }
   need(pl, BUF_FS, (size_t)outer * n2 * S2 * esz);
   pl->passes.push_back(a);
@@ -992,12 +1058,20 @@ int plan_fused3(gfft_plan_s *pl) {
     p.src = src; p.dst = dst;
     return p;
   };
+  // A complex transform may run its axes in either order.  Where the last two passes can be fused into one
+  // launch (make_fused2, FUSED_COLS_ROWS) the forward direction takes the backward schedule's order -- axis 1,
+  // then [axis 0 -> rows] plane by plane: the fused pair then WRITES the caller's rows scattered (plane i1 =
+  // rows 16 MiB apart), which costs nothing, where the mirror pair [rows -> axis 0] READS them scattered and
+  // loses what the fusion gains (1024^3 c128, tools/fused2_probe.py: 20.0 ms against 18.4 ms).
+  const bool cols_first = !inverse && !real && !tr && !flat_out && Pu == nc && opts().fuse2 &&
+                          ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && n1 >= 2 * opts().fuse2_ring &&
+                          fused2_supported(FUSED_COLS_ROWS, prec, (int)n0, (int)n2);
   std::vector<Pass> seq;
   if (flat_out) {
     seq.push_back(rows(MODE_R2C, false, true, BUF_IN, BUF_WS));
     seq.push_back(axis1(true, true, BUF_WS, BUF_WS));
     seq.push_back(axis0_flat(BUF_WS, BUF_OUT));
-  } else if (!inverse) {
+  } else if (!inverse && !cols_first) {
     seq.push_back(rows(real ? MODE_R2C : MODE_C2C, false, true, BUF_IN, BUF_WS));
     seq.push_back(axis0(BUF_WS, BUF_WS));
     seq.push_back(axis1(true, false, BUF_WS, BUF_OUT));
@@ -1022,6 +1096,28 @@ int plan_fused3(gfft_plan_s *pl) {
     if (p.d.tr_dir == 2) nin = p.d.tr_n;
     pl->bytes += lines * (nin * ein + nout * eout);
     pl->passes.push_back(p);
+  }
+  // Complex schedules: [rows along axis 2] + [axis 0 inside the workspace] -- passes 1 + 2 forward, 2 + 3
+  // backward -- as ONE persistent launch per direction, plane by plane (a plane = one i1: n0 rows of n2
+  // entries), the plane handed over through the Infinity Cache instead of W (FUSED_ROWS_COLS / _COLS_ROWS).
+  if (!real && !tr && !flat_out && Pu == nc && pl->passes.size() >= 3) {
+    const size_t base = pl->passes.size() - 3;
+    Pass &p1 = pl->passes[base], &p2 = pl->passes[base + 1], &p3 = pl->passes[base + 2];
+    Pass f;
+    bool ok = false;
+    if (!inverse && !cols_first) {
+      PassDesc dA = p1.d, dB = p2.d;                  // rows IN -> slot[i0][c];  axis 0: slot -> W[i1][k0][c]
+      dA.batch = n0; dA.inner = 1; dA.in_is = 0; dA.out_is = 0; dA.out_os = P;
+      dB.batch = Pu; dB.in_os = 0; dB.out_os = 0; dB.in_es = P;
+      ok = make_fused2(pl, FUSED_ROWS_COLS, p1, p2, dA, dB, (int)n1, n2 * esz, w_i1 * esz, n0 * P * esz, &f);
+      if (ok) { f.bytes2 = 1; pl->passes[base] = f; pl->passes.erase(pl->passes.begin() + base + 1); }
+    } else {
+      PassDesc dA = p2.d, dB = p3.d;                  // axis 0: W[i1][k0][c] -> slot[i0][c];  rows slot -> OUT
+      dA.batch = Pu; dA.in_os = 0; dA.out_os = 0; dA.out_es = P;
+      dB.batch = n0; dB.inner = 1; dB.in_is = 0; dB.out_is = 0; dB.in_os = P; dB.out_os = n1 * n2;
+      ok = make_fused2(pl, FUSED_COLS_ROWS, p2, p3, dA, dB, (int)n1, w_i1 * esz, n2 * esz, n0 * P * esz, &f);
+      if (ok) { f.bytes2 = 1; pl->passes[base + 1] = f; pl->passes.erase(pl->passes.begin() + base + 2); }
+    }
   }
   pl->fused3 = true;
   // fp32 strided passes of this schedule run between pitched rows, where two 512-thread workgroups
@@ -1138,6 +1234,10 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "copy_nt")) gfft::g_copy_nt = value;
   else if (!strcmp(key, "fused3")) opts().fused3 = value;
   else if (!strcmp(key, "real_half")) opts().real_half = value;
+  else if (!strcmp(key, "fuse2")) opts().fuse2 = value;
+  else if (!strcmp(key, "fuse2_ring")) opts().fuse2_ring = value;
+  else if (!strcmp(key, "fuse2_lag")) opts().fuse2_lag = value;
+  else if (!strcmp(key, "fuse2_kinds")) opts().fuse2_kinds = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
@@ -1340,7 +1440,7 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
     return fail(GFFT_ERR_INVALID, "in-place real transforms are not supported");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // scratch regions: carved from the stream's shared buffer (scratch_pool)
-  size_t off[BUF_COUNT] = {0, 0, 0, 0, 0}, total = 0;
+  size_t off[BUF_COUNT] = {0, 0, 0, 0, 0, 0}, total = 0;
   for (int b = BUF_WS; b < BUF_COUNT; ++b) {
     off[b] = total;
     total += align256(pl->region_bytes[b]);
@@ -1352,7 +1452,7 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
     if (rc) return rc;
     scratch = static_cast<char *>(scratch) + skew;
   }
-  void *bufs[BUF_COUNT] = {const_cast<void *>(d_in), d_out, nullptr, nullptr, nullptr};
+  void *bufs[BUF_COUNT] = {const_cast<void *>(d_in), d_out, nullptr, nullptr, nullptr, nullptr};
   for (int b = BUF_WS; b < BUF_COUNT; ++b)
     if (pl->region_bytes[b]) bufs[b] = static_cast<char *>(scratch) + off[b];
 
@@ -1373,6 +1473,27 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
   }
   for (const Pass &p : pl->passes) {
     PassDesc d = p.d;
+    if (p.kind == PK_FUSED2) {
+      PassDesc d2 = p.d2;
+      if (p.carries_scale) d2.scale = scale;
+      FusedDesc f = p.fused;
+      char *ring = static_cast<char *>(bufs[BUF_RING]);
+      f.ctr = reinterpret_cast<unsigned *>(ring + (size_t)f.ring * (size_t)f.slot_bytes);
+      static const int debug = getenv("GFFT_FUSE2_DEBUG") ? atoi(getenv("GFFT_FUSE2_DEBUG")) : 0;
+      if (debug) { f.spin_limit = 1u << 12; f.debug = (unsigned)debug; }
+      HIP_TRY(launch_fused2_f64(p.fused_kind, p.fused_variant, d, d2, f, bufs[p.src], ring, bufs[p.dst], s));
+      if (debug) {      // developer aid: the launch's counters (tickets drawn, waits given up, tiles per plane)
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned> h(16 + 2 * (size_t)f.planes);
+        HIP_TRY(hipMemcpy(h.data(), f.ctr, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        unsigned long long sa = 0, sb = 0;
+        for (int i = 0; i < f.planes; ++i) { sa += h[16 + i]; sb += h[16 + f.planes + i]; }
+        fprintf(stderr, "[gfft fuse2] kind %d planes %d tiles %d+%d ring %d lag %d: tickets %u, waits given up %u, A tiles %llu, B tiles %llu\n",
+                p.fused_kind, f.planes, f.tiles_a, f.tiles_b, f.ring, f.lag, h[0], h[1], sa, sb);
+      }
+      HIP_TRY(mark());
+      continue;
+    }
     if (p.carries_scale) d.scale = scale;
     HIP_TRY(run_pass(pl, p, d, bufs[p.src], bufs[p.dst], p.carries_scale ? scale : 1.0, s));
     HIP_TRY(mark());
@@ -1408,6 +1529,14 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
   if (!pl || i < 0 || i >= (int)pl->passes.size()) return fail(GFFT_ERR_INVALID, "bad pass index");
   const Pass &p = pl->passes[i];
   static const char *kinds[] = {"", "embed", "mul-B", "extract"};
+  if (p.kind == PK_FUSED2) {
+    // two axis passes in one launch: the algorithmic bytes of both (one read + one write of the array each)
+    static const char *fk[] = {"fused rows+cols", "fused cols+rows", "fused four-step"};
+    snprintf(buf, len, "%s n=%dx%d", fk[p.fused_kind], p.d.n, p.d2.n);
+    if (bytes) *bytes = (double)p.fused.planes * 2.0 * pl->precision *
+                        ((double)p.d.batch * 2.0 * p.d.n + (double)p.d2.batch * 2.0 * p.d2.n);
+    return GFFT_OK;
+  }
   if (p.kind != PK_FFT) {
     snprintf(buf, len, "%s n=%lld", kinds[p.kind], (long long)p.pt.n);
     if (bytes) *bytes = 0;
@@ -1752,8 +1881,16 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
   snprintf(line, sizeof line, "gfft plan: %s %s, %d dims, %zu passes%s\n", kn, pl->precision == 8 ? "f64" : "f32",
            pl->ndims, pl->passes.size(), pl->fused3 ? " [3-D schedule: padded-pitch workspace]" : "");
   s += line;
-  static const char *bufn[] = {"IN", "OUT", "WS", "FS", "AUX"};
+  static const char *bufn[] = {"IN", "OUT", "WS", "FS", "AUX", "RING"};
   for (const Pass &p : pl->passes) {
+    if (p.kind == PK_FUSED2) {
+      static const char *fk[] = {"rows -> strided", "strided -> rows", "four-step"};
+      snprintf(line, sizeof line, "  fused pair (%s) n=%d then n=%d: %d planes, %d + %d tiles per plane, ring of %d slots x %lld KiB, one persistent launch%s  %s -> %s\n",
+               fk[p.fused_kind], p.d.n, p.d2.n, p.fused.planes, p.fused.tiles_a, p.fused.tiles_b, p.fused.ring,
+               (long long)(p.fused.slot_bytes >> 10), p.carries_scale ? " [scale]" : "", bufn[p.src], bufn[p.dst]);
+      s += line;
+      continue;
+    }
     if (p.kind != PK_FFT) {
       static const char *kinds[] = {"", "embed (chirp/zero-pad into AUX)", "multiply by B = FFT(chirp)", "extract (chirp, scale)"};
       snprintf(line, sizeof line, "  %s n=%lld Lw=%lld  %s -> %s\n", kinds[p.kind], (long long)p.pt.n,

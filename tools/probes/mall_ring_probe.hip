@@ -28,40 +28,40 @@ constexpr int TPP = ROWS / TILE;
 // 16-byte accesses at SYSTEM scope (sc0 sc1): the store is written through the XCD's L2 to the memory side
 // (Infinity Cache / HBM), the load never hits a (possibly stale) L2 line -- coherence between workgroups on
 // different XCDs per access, instead of writing back / invalidating whole L2s at every hand-off
-__device__ __forceinline__ void st_sys(vec4 *p, vec4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ vec4 ld_sys(const vec4 *p) {
-  vec4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
+typedef unsigned uvec4 __attribute__((ext_vector_type(4)));
+// (raw buffer accesses with cache policy aux = sc0 | sc1 = 1 | 16: the compiler tracks their completion itself)
+struct SysBuf {
+  __amdgpu_buffer_rsrc_t r;
+  __device__ __forceinline__ explicit SysBuf(const void *base) : r(__builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00020000)) {}
+  __device__ __forceinline__ void st(unsigned elem, vec4 v) const {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uvec4, v), r, elem * 16u, 0, 17);
+  }
+  __device__ __forceinline__ vec4 ld(unsigned elem) const {
+    return __builtin_bit_cast(vec4, __builtin_amdgcn_raw_buffer_load_b128(r, elem * 16u, 0, 17));
+  }
+};
 template <bool SYS_ST>
 __device__ __forceinline__ void copy_rows_t(const vec4 *__restrict__ src, vec4 *__restrict__ dst, int t) {
   const size_t base = (size_t)t * TILE * ROWS;
-  vec4 v[TILE];
-#pragma unroll
-  for (int q = 0; q < TILE; ++q) v[q] = src[base + (size_t)q * ROWS + threadIdx.x] * 1.0000001f;
+  const SysBuf sb(dst);                 // dst = the plane's ring slot (16 MiB: 32-bit offsets)
 #pragma unroll
   for (int q = 0; q < TILE; ++q) {
-    vec4 *p = dst + base + (size_t)q * ROWS + threadIdx.x;
-    if (SYS_ST) st_sys(p, v[q]); else *p = v[q];
+    const vec4 v = src[base + (size_t)q * ROWS + threadIdx.x] * 1.0000001f;
+    if (SYS_ST) sb.st((unsigned)(base + (size_t)q * ROWS + threadIdx.x), v); else dst[base + (size_t)q * ROWS + threadIdx.x] = v;
   }
-  if (SYS_ST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (SYS_ST) __builtin_amdgcn_s_waitcnt(0);       // every write-through store acknowledged before the flag goes up
 }
 template <bool SYS_LD>
 __device__ __forceinline__ void copy_cols_t(const vec4 *__restrict__ src, vec4 *__restrict__ dst, int t) {
   const int c = threadIdx.x % TILE, r0 = threadIdx.x / TILE;
   constexpr int Q = ROWS / (THREADS / TILE);
-  vec4 v[Q];
+  const SysBuf sb(src);
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    const vec4 *p = src + (size_t)(r0 + q * (THREADS / TILE)) * ROWS + (size_t)t * TILE + c;
-    if (SYS_LD) v[q] = ld_sys(p); else v[q] = *p;
+    const size_t i = (size_t)(r0 + q * (THREADS / TILE)) * ROWS + (size_t)t * TILE + c;
+    const vec4 v = SYS_LD ? sb.ld((unsigned)i) : src[i];
+    dst[i] = v * 1.0000001f;
   }
-  if (SYS_LD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int q = 0; q < Q; ++q) dst[(size_t)(r0 + q * (THREADS / TILE)) * ROWS + (size_t)t * TILE + c] = v[q] * 1.0000001f;
 }
 __global__ void diff_kernel(const vec4 *a, const vec4 *b, size_t n, unsigned *bad) {
   unsigned cnt = 0;
