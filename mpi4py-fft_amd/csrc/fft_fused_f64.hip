@@ -11,19 +11,19 @@ namespace gfft {
 
 namespace {
 //                      real   N     R   T   COLS   SPLIT FLAGS        MODE      BIGTW  radices
-typedef PassCfg<double, 1024, 16, 16, false, true, 2048, MODE_C2C, false, 16, 16, 4> RowsToRing;
-typedef PassCfg<double, 1024, 16, 16, false, true, 4096, MODE_C2C, false, 16, 16, 4> RowsFromRing;
-typedef PassCfg<double, 1024, 16, 16, true, true, 8 | 2048, MODE_C2C, false, 16, 16, 4> ColsToRing;
-typedef PassCfg<double, 1024, 16, 16, true, true, 8 | 4096, MODE_C2C, false, 16, 16, 4> ColsFromRing;
-typedef PassCfg<double, 1024, 16, 16, true, true, 32 | 2048, MODE_C2C, true, 16, 16, 4> FourStepFirst;   // twiddle + transposing store
+typedef PassCfg<double, 1024, 16, 16, false, true, 2048 | 8192, MODE_C2C, false, 16, 16, 4> RowsToRing;
+typedef PassCfg<double, 1024, 16, 16, false, true, 4096 | 8192, MODE_C2C, false, 16, 16, 4> RowsFromRing;
+typedef PassCfg<double, 1024, 16, 16, true, true, 8 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> ColsToRing;
+typedef PassCfg<double, 1024, 16, 16, true, true, 8 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> ColsFromRing;
+typedef PassCfg<double, 1024, 16, 16, true, true, 32 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirst;   // twiddle + transposing store
 // variant 2: 8 lines per tile, 512 threads, two workgroups per CU (a fused pair moves a third less through HBM
 // than two launches, so what bounds it is how long ONE workgroup takes per tile -- load, butterflies and
 // store in sequence -- and a second workgroup on the CU fills those gaps)
-typedef PassCfg<double, 1024, 16, 8, false, true, 2048, MODE_C2C, false, 16, 16, 4> RowsToRing8;
-typedef PassCfg<double, 1024, 16, 8, false, true, 4096, MODE_C2C, false, 16, 16, 4> RowsFromRing8;
-typedef PassCfg<double, 1024, 16, 8, true, true, 8 | 2048, MODE_C2C, false, 16, 16, 4> ColsToRing8;
-typedef PassCfg<double, 1024, 16, 8, true, true, 8 | 4096, MODE_C2C, false, 16, 16, 4> ColsFromRing8;
-typedef PassCfg<double, 1024, 16, 8, true, true, 32 | 2048, MODE_C2C, true, 16, 16, 4> FourStepFirst8;
+typedef PassCfg<double, 1024, 16, 8, false, true, 2048 | 8192, MODE_C2C, false, 16, 16, 4> RowsToRing8;
+typedef PassCfg<double, 1024, 16, 8, false, true, 4096 | 8192, MODE_C2C, false, 16, 16, 4> RowsFromRing8;
+typedef PassCfg<double, 1024, 16, 8, true, true, 8 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> ColsToRing8;
+typedef PassCfg<double, 1024, 16, 8, true, true, 8 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> ColsFromRing8;
+typedef PassCfg<double, 1024, 16, 8, true, true, 32 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirst8;
 }  // namespace
 
 bool fused2_supported(int kind, int precision, int n_a, int n_b) {

@@ -789,6 +789,23 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
   constexpr int IOMODE = HALF ? MODE_C2C : MODE;
   static_assert(!HALF || (!COLS && !BIGTW && !(FLAGS & 32)), "packed-real modes: contiguous axis only");
   static_assert(!(FLAGS & (2048 | 4096)) || (MODE == MODE_C2C && !(FLAGS & 16)), "hand-off buffers: plain complex passes");
+  // FLAGS & 8192: natural layouts on both sides (fused pairs) -- the exchange-buffer layout fields of the
+  // descriptor (blocks, tile-major lines / columns, flat tiles, masked columns) are compile-time zeros, so
+  // neither their loads nor the arithmetic on them survive (the fused kernels hold TWO descriptors)
+  constexpr bool PLAIN = (FLAGS & 8192) != 0;
+  const auto L_in_tlg = PLAIN ? decltype(d.in_tlg)(0) : d.in_tlg;
+  const auto L_out_tlg = PLAIN ? decltype(d.out_tlg)(0) : d.out_tlg;
+  const auto L_in_lgp = PLAIN ? decltype(d.in_lgp)(0) : d.in_lgp;
+  const auto L_out_lgp = PLAIN ? decltype(d.out_lgp)(0) : d.out_lgp;
+  const auto L_in_jump = PLAIN ? decltype(d.in_jump)(0) : d.in_jump;
+  const auto L_out_jump = PLAIN ? decltype(d.out_jump)(0) : d.out_jump;
+  const auto L_in_ilg = PLAIN ? decltype(d.in_ilg)(0) : d.in_ilg;
+  const auto L_out_ilg = PLAIN ? decltype(d.out_ilg)(0) : d.out_ilg;
+  const auto L_fl_bw = PLAIN ? decltype(d.fl_bw)(0) : d.fl_bw;
+  const auto L_flat = PLAIN ? decltype(d.flat)(0) : d.flat;
+  const auto L_inner_ld = PLAIN ? decltype(d.inner_ld)(0) : d.inner_ld;
+  const auto L_inner_st = PLAIN ? decltype(d.inner_st)(0) : d.inner_st;
+  const auto L_out_pad = PLAIN ? decltype(d.out_pad)(0) : d.out_pad;
   [[maybe_unused]] const SysBuf sys_in(in), sys_out(out);
   const cx<real> *tw = reinterpret_cast<const cx<real> *>(d.tw);
   const int tid = threadIdx.x;
@@ -802,20 +819,20 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
   // ROWS: the batch is flat (each column is itself a contiguous row of the array).
   // (four-step passes -- BIGTW -- run their columns along `mid` and use the flat form too.)
   constexpr bool ROWTILES = COLS && !BIGTW;
-  const unsigned flat_cols = mid * inner;                       // d.flat: columns per outer index
-  const unsigned chunks = ROWTILES ? ((d.flat ? flat_cols : inner) + T - 1) / T : 1;
-  const unsigned ntiles = ROWTILES ? (d.flat ? batch / flat_cols : batch / inner) * chunks : (batch + T - 1) / T;
+  const unsigned flat_cols = mid * inner;                       // L_flat: columns per outer index
+  const unsigned chunks = ROWTILES ? ((L_flat ? flat_cols : inner) + T - 1) / T : 1;
+  const unsigned ntiles = ROWTILES ? (L_flat ? batch / flat_cols : batch / inner) * chunks : (batch + T - 1) / T;
   const real sy_in = d.conj_in ? (real)-1 : (real)1;
   const real sx_out = (real)(MODE == MODE_R2C_H ? 0.5 * d.scale : d.scale);   // (the Hermitian pass leaves 2 X)
   const real sy_out = d.conj_out ? -sx_out : sx_out;
   // per thread (tile-major lines, PassDesc::in_tlg / out_tlg: tile index and lane within the tile)
-  const int64_t t_in = (!COLS && d.in_tlg) ? (int64_t)(t >> d.in_tlg) * d.in_tS + (t & ((1 << d.in_tlg) - 1)) : (int64_t)t * d.in_es;
-  const int64_t t_out = (!COLS && d.out_tlg) ? (int64_t)(t >> d.out_tlg) * d.out_tS + (t & ((1 << d.out_tlg) - 1)) : (int64_t)t * d.out_es;
+  const int64_t t_in = (!COLS && L_in_tlg) ? (int64_t)(t >> L_in_tlg) * d.in_tS + (t & ((1 << L_in_tlg) - 1)) : (int64_t)t * d.in_es;
+  const int64_t t_out = (!COLS && L_out_tlg) ? (int64_t)(t >> L_out_tlg) * d.out_tS + (t & ((1 << L_out_tlg) - 1)) : (int64_t)t * d.out_es;
   // fused padding / truncation: distance between the two halves of the padded spectrum (uniform)
   const int64_t pad_shift_in = (FLAGS & 16) ? (int64_t)(d.n - d.tr_N) * d.in_es : 0;
   const int64_t pad_shift_out = (FLAGS & 16) ? (int64_t)(d.n - d.tr_N) * d.out_es : 0;
-  const int64_t q_in = (!COLS && d.in_tlg) ? (int64_t)(NT >> d.in_tlg) * d.in_tS : (int64_t)NT * d.in_es;     // uniform steps
-  const int64_t q_out = (!COLS && d.out_tlg) ? (int64_t)(NT >> d.out_tlg) * d.out_tS : (int64_t)NT * d.out_es;
+  const int64_t q_in = (!COLS && L_in_tlg) ? (int64_t)(NT >> L_in_tlg) * d.in_tS : (int64_t)NT * d.in_es;     // uniform steps
+  const int64_t q_out = (!COLS && L_out_tlg) ? (int64_t)(NT >> L_out_tlg) * d.out_tS : (int64_t)NT * d.out_es;
 
   for (unsigned k = k_first; k < k_end; k += k_step) {
     const unsigned tile = xcd_base + k;
@@ -829,7 +846,7 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
     unsigned o, m, i;
     if constexpr (ROWTILES) {
       const unsigned row = tile / chunks, j = tile - row * chunks;
-      if (d.flat) {
+      if (L_flat) {
         // tiles over the flattened (m, i) index of one outer slab: per-lane row and column
         o = row;
         unsigned J = j * T + c;
@@ -839,8 +856,8 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
         i = J - m * inner;
       } else {
         i = j * T + c;
-        valid = i < (d.inner_ld ? (unsigned)d.inner_ld : inner);          // columns that are read
-        valid_st = i < (d.inner_st ? (unsigned)d.inner_st : inner);       // columns that are written
+        valid = i < (L_inner_ld ? (unsigned)L_inner_ld : inner);          // columns that are read
+        valid_st = i < (L_inner_st ? (unsigned)L_inner_st : inner);       // columns that are written
         if (!(valid || valid_st)) i = 0;
         o = row / mid;
         m = row - o * mid;
@@ -858,9 +875,9 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
     if constexpr (COLS) {
       // (tile-major columns of an exchange buffer, PassDesc::in_ilg / out_ilg; flat tiles over rows
       // stored as body + leftover columns, PassDesc::fl_bw)
-      if (d.fl_bw && i >= (unsigned)d.fl_bw) in0 = (int64_t)o * d.in_os + d.fl_tail + (int64_t)m * d.fl_tail_ms + (i - (unsigned)d.fl_bw);
-      else in0 += d.in_ilg ? (int64_t)(i >> d.in_ilg) * d.in_iS + (i & ((1u << d.in_ilg) - 1)) : (int64_t)i * d.in_is;
-      out0 += d.out_ilg ? (int64_t)(i >> d.out_ilg) * d.out_iS + (i & ((1u << d.out_ilg) - 1)) : (int64_t)i * d.out_is;
+      if (L_fl_bw && i >= (unsigned)L_fl_bw) in0 = (int64_t)o * d.in_os + d.fl_tail + (int64_t)m * d.fl_tail_ms + (i - (unsigned)L_fl_bw);
+      else in0 += L_in_ilg ? (int64_t)(i >> L_in_ilg) * d.in_iS + (i & ((1u << L_in_ilg) - 1)) : (int64_t)i * d.in_is;
+      out0 += L_out_ilg ? (int64_t)(i >> L_out_ilg) * d.out_iS + (i & ((1u << L_out_ilg) - 1)) : (int64_t)i * d.out_is;
     } else {
       in0 += (int64_t)i * d.in_is;
       out0 += (int64_t)i * d.out_is;
@@ -870,7 +887,7 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
     // Split layouts: thread slots e = t + q*NT advance by NT, and a block of the cut axis holds
     // (R >> lgp) * NT entries, so block boundaries fall between the same q for every thread: a
     // workgroup-uniform counter adds the block jump to the (uniform) step -- scalar work only.
-    const int seg_in = R >> d.in_lgp, seg_out = R >> d.out_lgp;
+    const int seg_in = R >> L_in_lgp, seg_out = R >> L_out_lgp;
     if (valid) {
       int64_t idx = in0 + t_in;
       int cnt = 0;
@@ -899,7 +916,7 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
         int64_t step = q_in;
         if (++cnt == seg_in) {
           cnt = 0;
-          step += d.in_jump;
+          step += L_in_jump;
         }
         idx += step;
       }
@@ -1078,7 +1095,7 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
         int64_t step = q_out;
         if (++cnt == seg_out) {
           cnt = 0;
-          step += d.out_jump;
+          step += L_out_jump;
         }
         idx += step;
       }
@@ -1086,9 +1103,9 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
         if (tl == 0)
           reinterpret_cast<cx<real> *>(out)[uneven_offset(d, row_ub, o, i, N)] = {(z0.x - z0.y) * 2 * sx_out, 0};
       } else if constexpr (MODE == MODE_R2C_H && !(FLAGS & 16)) {
-        // X[N] from thread 0, followed by d.out_pad zeros from its neighbours: one coalesced store
+        // X[N] from thread 0, followed by L_out_pad zeros from its neighbours: one coalesced store
         // that completes the row's last 128-byte line when the output rows are pitched
-        if (tl <= d.out_pad)
+        if (tl <= L_out_pad)
           reinterpret_cast<cx<real> *>(out)[out0 + (int64_t)(N + tl) * d.out_es] =
               {tl == 0 ? (z0.x - z0.y) * 2 * sx_out : (real)0, 0};
       }

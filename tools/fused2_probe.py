@@ -28,3 +28,10 @@ if len(sys.argv) > 1:
         fft = PFFT(comm.COMM_SELF, (1024,)*3, dtype='D')
         print('ring %2d lag %d: fwd %.3f / %.3f  bwd %.3f / %.3f' % ((ring, lag) + timeit(lambda: fft.forward()) + timeit(lambda: fft.backward())), flush=True)
         fft.destroy(); del fft; torch.cuda.empty_cache()
+if len(sys.argv) > 2 and sys.argv[2] == 'c2':
+    for ring, lag in ((3, 1), (4, 2), (6, 2), (8, 2), (6, 3), (8, 4), (12, 4)):
+        _lib.set_option('fuse2_ring', ring); _lib.set_option('fuse2_lag', lag)
+        a = zeros((64, 1 << 20), 'D'); torch.view_as_real(a.tensor).normal_()
+        p = fftw.fftn(a, axes=(1,))
+        print('C2 ring %2d lag %d: %.3f / %.3f ms' % ((ring, lag) + timeit(lambda: p.execute_scaled(a, p.output_array, 1.0), iters=20)), flush=True)
+        p.destroy(); del a, p; torch.cuda.empty_cache()
