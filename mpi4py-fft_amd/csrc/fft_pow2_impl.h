@@ -1243,6 +1243,13 @@ fft_fused2_kernel(PassDesc dA, PassDesc dB, FusedDesc f, const void *__restrict_
   }
 }
 
+// A wait that gave up means a plane was read before it was complete: make that loud.  One thread, enqueued
+// behind the fused launch; the trap surfaces as a launch failure at the stream's next synchronisation.
+template <typename A>
+__global__ void fused2_check_kernel(const unsigned *ctr) {
+  if (ctr[1] != 0) __builtin_trap();
+}
+
 template <typename A, typename B>
 hipError_t launch_fused2(const PassDesc &dA, const PassDesc &dB, const FusedDesc &f, const void *in, void *ring, void *out,
                          hipStream_t s) {
@@ -1269,6 +1276,7 @@ hipError_t launch_fused2(const PassDesc &dA, const PassDesc &dB, const FusedDesc
   // two 512-thread ones share it): persistent, tickets do the load balancing
   const int per_cu = (A::threads <= 512 && 2 * lds + 1024 <= 160 * 1024) ? 2 : 1;
   hipLaunchKernelGGL(kern, dim3(cus * per_cu), dim3(A::threads), lds, s, dA, dB, f, in, ring, out);
+  if (!f.debug) hipLaunchKernelGGL(fused2_check_kernel<A>, dim3(1), dim3(1), 0, s, f.ctr);
   return hipGetLastError();
 }
 
