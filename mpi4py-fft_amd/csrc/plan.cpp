@@ -74,6 +74,7 @@ struct Options {
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
   int fuse2 = 1;             // pass pairs in one persistent launch, handed over through the Infinity Cache (fft_fused_f64.hip)
   int fuse2_ring = 8, fuse2_lag = 4;
+  int fuse2_wlayout = 0;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (A/B)
   int fuse2_kinds = 6;       // which pairs (bit = FusedKind): measured per kind, see make_fused2
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
@@ -90,6 +91,7 @@ struct Options {
     if (const char *s = getenv("GFFT_FUSE2_RING")) fuse2_ring = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_LAG")) fuse2_lag = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_KINDS")) fuse2_kinds = atoi(s);
+    if (const char *s = getenv("GFFT_FUSE2_WLAYOUT")) fuse2_wlayout = atoi(s);
   }
 };
 Options &opts() {
@@ -1063,9 +1065,13 @@ int plan_fused3(gfft_plan_s *pl) {
   // then [axis 0 -> rows] plane by plane: the fused pair then WRITES the caller's rows scattered (plane i1 =
   // rows 16 MiB apart), which costs nothing, where the mirror pair [rows -> axis 0] READS them scattered and
   // loses what the fusion gains (1024^3 c128, tools/fused2_probe.py: 20.0 ms against 18.4 ms).
-  const bool cols_first = !inverse && !real && !tr && !flat_out && Pu == nc && opts().fuse2 &&
-                          ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && n1 >= 2 * opts().fuse2_ring &&
-                          fused2_supported(FUSED_COLS_ROWS, prec, (int)n0, (int)n2);
+  const bool pair_cols_rows = !real && !tr && !flat_out && Pu == nc && opts().fuse2 &&
+                              ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && n1 >= 2 * opts().fuse2_ring &&
+                              fused2_supported(FUSED_COLS_ROWS, prec, (int)n0, (int)n2);
+  const bool cols_first = !inverse && pair_cols_rows;
+  // ... and the workspace then is W[i0][k1][c]: the stand-alone axis-1 pass stores on NEAR strides (stores are
+  // what far strides hurt), the fused pair's axis-0 tiles read the far (pitched) ones
+  if (pair_cols_rows && opts().fuse2_wlayout) { w_i0 = n1 * P; w_i1 = P; }
   std::vector<Pass> seq;
   if (flat_out) {
     seq.push_back(rows(MODE_R2C, false, true, BUF_IN, BUF_WS));
@@ -1238,6 +1244,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "fuse2_ring")) opts().fuse2_ring = value;
   else if (!strcmp(key, "fuse2_lag")) opts().fuse2_lag = value;
   else if (!strcmp(key, "fuse2_kinds")) opts().fuse2_kinds = value;
+  else if (!strcmp(key, "fuse2_wlayout")) opts().fuse2_wlayout = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
