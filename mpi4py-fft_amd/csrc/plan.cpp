@@ -74,7 +74,7 @@ struct Options {
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
   int fuse2 = 1;             // pass pairs in one persistent launch, handed over through the Infinity Cache (fft_fused_f64.hip)
   int fuse2_ring = 8, fuse2_lag = 4;
-  int fuse2_wlayout = 0;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (A/B)
+  int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
   int fuse2_kinds = 6;       // which pairs (bit = FusedKind): measured per kind, see make_fused2
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
