@@ -1191,7 +1191,9 @@ fft_fused2_kernel(PassDesc dA, PassDesc dB, FusedDesc f, const void *__restrict_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ unsigned tk[2];          // the ticket being worked on and the next one, drawn a tile ahead
   unsigned *done_a = f.ctr + 16, *done_b = f.ctr + 16 + f.planes;
-  const unsigned ta = (unsigned)f.tiles_a, tb = (unsigned)f.tiles_b, per_pair = ta + tb;
+  // (tickets count GROUPS of f.group consecutive tiles of one plane and pass)
+  const unsigned grp = (unsigned)f.group;
+  const unsigned ta = (unsigned)f.tiles_a / grp, tb = (unsigned)f.tiles_b / grp, per_pair = ta + tb;
   const unsigned head = (unsigned)f.lag * ta, pairs = (unsigned)(f.planes - f.lag);
   const unsigned total = (unsigned)f.planes * per_pair;
   // The next ticket is drawn while the current tile is being worked on (the atomic's round trip, ~2 us,
@@ -1226,7 +1228,8 @@ fft_fused2_kernel(PassDesc dA, PassDesc dB, FusedDesc f, const void *__restrict_
     if (f.debug == 2) continue;
     if (is_a) {
       if (p >= (unsigned)f.ring) fused_wait(&done_b[p - f.ring], tb, &f.ctr[1], f.spin_limit);
-      if (f.debug != 3 && f.debug != 5) A::tile(dA, static_cast<const char *>(in) + (size_t)p * f.a_in_plane, slot, smem, t);
+      if (f.debug != 3 && f.debug != 5)
+        for (unsigned g = 0; g < grp; ++g) A::tile(dA, static_cast<const char *>(in) + (size_t)p * f.a_in_plane, slot, smem, t * grp + g);
       __builtin_amdgcn_s_waitcnt(0);         // every write-through store of this wave acknowledged ...
       __syncthreads();                       // ... of every wave of the tile
       if (wave_of_thread0()) {
@@ -1234,7 +1237,8 @@ fft_fused2_kernel(PassDesc dA, PassDesc dB, FusedDesc f, const void *__restrict_
       }
     } else {
       fused_wait(&done_a[p], ta, &f.ctr[1], f.spin_limit);
-      if (f.debug != 3 && f.debug != 4) B::tile(dB, slot, static_cast<char *>(out) + (size_t)p * f.b_out_plane, smem, t);
+      if (f.debug != 3 && f.debug != 4)
+        for (unsigned g = 0; g < grp; ++g) B::tile(dB, slot, static_cast<char *>(out) + (size_t)p * f.b_out_plane, smem, t * grp + g);
       __syncthreads();
       if (wave_of_thread0()) {
         if (threadIdx.x == 0) __hip_atomic_fetch_add(&done_b[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1255,7 +1259,8 @@ hipError_t launch_fused2(const PassDesc &dA, const PassDesc &dB, const FusedDesc
                          hipStream_t s) {
   constexpr size_t lds = A::lds > B::lds ? A::lds : B::lds;
   static_assert(lds <= 160 * 1024, "LDS budget");
-  if (f.lag < 1 || f.ring <= f.lag || f.planes < 1 || f.tiles_a != (int)A::ntiles(dA) || f.tiles_b != (int)B::ntiles(dB))
+  if (f.lag < 1 || f.ring <= f.lag || f.planes < 1 || f.tiles_a != (int)A::ntiles(dA) || f.tiles_b != (int)B::ntiles(dB) ||
+      f.group < 1 || f.tiles_a % f.group || f.tiles_b % f.group)
     return hipErrorInvalidValue;
   auto kern = fft_fused2_kernel<A, B>;
   static bool attr_set = false;

@@ -155,6 +155,7 @@ int pow2_grid_cap();
 // FUSED_FOURSTEP = the two passes of a four-step transform of length n * n
 struct FusedDesc {
   int planes, tiles_a, tiles_b, ring, lag;
+  int group;                         // tiles per ticket (divides tiles_a and tiles_b): fewer tickets, counters and acknowledgement waits per byte
   int64_t a_in_plane, b_out_plane;   // BYTES from one plane to the next on A's input / B's output side
   int64_t slot_bytes;
   unsigned debug;                    // developer aid (GFFT_FUSE2_DEBUG): 2 tickets only, 3 + waits, 4 + A tiles, 5 + B tiles instead
@@ -162,11 +163,13 @@ struct FusedDesc {
   unsigned *ctr;                     // [0] ticket, [1] watchdog, [16 + p] A tiles of plane p stored, [16 + planes + p] B tiles done
 };
 enum FusedKind { FUSED_ROWS_COLS = 0, FUSED_COLS_ROWS = 1, FUSED_FOURSTEP = 2 };
-bool fused2_supported(int kind, int precision, int n_a, int n_b);
-// variant: 1 = 16 lines per tile, one 1024-thread workgroup per CU; 2 = 8 lines, two 512-thread workgroups per CU
+// variant: 1 = one 1024-thread workgroup per CU; 2 = (make VARIANTS=1, fp64 n = 1024) 8 lines per tile, two 512-thread
+// workgroups per CU
+bool fused2_supported_f64(int kind, int variant, int n_a, int n_b);
+int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b);
 hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, const FusedDesc &f, const void *in,
                              void *ring, void *out, hipStream_t s);
-int fused2_tiles(int kind, int variant, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b);
+
 // packed-real row kernels (fft_real_*.hip): d.n = complex length = half the real length
 bool real_half_supported(int n_complex);
 hipError_t launch_real_half_f64(const PassDesc &d, int variant, const void *in, void *out, hipStream_t s);

@@ -74,6 +74,7 @@ struct Options {
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
   int fuse2 = 1;             // pass pairs in one persistent launch, handed over through the Infinity Cache (fft_fused_f64.hip)
   int fuse2_ring = 8, fuse2_lag = 4;
+  int fuse2_group = 1;       // tiles per ticket
   int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
   int fuse2_kinds = 6;       // which pairs (bit = FusedKind): measured per kind, see make_fused2
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
@@ -92,6 +93,7 @@ struct Options {
     if (const char *s = getenv("GFFT_FUSE2_LAG")) fuse2_lag = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_KINDS")) fuse2_kinds = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_WLAYOUT")) fuse2_wlayout = atoi(s);
+    if (const char *s = getenv("GFFT_FUSE2_GROUP")) fuse2_group = atoi(s);
   }
 };
 Options &opts() {
@@ -361,10 +363,11 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
                  int64_t a_in_plane, int64_t b_out_plane, int64_t slot_bytes, Pass *out) {
   const int ring = opts().fuse2_ring, lag = opts().fuse2_lag;
   if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1) || planes < 2 * ring || lag < 1 || ring <= lag) return false;
-  if (!fused2_supported(kind, pl->precision, dA.n, dB.n)) return false;
-  int ta = 0, tb = 0;
   const int variant = opts().fuse2 == 2 ? 2 : 1;
-  if (fused2_tiles(kind, variant, dA, dB, &ta, &tb) || ta < 1 || tb < 1) return false;
+  // (fp64 only: the fp32 pairs measured slower than their stand-alone passes, fft_fused_f64.hip)
+  if (pl->precision != GFFT_F64 || !fused2_supported_f64(kind, variant, dA.n, dB.n)) return false;
+  int ta = 0, tb = 0;
+  if (fused2_tiles_f64(kind, variant, dA, dB, &ta, &tb) || ta < 1 || tb < 1) return false;
   // (hand-off accesses carry 32-bit byte offsets inside a slot; tickets are 32-bit)
   if (slot_bytes >= ((int64_t)1 << 31) || (double)planes * (ta + tb) >= 4.0e9) return false;
   Pass f = a;
@@ -381,6 +384,7 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   f.fused.tiles_b = tb;
   f.fused.ring = ring;
   f.fused.lag = lag;
+  f.fused.group = (opts().fuse2_group >= 1 && ta % opts().fuse2_group == 0 && tb % opts().fuse2_group == 0) ? opts().fuse2_group : 1;
   f.fused.a_in_plane = a_in_plane;
   f.fused.b_out_plane = b_out_plane;
   f.fused.slot_bytes = (int64_t)align256((size_t)slot_bytes);
@@ -1067,7 +1071,7 @@ int plan_fused3(gfft_plan_s *pl) {
   // loses what the fusion gains (1024^3 c128, tools/fused2_probe.py: 20.0 ms against 18.4 ms).
   const bool pair_cols_rows = !real && !tr && !flat_out && Pu == nc && opts().fuse2 &&
                               ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && n1 >= 2 * opts().fuse2_ring &&
-                              fused2_supported(FUSED_COLS_ROWS, prec, (int)n0, (int)n2);
+                              prec == GFFT_F64 && fused2_supported_f64(FUSED_COLS_ROWS, opts().fuse2 == 2 ? 2 : 1, (int)n0, (int)n2);
   const bool cols_first = !inverse && pair_cols_rows;
   // ... and the workspace then is W[i0][k1][c]: the stand-alone axis-1 pass stores on NEAR strides (stores are
   // what far strides hurt), the fused pair's axis-0 tiles read the far (pitched) ones
@@ -1245,6 +1249,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "fuse2_lag")) opts().fuse2_lag = value;
   else if (!strcmp(key, "fuse2_kinds")) opts().fuse2_kinds = value;
   else if (!strcmp(key, "fuse2_wlayout")) opts().fuse2_wlayout = value;
+  else if (!strcmp(key, "fuse2_group")) opts().fuse2_group = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;

@@ -22,27 +22,28 @@ def _restore():
     _opts(fuse2=1, fuse2_ring=8, fuse2_lag=4, fuse2_kinds=6)
 
 
-def _plans(shape, axes, fuse, ring=8, lag=4, kinds=7):
+def _plans(shape, axes, fuse, ring=8, lag=4, kinds=7, dt='D'):
     from mpi4py_fft_amd import fftw, zeros
     _opts(fuse2=fuse, fuse2_ring=ring, fuse2_lag=lag, fuse2_kinds=kinds)
-    a = zeros(shape, 'D')
+    a = zeros(shape, dt)
     f = fftw.fftn(a, axes=axes)
-    b = fftw.ifftn(f.output_array, axes=axes, output_array=zeros(shape, 'D'))
+    b = fftw.ifftn(f.output_array, axes=axes, output_array=zeros(shape, dt))
     return a, f, b
 
 
-@pytest.mark.parametrize('shape', [(1024, 16, 1024), (1024, 40, 1024)])
-def test_fused_3d_schedule_matches_the_unfused_one(shape):
+@pytest.mark.parametrize('shape,dt', [((1024, 16, 1024), 'D'), ((1024, 40, 1024), 'D')])
+def test_fused_3d_schedule_matches_the_unfused_one(shape, dt):
     from mpi4py_fft_amd import _lib
     rng = np.random.default_rng(5)
-    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape))
-    a0, f0, b0 = _plans(shape, (0, 1, 2), 0)
+    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dt)
+    eps = 1e-13 if dt == 'D' else 1e-5
+    a0, f0, b0 = _plans(shape, (0, 1, 2), 0, dt=dt)
     assert 'fused pair' not in _lib.engine().plan_describe(f0._plan)
     a0[...] = x
     want = np.asarray(f0.execute_scaled(a0, f0.output_array, 1.0)).copy()
     wantb = np.asarray(b0.execute_scaled(f0.output_array, b0.output_array, 1.0 / x.size)).copy()
-    ref = np.fft.fftn(x)
-    assert np.abs(want - ref).max() <= 2e-10 * np.abs(ref).max()
+    ref = np.fft.fftn(x.astype('D'))
+    assert np.abs(want - ref).max() <= (2e-10 if dt == 'D' else 2e-4) * np.abs(ref).max()
     for f in (f0, b0):
         f.destroy()
     # kinds 7: both directions run axis 1, then the fused pair [axis 0 -> rows]; kinds 1: only the mirror pair
@@ -50,7 +51,7 @@ def test_fused_3d_schedule_matches_the_unfused_one(shape):
     for ring, lag, kinds in ((8, 4, 7), (8, 1, 7), (5, 4, 7), (3, 2, 7), (16, 8, 7), (8, 4, 1), (4, 3, 1)):
         if shape[1] < 2 * ring:
             continue
-        a1, f1, b1 = _plans(shape, (0, 1, 2), 1, ring, lag, kinds)
+        a1, f1, b1 = _plans(shape, (0, 1, 2), 1, ring, lag, kinds, dt)
         desc = _lib.engine().plan_describe(f1._plan)
         assert ('fused pair (strided -> rows)' if kinds == 7 else 'fused pair (rows -> strided)') in desc, desc
         assert 'ring of %d slots' % ring in desc, desc
@@ -58,46 +59,50 @@ def test_fused_3d_schedule_matches_the_unfused_one(shape):
         a1[...] = x
         for rep in range(3):
             got = np.asarray(f1.execute_scaled(a1, f1.output_array, 1.0))
-            assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), (ring, lag, rep)
+            assert np.abs(got - want).max() <= eps * np.abs(want).max(), (ring, lag, rep)
             if rep == 0:
                 first = got.copy()
             assert np.array_equal(got, first), ('forward not reproducible', ring, lag, rep)
             back = np.asarray(b1.execute_scaled(f1.output_array, b1.output_array, 1.0 / x.size))
-            assert np.abs(back - wantb).max() <= 1e-13 * np.abs(wantb).max(), (ring, lag, rep)
-            assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
+            assert np.abs(back - wantb).max() <= eps * np.abs(wantb).max(), (ring, lag, rep)
+            assert np.abs(back - x).max() <= 10 * eps * np.abs(x).max()
         assert np.array_equal(np.asarray(a1), x)          # out of place: the input is preserved
         f1.destroy()
         b1.destroy()
 
 
-def test_fused_four_step_matches_the_two_launch_form():
+@pytest.mark.parametrize('shape,dt', [((32, 1 << 20), 'D')])
+def test_fused_four_step_matches_the_two_launch_form(shape, dt):
     from mpi4py_fft_amd import _lib
-    shape = (32, 1 << 20)
     rng = np.random.default_rng(6)
-    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape))
-    a0, f0, b0 = _plans(shape, (1,), 0)
+    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dt)
+    eps = 1e-13 if dt == 'D' else 1e-5
+    a0, f0, b0 = _plans(shape, (1,), 0, dt=dt)
     a0[...] = x
     want = np.asarray(f0.execute_scaled(a0, f0.output_array, 1.0)).copy()
-    ref = np.fft.fft(x[:2], axis=1)
-    assert np.abs(want[:2] - ref).max() <= 2e-10 * np.abs(ref).max()
+    ref = np.fft.fft(x[:2].astype('D'), axis=1)
+    assert np.abs(want[:2] - ref).max() <= (2e-10 if dt == 'D' else 2e-4) * np.abs(ref).max()
     f0.destroy()
     b0.destroy()
     for ring, lag in ((8, 4), (4, 1), (16, 8)):
-        a1, f1, b1 = _plans(shape, (1,), 1, ring, lag)
+        a1, f1, b1 = _plans(shape, (1,), 1, ring, lag, dt=dt)
         assert 'fused pair (four-step)' in _lib.engine().plan_describe(f1._plan)
         a1[...] = x
         for rep in range(3):
             got = np.asarray(f1.execute_scaled(a1, f1.output_array, 1.0))
-            assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), (ring, lag, rep)
+            assert np.abs(got - want).max() <= eps * np.abs(want).max(), (ring, lag, rep)
             back = np.asarray(b1.execute_scaled(f1.output_array, b1.output_array, 1.0 / shape[1]))
-            assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
+            assert np.abs(back - x).max() <= 10 * eps * np.abs(x).max()
         f1.destroy()
         b1.destroy()
 
 
-def test_short_batches_keep_the_unfused_plans():
+def test_shapes_without_a_paying_pair_keep_the_unfused_plans():
     from mpi4py_fft_amd import _lib
-    a, f, b = _plans((4, 1 << 20), (1,), 1)           # fewer planes than two rings: nothing to pipeline
-    assert 'fused pair' not in _lib.engine().plan_describe(f._plan)
-    f.destroy()
-    b.destroy()
+    # fewer planes than two rings: nothing to pipeline; fp32 and n = 512: measured slower fused (fft_fused_f64.hip)
+    for shape, axes, dt in (((4, 1 << 20), (1,), 'D'), ((32, 1 << 20), (1,), 'F'), ((512, 32, 512), (0, 1, 2), 'D'),
+                            ((1024, 32, 1024), (0, 1, 2), 'F')):
+        a, f, b = _plans(shape, axes, 1, dt=dt)
+        assert 'fused pair' not in _lib.engine().plan_describe(f._plan), (shape, dt)
+        f.destroy()
+        b.destroy()
