@@ -776,10 +776,13 @@ struct SysBuf {
 // FLAGS & 2048 / 4096: the output / input array is a hand-off buffer between workgroups of ONE launch
 // (fused kernels): stored with / loaded at SYSTEM scope (sc0 sc1: written through to the memory side,
 // never served from a possibly stale L2 line), plain complex accesses only; see fft_fused2_kernel.
-template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int FLAGS, int MODE, bool BIGTW, int... RADS>
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `after_loads`: called once per tile by every thread, after the tile's loads have been issued and before its
+// first butterfly (the fused kernel settles the previous tile's hand-off there, behind the new loads)
+template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int FLAGS, int MODE, bool BIGTW, int... RADS, typename HOOK = NoHook>
 __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restrict__ in, void *__restrict__ out,
                                           unsigned char *smem, unsigned k_first, unsigned k_step, unsigned k_end,
-                                          unsigned xcd_base) {
+                                          unsigned xcd_base, HOOK &&after_loads = HOOK()) {
   static_assert(SPLIT || sizeof(real) == 4, "fp64 exchanges split planes");
   constexpr int NT = N / R;
   constexpr int WORD = SPLIT ? sizeof(real) : 2 * sizeof(real);
@@ -924,6 +927,7 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
 #pragma unroll
       for (int q = 0; q < R; ++q) v[q] = {0, 0};
     }
+    after_loads();
     // Launder the (loop-invariant) twiddle table pointer once per tile: otherwise LICM hoists every
     // stage's twiddle loads out of the tile loop and parks them in VGPRs for the whole kernel
     // (40 VGPRs at fp64 n=1024), costing a wave of occupancy per SIMD.
@@ -1155,8 +1159,9 @@ struct PassCfg {
   typedef real_ real;
   static constexpr int threads = T * (N / R);
   static constexpr size_t lds = (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real_) == 4)>::CS * (SPLIT ? sizeof(real_) : 2 * sizeof(real_));
-  static __device__ __forceinline__ void tile(const PassDesc &d, const void *in, void *out, unsigned char *smem, unsigned t) {
-    pow2_body<real_, N, R, T, COLS, SPLIT, FLAGS, MODE, BIGTW, RADS...>(d, in, out, smem, t, 1u, t + 1u, 0u);
+  template <typename HOOK>
+  static __device__ __forceinline__ void tile(const PassDesc &d, const void *in, void *out, unsigned char *smem, unsigned t, HOOK &&hook) {
+    pow2_body<real_, N, R, T, COLS, SPLIT, FLAGS, MODE, BIGTW, RADS...>(d, in, out, smem, t, 1u, t + 1u, 0u, hook);
   }
   static unsigned ntiles(const PassDesc &d) { return pow2_ntiles<T, COLS, BIGTW>(d); }
 };
@@ -1189,7 +1194,7 @@ __global__ void __launch_bounds__(A::threads, A::threads <= 512 ? 4 : 1)
 fft_fused2_kernel(PassDesc dA, PassDesc dB, FusedDesc f, const void *__restrict__ in, void *__restrict__ ring, void *__restrict__ out) {
   static_assert(A::threads == B::threads, "both passes of a fused pair run on one workgroup shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ unsigned tk[2];          // the ticket being worked on and the next one, drawn a tile ahead
+  __shared__ unsigned tk[4];          // [0], [1]: the ticket being worked on and the next one, drawn a tile ahead; [2]: a poll's result
   unsigned *done_a = f.ctr + 16, *done_b = f.ctr + 16 + f.planes;
   // (tickets count GROUPS of f.group consecutive tiles of one plane and pass)
   const unsigned grp = (unsigned)f.group;
@@ -1203,6 +1208,35 @@ fft_fused2_kernel(PassDesc dA, PassDesc dB, FusedDesc f, const void *__restrict_
   if (wave_of_thread0()) {
     if (threadIdx.x == 0) tk[0] = atomicAdd(&f.ctr[0], 1u);
   }
+  // An A tile's counter may only go up once its write-through stores are acknowledged.  Waiting for that at
+  // the end of the tile leaves the CU idle for a memory round trip; instead the tile leaves its counter OWED
+  // (`owed` = the plane) and the workgroup settles it from inside the NEXT tile, right behind that tile's
+  // loads (one s_waitcnt covers both) -- or before it starts polling a counter itself, so that it can never
+  // wait, directly or through others, for its own debt (f.defer = 0: settle at the end of the tile).
+  int owed = -1;
+  auto settle = [&]() {
+    if (owed >= 0) {
+      __builtin_amdgcn_s_waitcnt(0);         // every write-through store of this wave acknowledged ...
+      __syncthreads();                       // ... of every wave of the tile
+      if (wave_of_thread0()) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&done_a[owed], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      owed = -1;
+    }
+  };
+  // a counter that is already there costs one poll; one that is not: settle the debt first, then wait
+  auto await = [&](const unsigned *flag, unsigned want) {
+    if (owed >= 0) {
+      if (wave_of_thread0()) {
+        if (threadIdx.x == 0) tk[2] = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want ? 1u : 0u;
+      }
+      __syncthreads();
+      const bool there = __builtin_amdgcn_readfirstlane(tk[2]) != 0;
+      if (there) return;
+      settle();
+    }
+    fused_wait(flag, want, &f.ctr[1], f.spin_limit);
+  };
   for (unsigned it = 0;; ++it) {
     __syncthreads();
     const unsigned k = __builtin_amdgcn_readfirstlane(tk[it & 1]);
@@ -1227,24 +1261,24 @@ fft_fused2_kernel(PassDesc dA, PassDesc dB, FusedDesc f, const void *__restrict_
     char *slot = static_cast<char *>(ring) + (size_t)(p % (unsigned)f.ring) * f.slot_bytes;
     if (f.debug == 2) continue;
     if (is_a) {
-      if (p >= (unsigned)f.ring) fused_wait(&done_b[p - f.ring], tb, &f.ctr[1], f.spin_limit);
+      if (p >= (unsigned)f.ring) await(&done_b[p - f.ring], tb);
       if (f.debug != 3 && f.debug != 5)
-        for (unsigned g = 0; g < grp; ++g) A::tile(dA, static_cast<const char *>(in) + (size_t)p * f.a_in_plane, slot, smem, t * grp + g);
-      __builtin_amdgcn_s_waitcnt(0);         // every write-through store of this wave acknowledged ...
-      __syncthreads();                       // ... of every wave of the tile
-      if (wave_of_thread0()) {
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(&done_a[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+        for (unsigned g = 0; g < grp; ++g)
+          A::tile(dA, static_cast<const char *>(in) + (size_t)p * f.a_in_plane, slot, smem, t * grp + g, settle);
+      owed = (int)p;
+      if (!f.defer) settle();
     } else {
-      fused_wait(&done_a[p], ta, &f.ctr[1], f.spin_limit);
+      await(&done_a[p], ta);
       if (f.debug != 3 && f.debug != 4)
-        for (unsigned g = 0; g < grp; ++g) B::tile(dB, slot, static_cast<char *>(out) + (size_t)p * f.b_out_plane, smem, t * grp + g);
+        for (unsigned g = 0; g < grp; ++g)
+          B::tile(dB, slot, static_cast<char *>(out) + (size_t)p * f.b_out_plane, smem, t * grp + g, settle);
       __syncthreads();
       if (wave_of_thread0()) {
         if (threadIdx.x == 0) __hip_atomic_fetch_add(&done_b[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
+  settle();
 }
 
 // A wait that gave up means a plane was read before it was complete: make that loud.  One thread, enqueued

@@ -155,6 +155,7 @@ int pow2_grid_cap();
 // FUSED_FOURSTEP = the two passes of a four-step transform of length n * n
 struct FusedDesc {
   int planes, tiles_a, tiles_b, ring, lag;
+  int defer;                         // 1: an A tile's counter is settled from inside the workgroup's next tile (fft_fused2_kernel)
   int group;                         // tiles per ticket (divides tiles_a and tiles_b): fewer tickets, counters and acknowledgement waits per byte
   int64_t a_in_plane, b_out_plane;   // BYTES from one plane to the next on A's input / B's output side
   int64_t slot_bytes;

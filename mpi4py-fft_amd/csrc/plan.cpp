@@ -75,6 +75,7 @@ struct Options {
   int fuse2 = 1;             // pass pairs in one persistent launch, handed over through the Infinity Cache (fft_fused_f64.hip)
   int fuse2_ring = 8, fuse2_lag = 4;
   int fuse2_group = 1;       // tiles per ticket
+  int fuse2_defer = 0;       // settle an A tile's counter behind the next tile's loads (A/B)
   int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
   int fuse2_kinds = 6;       // which pairs (bit = FusedKind): measured per kind, see make_fused2
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
@@ -94,6 +95,7 @@ struct Options {
     if (const char *s = getenv("GFFT_FUSE2_KINDS")) fuse2_kinds = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_WLAYOUT")) fuse2_wlayout = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_GROUP")) fuse2_group = atoi(s);
+    if (const char *s = getenv("GFFT_FUSE2_DEFER")) fuse2_defer = atoi(s);
   }
 };
 Options &opts() {
@@ -384,6 +386,7 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   f.fused.tiles_b = tb;
   f.fused.ring = ring;
   f.fused.lag = lag;
+  f.fused.defer = opts().fuse2_defer ? 1 : 0;
   f.fused.group = (opts().fuse2_group >= 1 && ta % opts().fuse2_group == 0 && tb % opts().fuse2_group == 0) ? opts().fuse2_group : 1;
   f.fused.a_in_plane = a_in_plane;
   f.fused.b_out_plane = b_out_plane;
@@ -1250,6 +1253,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "fuse2_kinds")) opts().fuse2_kinds = value;
   else if (!strcmp(key, "fuse2_wlayout")) opts().fuse2_wlayout = value;
   else if (!strcmp(key, "fuse2_group")) opts().fuse2_group = value;
+  else if (!strcmp(key, "fuse2_defer")) opts().fuse2_defer = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
