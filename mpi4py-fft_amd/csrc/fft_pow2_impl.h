@@ -748,6 +748,9 @@ __device__ __host__ __forceinline__ unsigned pow2_ntiles(const PassDesc &d) {
 
 // Complex values at SYSTEM scope through raw buffer accesses (cache policy sc0 | sc1): element offsets
 // are 32-bit, i.e. the hand-off buffer a tile addresses stays below 4 GiB (one plane of a fused pair)
+#ifndef GFFT_HANDOFF_AUX
+#define GFFT_HANDOFF_AUX 17      // cache policy of the hand-off accesses: 17 = sc0 | sc1 (system scope), 16 = sc1 (agent scope)
+#endif
 struct SysBuf {
   __amdgpu_buffer_rsrc_t r;
   __device__ __forceinline__ explicit SysBuf(const void *base)
@@ -755,12 +758,12 @@ struct SysBuf {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
   template <typename real> __device__ __forceinline__ cx<real> ld(int64_t elem) const {
-    if constexpr (sizeof(real) == 8) return __builtin_bit_cast(cx<real>, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)elem * 16u, 0, 17));
-    else return __builtin_bit_cast(cx<real>, __builtin_amdgcn_raw_buffer_load_b64(r, (unsigned)elem * 8u, 0, 17));
+    if constexpr (sizeof(real) == 8) return __builtin_bit_cast(cx<real>, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)elem * 16u, 0, GFFT_HANDOFF_AUX));
+    else return __builtin_bit_cast(cx<real>, __builtin_amdgcn_raw_buffer_load_b64(r, (unsigned)elem * 8u, 0, GFFT_HANDOFF_AUX));
   }
   template <typename real> __device__ __forceinline__ void st(int64_t elem, cx<real> v) const {
-    if constexpr (sizeof(real) == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (unsigned)elem * 16u, 0, 17);
-    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, (unsigned)elem * 8u, 0, 17);
+    if constexpr (sizeof(real) == 8) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (unsigned)elem * 16u, 0, GFFT_HANDOFF_AUX);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, (unsigned)elem * 8u, 0, GFFT_HANDOFF_AUX);
   }
 };
 
