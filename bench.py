@@ -10,8 +10,11 @@ as it is.  Rank 0 prints ONE JSON line.
 `value` = whole-job GFLOP/s with the work model of BASELINE.md section 3 (5 N log2 N flops per
 1-D line => 1.6106e11 per 1024^3 transform, fwd + bwd per step), inputs resident in HBM before the
 timed region, barrier + device sync on both sides, max over ranks.  `roofline` is for the dominant
-kernel: algorithmic bytes per launch (one read + one write of the local array) / its mean launch
-duration from HIP events recorded on the launch stream inside the timed region.  `cpu_baseline`
+kernel: algorithmic bytes per launch (one read + one write of the local array per axis pass the
+launch performs -- the fused launch of DESIGN.md section 4.7 performs two) / its mean launch
+duration from HIP events recorded on the launch stream inside the timed region; that launch hands
+its intermediate over inside the Infinity Cache, which is how `achieved` can exceed the same-run
+streaming-copy ceiling (`hbm_copy_ceiling`).  `cpu_baseline`
 times the CPU path on this box's host cores on a bounded sample (N = 1 only): FFTW through its guru
 interface when a libfftw3 (or MKL's FFTW3 interface) can be loaded, else the oracle (pocketfft).
 
