@@ -15,6 +15,7 @@ template <typename C>
 static hipError_t launch_fused2_kind(int kind, const PassDesc &dA, const PassDesc &dB, const FusedDesc &f, const void *in,
                                      void *ring, void *out, hipStream_t s) {
   switch (kind) {
+    case FUSED_PLANES_2D:
     case FUSED_ROWS_COLS: return launch_fused2<typename C::RowsToRing, typename C::ColsFromRing>(dA, dB, f, in, ring, out, s);
     case FUSED_COLS_ROWS: return launch_fused2<typename C::ColsToRing, typename C::RowsFromRing>(dA, dB, f, in, ring, out, s);
     case FUSED_FOURSTEP: return launch_fused2<typename C::FourStepFirst, typename C::ColsFromRing>(dA, dB, f, in, ring, out, s);
@@ -27,6 +28,7 @@ static hipError_t launch_fused2_kind(int kind, const PassDesc &dA, const PassDes
 template <typename C>
 static int fused2_tiles_kind(int kind, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b) {
   switch (kind) {
+    case FUSED_PLANES_2D:
     case FUSED_ROWS_COLS: *tiles_a = (int)C::RowsToRing::ntiles(dA); *tiles_b = (int)C::ColsFromRing::ntiles(dB); return 0;
     case FUSED_COLS_ROWS: *tiles_a = (int)C::ColsToRing::ntiles(dA); *tiles_b = (int)C::RowsFromRing::ntiles(dB); return 0;
     case FUSED_FOURSTEP: *tiles_a = (int)C::FourStepFirst::ntiles(dA); *tiles_b = (int)C::ColsFromRing::ntiles(dB); return 0;

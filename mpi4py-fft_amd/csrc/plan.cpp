@@ -77,7 +77,7 @@ struct Options {
   int fuse2_group = 1;       // tiles per ticket
   int fuse2_defer = 0;       // settle an A tile's counter behind the next tile's loads (A/B)
   int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
-  int fuse2_kinds = 6;       // which pairs (bit = FusedKind): measured per kind, see make_fused2
+  int fuse2_kinds = 14;      // which pairs (bit = FusedKind): measured per kind, see make_fused2
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
   int64_t fused3_min_bytes = 32 << 20;
@@ -1329,6 +1329,27 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
     const bool inv = kind == GFFT_C2C_BACKWARD;
     for (int i = naxes - 1; i >= 0 && !rc; --i)
       rc = line(ax[i], MODE_C2C, inv, pl->sizes_in, pl->sizes_in, i == naxes - 1 ? BUF_IN : BUF_OUT, BUF_OUT);
+    // Batched 2-D transforms over the last two axes of a 3-D array -- the leading stage of a slab-decomposed
+    // PFFT with collapse=True, or fftn(axes=(1, 2)) --: [rows] -> [columns] plane by plane in one fused launch
+    // (FUSED_PLANES_2D: the [rows -> strided] kernels on planes whose rows are CONTIGUOUS, the case that pays;
+    // in the 3-D schedule the same pair would read rows scattered and stays off, plan_fused3)
+    if (!rc && ndims == 3 && naxes == 2 && ax[0] == 1 && ax[1] == 2 && pl->passes.size() == 2) {
+      const Pass &pr = pl->passes[0], &pc = pl->passes[1];
+      const int64_t n0 = sizes_in[0], n1 = sizes_in[1], n2 = sizes_in[2], esz = 2 * (int64_t)precision;
+      if (pr.kind == PK_FFT && pc.kind == PK_FFT && pr.regk && pc.regk && !pr.cols && pc.cols && !pr.d.tw_hi && !pc.d.tw_hi &&
+          n0 < ((int64_t)1 << 30)) {
+        int64_t P = n2;                                   // slot rows pitched off the power of two
+        if ((P * esz) % 2048 == 0) P += 256 / esz;
+        PassDesc dA = pr.d, dB = pc.d;
+        dA.batch = n1; dA.out_os = P;
+        dB.batch = n2; dB.in_os = 0; dB.out_os = 0; dB.in_es = P;
+        Pass f;
+        if (make_fused2(pl, FUSED_PLANES_2D, pr, pc, dA, dB, (int)n0, n1 * n2 * esz, n1 * n2 * esz, n1 * P * esz, &f)) {
+          pl->passes.clear();
+          pl->passes.push_back(f);
+        }
+      }
+    }
   } else if (kind == GFFT_R2C) {
     rc = line(last, MODE_R2C, false, pl->sizes_in, pl->sizes_out, BUF_IN, BUF_OUT);
     for (int i = naxes - 2; i >= 0 && !rc; --i)
@@ -1547,7 +1568,7 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
   static const char *kinds[] = {"", "embed", "mul-B", "extract"};
   if (p.kind == PK_FUSED2) {
     // two axis passes in one launch: the algorithmic bytes of both (one read + one write of the array each)
-    static const char *fk[] = {"fused rows+cols", "fused cols+rows", "fused four-step"};
+    static const char *fk[] = {"fused rows+cols", "fused cols+rows", "fused four-step", "fused 2-D rows+cols"};
     snprintf(buf, len, "%s n=%dx%d", fk[p.fused_kind], p.d.n, p.d2.n);
     if (bytes) *bytes = (double)p.fused.planes * 2.0 * pl->precision *
                         ((double)p.d.batch * 2.0 * p.d.n + (double)p.d2.batch * 2.0 * p.d2.n);
@@ -1900,7 +1921,7 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
   static const char *bufn[] = {"IN", "OUT", "WS", "FS", "AUX", "RING"};
   for (const Pass &p : pl->passes) {
     if (p.kind == PK_FUSED2) {
-      static const char *fk[] = {"rows -> strided", "strided -> rows", "four-step"};
+      static const char *fk[] = {"rows -> strided", "strided -> rows", "four-step", "2-D planes: rows -> strided"};
       snprintf(line, sizeof line, "  fused pair (%s) n=%d then n=%d: %d planes, %d + %d tiles per plane, ring of %d slots x %lld KiB, one persistent launch%s  %s -> %s\n",
                fk[p.fused_kind], p.d.n, p.d2.n, p.fused.planes, p.fused.tiles_a, p.fused.tiles_b, p.fused.ring,
                (long long)(p.fused.slot_bytes >> 10), p.carries_scale ? " [scale]" : "", bufn[p.src], bufn[p.dst]);

@@ -19,10 +19,10 @@ def _opts(**kw):
 @pytest.fixture(autouse=True)
 def _restore():
     yield
-    _opts(fuse2=1, fuse2_ring=8, fuse2_lag=4, fuse2_kinds=6)
+    _opts(fuse2=1, fuse2_ring=8, fuse2_lag=4, fuse2_kinds=14)
 
 
-def _plans(shape, axes, fuse, ring=8, lag=4, kinds=7, dt='D'):
+def _plans(shape, axes, fuse, ring=8, lag=4, kinds=15, dt='D'):
     from mpi4py_fft_amd import fftw, zeros
     _opts(fuse2=fuse, fuse2_ring=ring, fuse2_lag=lag, fuse2_kinds=kinds)
     a = zeros(shape, dt)
@@ -46,16 +46,16 @@ def test_fused_3d_schedule_matches_the_unfused_one(shape, dt):
     assert np.abs(want - ref).max() <= (2e-10 if dt == 'D' else 2e-4) * np.abs(ref).max()
     for f in (f0, b0):
         f.destroy()
-    # kinds 7: both directions run axis 1, then the fused pair [axis 0 -> rows]; kinds 1: only the mirror pair
+    # kinds 15: both directions run axis 1, then the fused pair [axis 0 -> rows]; kinds 1: only the mirror pair
     # [rows -> axis 0] exists, which the forward direction then takes (the backward one stays unfused)
-    for ring, lag, kinds in ((8, 4, 7), (8, 1, 7), (5, 4, 7), (3, 2, 7), (16, 8, 7), (8, 4, 1), (4, 3, 1)):
+    for ring, lag, kinds in ((8, 4, 15), (8, 1, 15), (5, 4, 15), (3, 2, 15), (16, 8, 15), (8, 4, 1), (4, 3, 1)):
         if shape[1] < 2 * ring:
             continue
         a1, f1, b1 = _plans(shape, (0, 1, 2), 1, ring, lag, kinds, dt)
         desc = _lib.engine().plan_describe(f1._plan)
-        assert ('fused pair (strided -> rows)' if kinds == 7 else 'fused pair (rows -> strided)') in desc, desc
+        assert ('fused pair (strided -> rows)' if kinds == 15 else 'fused pair (rows -> strided)') in desc, desc
         assert 'ring of %d slots' % ring in desc, desc
-        assert ('fused pair (strided -> rows)' in _lib.engine().plan_describe(b1._plan)) == (kinds == 7)
+        assert ('fused pair (strided -> rows)' in _lib.engine().plan_describe(b1._plan)) == (kinds == 15)
         a1[...] = x
         for rep in range(3):
             got = np.asarray(f1.execute_scaled(a1, f1.output_array, 1.0))
@@ -106,3 +106,32 @@ def test_shapes_without_a_paying_pair_keep_the_unfused_plans():
         assert 'fused pair' not in _lib.engine().plan_describe(f._plan), (shape, dt)
         f.destroy()
         b.destroy()
+
+
+def test_fused_batched_2d_transform():
+    """fftn over the last two axes of a 3-D array (the leading stage of a slab-decomposed PFFT with
+    collapse=True): [rows] -> [columns] plane by plane in one launch."""
+    from mpi4py_fft_amd import _lib
+    shape = (24, 1024, 1024)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    a0, f0, b0 = _plans(shape, (1, 2), 0)
+    a0[...] = x
+    want = np.asarray(f0.execute_scaled(a0, f0.output_array, 1.0)).copy()
+    ref = np.fft.fftn(x[:3], axes=(1, 2))
+    assert np.abs(want[:3] - ref).max() <= 2e-10 * np.abs(ref).max()
+    f0.destroy()
+    b0.destroy()
+    for ring, lag in ((8, 4), (4, 2), (12, 6)):
+        if shape[0] < 2 * ring:
+            continue
+        a1, f1, b1 = _plans(shape, (1, 2), 1, ring, lag)
+        assert 'fused pair (2-D planes' in _lib.engine().plan_describe(f1._plan)
+        a1[...] = x
+        for rep in range(3):
+            got = np.asarray(f1.execute_scaled(a1, f1.output_array, 1.0))
+            assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), (ring, lag, rep)
+            back = np.asarray(b1.execute_scaled(f1.output_array, b1.output_array, 1.0 / (1024 * 1024)))
+            assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
+        f1.destroy()
+        b1.destroy()
