@@ -135,3 +135,30 @@ def test_fused_batched_2d_transform():
             assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
         f1.destroy()
         b1.destroy()
+
+
+def test_fused_launch_replays_from_a_hip_graph():
+    """A fused launch is a memset of its counters, the persistent kernel and the one-thread check kernel: all
+    three capture into a HIP graph (after one warm-up execution, which allocates the ring) and replay."""
+    import torch
+    from mpi4py_fft_amd import _lib
+    shape = (1024, 16, 1024)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    a, f, b = _plans(shape, (0, 1, 2), 1)
+    assert 'fused pair' in _lib.engine().plan_describe(f._plan)
+    a[...] = x
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        want = f.execute_scaled(a, f.output_array, 1.0).tensor.clone()         # warm-up on the capture stream
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            f.execute_scaled(a, f.output_array, 1.0)
+        for rep in range(3):
+            f.output_array.tensor.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(f.output_array.tensor, want), rep
+    f.destroy()
+    b.destroy()
