@@ -70,7 +70,11 @@ int gfft_version(void);
 int gfft_device_count(int *count);          /* hipGetDeviceCount; GFFT_ERR_NO_DEVICE if none */
 int gfft_device_name(int device, char *buf, size_t len);
 /* tunables consulted when a plan is created: "grid_cap", "variant_rows", "variant_cols",
- * "force_generic", "fused3", "profile" (also readable from the environment as GFFT_<UPPERCASE NAME>) */
+ * "force_generic", "fused3", "profile" (also readable from the environment as GFFT_<UPPERCASE NAME>);
+ * "fuse2" (1: pass pairs as one persistent launch through the Infinity Cache where a pair exists and pays,
+ * 0: stand-alone passes), with "fuse2_ring" / "fuse2_lag" (slots of the hand-off ring / planes the producer
+ * runs ahead: 8 / 4), "fuse2_kinds" (bit mask of pair kinds) and the A/B switches "fuse2_wlayout",
+ * "fuse2_group", "fuse2_defer" (DESIGN.md section 4.7); GFFT_FUSE2_DEBUG=1 prints a fused launch's counters */
 int gfft_set_option(const char *key, int value);
 
 /* ---- serial multi-axis transform plan ------------------------------------------------
