@@ -55,13 +55,13 @@ int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &
   return fused2_tiles_kind<FusedCfgs<double, 1024>>(kind, dA, dB, tiles_a, tiles_b);
 }
 
-hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, const FusedDesc &f, const void *in,
-                             void *ring, void *out, hipStream_t s) {
+hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs,
+                             const FusedDesc &f, const void *in, void *ring, void *out, hipStream_t s) {
 #ifdef GFFT_VARIANTS
-  if (variant == 2) return launch_fused2_kind<Fused1024x8>(kind, dA, dB, f, in, ring, out, s);
+  if (variant == 2) return launch_fused2_kind<Fused1024x8>(kind, dA, dB, dev_descs, f, in, ring, out, s);
 #endif
   (void)variant;
-  return launch_fused2_kind<FusedCfgs<double, 1024>>(kind, dA, dB, f, in, ring, out, s);
+  return launch_fused2_kind<FusedCfgs<double, 1024>>(kind, dA, dB, dev_descs, f, in, ring, out, s);
 }
 
 }  // namespace gfft

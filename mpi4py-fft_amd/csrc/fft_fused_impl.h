@@ -12,13 +12,13 @@ namespace gfft {
 template <typename real, int N> struct FusedCfgs;
 
 template <typename C>
-static hipError_t launch_fused2_kind(int kind, const PassDesc &dA, const PassDesc &dB, const FusedDesc &f, const void *in,
-                                     void *ring, void *out, hipStream_t s) {
+static hipError_t launch_fused2_kind(int kind, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev, const FusedDesc &f,
+                                     const void *in, void *ring, void *out, hipStream_t s) {
   switch (kind) {
     case FUSED_PLANES_2D:
-    case FUSED_ROWS_COLS: return launch_fused2<typename C::RowsToRing, typename C::ColsFromRing>(dA, dB, f, in, ring, out, s);
-    case FUSED_COLS_ROWS: return launch_fused2<typename C::ColsToRing, typename C::RowsFromRing>(dA, dB, f, in, ring, out, s);
-    case FUSED_FOURSTEP: return launch_fused2<typename C::FourStepFirst, typename C::ColsFromRing>(dA, dB, f, in, ring, out, s);
+    case FUSED_ROWS_COLS: return launch_fused2<typename C::RowsToRing, typename C::ColsFromRing>(dA, dB, dev, f, in, ring, out, s);
+    case FUSED_COLS_ROWS: return launch_fused2<typename C::ColsToRing, typename C::RowsFromRing>(dA, dB, dev, f, in, ring, out, s);
+    case FUSED_FOURSTEP: return launch_fused2<typename C::FourStepFirst, typename C::ColsFromRing>(dA, dB, dev, f, in, ring, out, s);
   }
   return hipErrorInvalidValue;
 }

@@ -785,339 +785,16 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int FLAGS, int MODE, bool BIGTW, int... RADS, typename HOOK = NoHook>
 __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restrict__ in, void *__restrict__ out,
                                           unsigned char *smem, unsigned k_first, unsigned k_step, unsigned k_end,
-                                          unsigned xcd_base, HOOK &&after_loads = HOOK()) {
-  static_assert(SPLIT || sizeof(real) == 4, "fp64 exchanges split planes");
-  constexpr int NT = N / R;
-  constexpr int WORD = SPLIT ? sizeof(real) : 2 * sizeof(real);
-  constexpr int CS = Lds<N, COLS, T, WORD == 4>::CS;
-  // packed-real modes move complex pairs on both sides; the Hermitian pass is in the kernel body
-  constexpr bool HALF = MODE == MODE_R2C_H || MODE == MODE_C2R_H;
-  constexpr int IOMODE = HALF ? MODE_C2C : MODE;
-  static_assert(!HALF || (!COLS && !BIGTW && !(FLAGS & 32)), "packed-real modes: contiguous axis only");
-  static_assert(!(FLAGS & (2048 | 4096)) || (MODE == MODE_C2C && !(FLAGS & 16)), "hand-off buffers: plain complex passes");
-  // FLAGS & 8192: natural layouts on both sides (fused pairs) -- the exchange-buffer layout fields of the
-  // descriptor (blocks, tile-major lines / columns, flat tiles, masked columns) are compile-time zeros, so
-  // neither their loads nor the arithmetic on them survive (the fused kernels hold TWO descriptors)
-  constexpr bool PLAIN = (FLAGS & 8192) != 0;
-  const auto L_in_tlg = PLAIN ? decltype(d.in_tlg)(0) : d.in_tlg;
-  const auto L_out_tlg = PLAIN ? decltype(d.out_tlg)(0) : d.out_tlg;
-  const auto L_in_lgp = PLAIN ? decltype(d.in_lgp)(0) : d.in_lgp;
-  const auto L_out_lgp = PLAIN ? decltype(d.out_lgp)(0) : d.out_lgp;
-  const auto L_in_jump = PLAIN ? decltype(d.in_jump)(0) : d.in_jump;
-  const auto L_out_jump = PLAIN ? decltype(d.out_jump)(0) : d.out_jump;
-  const auto L_in_ilg = PLAIN ? decltype(d.in_ilg)(0) : d.in_ilg;
-  const auto L_out_ilg = PLAIN ? decltype(d.out_ilg)(0) : d.out_ilg;
-  const auto L_fl_bw = PLAIN ? decltype(d.fl_bw)(0) : d.fl_bw;
-  const auto L_flat = PLAIN ? decltype(d.flat)(0) : d.flat;
-  const auto L_inner_ld = PLAIN ? decltype(d.inner_ld)(0) : d.inner_ld;
-  const auto L_inner_st = PLAIN ? decltype(d.inner_st)(0) : d.inner_st;
-  const auto L_out_pad = PLAIN ? decltype(d.out_pad)(0) : d.out_pad;
-  [[maybe_unused]] const SysBuf sys_in(in), sys_out(out);
-  const cx<real> *tw = reinterpret_cast<const cx<real> *>(d.tw);
-  const int tid = threadIdx.x;
-  const int c = COLS ? (tid % T) : (tid / NT);
-  const int t = COLS ? (tid / T) : (tid % NT);
-  void *col = smem + (size_t)c * CS * WORD;
-  const unsigned batch = (unsigned)d.batch, inner = (unsigned)d.inner, mid = (unsigned)d.mid;
-  // COLS: a tile is T adjacent columns of ONE row of the batch (never straddles a row, so
-  // segments keep their alignment when `inner` is not a multiple of T, e.g. 513-wide half
-  // spectra); the (row, chunk) split is workgroup-uniform scalar arithmetic.
-  // ROWS: the batch is flat (each column is itself a contiguous row of the array).
-  // (four-step passes -- BIGTW -- run their columns along `mid` and use the flat form too.)
-  constexpr bool ROWTILES = COLS && !BIGTW;
-  const unsigned flat_cols = mid * inner;                       // L_flat: columns per outer index
-  const unsigned chunks = ROWTILES ? ((L_flat ? flat_cols : inner) + T - 1) / T : 1;
-  const unsigned ntiles = ROWTILES ? (L_flat ? batch / flat_cols : batch / inner) * chunks : (batch + T - 1) / T;
-  const real sy_in = d.conj_in ? (real)-1 : (real)1;
-  const real sx_out = (real)(MODE == MODE_R2C_H ? 0.5 * d.scale : d.scale);   // (the Hermitian pass leaves 2 X)
-  const real sy_out = d.conj_out ? -sx_out : sx_out;
-  // per thread (tile-major lines, PassDesc::in_tlg / out_tlg: tile index and lane within the tile)
-  const int64_t t_in = (!COLS && L_in_tlg) ? (int64_t)(t >> L_in_tlg) * d.in_tS + (t & ((1 << L_in_tlg) - 1)) : (int64_t)t * d.in_es;
-  const int64_t t_out = (!COLS && L_out_tlg) ? (int64_t)(t >> L_out_tlg) * d.out_tS + (t & ((1 << L_out_tlg) - 1)) : (int64_t)t * d.out_es;
-  // fused padding / truncation: distance between the two halves of the padded spectrum (uniform)
-  const int64_t pad_shift_in = (FLAGS & 16) ? (int64_t)(d.n - d.tr_N) * d.in_es : 0;
-  const int64_t pad_shift_out = (FLAGS & 16) ? (int64_t)(d.n - d.tr_N) * d.out_es : 0;
-  const int64_t q_in = (!COLS && L_in_tlg) ? (int64_t)(NT >> L_in_tlg) * d.in_tS : (int64_t)NT * d.in_es;     // uniform steps
-  const int64_t q_out = (!COLS && L_out_tlg) ? (int64_t)(NT >> L_out_tlg) * d.out_tS : (int64_t)NT * d.out_es;
-
-  for (unsigned k = k_first; k < k_end; k += k_step) {
-    const unsigned tile = xcd_base + k;
-    if (tile >= ntiles) continue;
-    // The thread's row index, laundered once per tile: everything derived from it inside the loop
-    // (twiddle-table offsets k*step, LDS slots, mirrored c2r offsets) is loop invariant, and
-    // hoisted it sits in -- or spills from -- 2 VGPRs per use for the whole kernel.
-    int tl = t;
-    asm volatile("" : "+v"(tl));
-    bool valid, valid_st;
-    unsigned o, m, i;
-    if constexpr (ROWTILES) {
-      const unsigned row = tile / chunks, j = tile - row * chunks;
-      if (L_flat) {
-        // tiles over the flattened (m, i) index of one outer slab: per-lane row and column
-        o = row;
-        unsigned J = j * T + c;
-        valid = valid_st = J < flat_cols;
-        if (!valid) J = 0;
-        m = J / inner;
-        i = J - m * inner;
-      } else {
-        i = j * T + c;
-        valid = i < (L_inner_ld ? (unsigned)L_inner_ld : inner);          // columns that are read
-        valid_st = i < (L_inner_st ? (unsigned)L_inner_st : inner);       // columns that are written
-        if (!(valid || valid_st)) i = 0;
-        o = row / mid;
-        m = row - o * mid;
-      }
-    } else {
-      const unsigned b = tile * T + c;
-      valid = valid_st = b < batch;
-      const unsigned bb = valid ? b : 0;
-      const unsigned bm = bb / inner;
-      i = bb - bm * inner;
-      o = bm / mid;
-      m = bm - o * mid;
-    }
-    int64_t in0 = (int64_t)o * d.in_os + (int64_t)m * d.in_ms, out0 = (int64_t)o * d.out_os + (int64_t)m * d.out_ms;
-    if constexpr (COLS) {
-      // (tile-major columns of an exchange buffer, PassDesc::in_ilg / out_ilg; flat tiles over rows
-      // stored as body + leftover columns, PassDesc::fl_bw)
-      if (L_fl_bw && i >= (unsigned)L_fl_bw) in0 = (int64_t)o * d.in_os + d.fl_tail + (int64_t)m * d.fl_tail_ms + (i - (unsigned)L_fl_bw);
-      else in0 += L_in_ilg ? (int64_t)(i >> L_in_ilg) * d.in_iS + (i & ((1u << L_in_ilg) - 1)) : (int64_t)i * d.in_is;
-      out0 += L_out_ilg ? (int64_t)(i >> L_out_ilg) * d.out_iS + (i & ((1u << L_out_ilg) - 1)) : (int64_t)i * d.out_is;
-    } else {
-      in0 += (int64_t)i * d.in_is;
-      out0 += (int64_t)i * d.out_is;
-    }
-    [[maybe_unused]] const unsigned row_ub = o * inner + i;     // FLAGS & 128: row of the exchange buffer
-    cx<real> v[R];
-    // Split layouts: thread slots e = t + q*NT advance by NT, and a block of the cut axis holds
-    // (R >> lgp) * NT entries, so block boundaries fall between the same q for every thread: a
-    // workgroup-uniform counter adds the block jump to the (uniform) step -- scalar work only.
-    const int seg_in = R >> L_in_lgp, seg_out = R >> L_out_lgp;
-    if (valid) {
-      int64_t idx = in0 + t_in;
-      int cnt = 0;
-#pragma unroll
-      for (int q = 0; q < R; ++q) {
-        if constexpr ((FLAGS & 16) != 0) {
-          if constexpr (HALF && (FLAGS & 64) != 0) {
-            // zero-padded half spectrum (libfft.py:298-311): entries >= tr_n are zero, the last kept
-            // entry of an even truncated length is a real Nyquist value taken at half weight
-            const int e = tl + q * NT;
-            const bool ok = e < d.tr_n, nyq = d.tr_even && e == d.tr_n - 1;
-            if constexpr ((FLAGS & 128) != 0) v[q] = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, o, i, ok ? e : 0)];
-            else v[q] = reinterpret_cast<const cx<real> *>(in)[ok ? idx : in0];
-            v[q].x *= ok ? (nyq ? (real)0.5 : (real)1) : (real)0;
-            v[q].y *= (ok && !nyq) ? (real)1 : (real)0;
-          } else if constexpr ((FLAGS & 64) != 0) v[q] = tile_load_pad<real, IOMODE>(d, in, in0, idx, pad_shift_in, tl + q * NT, sy_in);
-          else v[q] = tile_load<real, IOMODE, false>(d, in, in0, idx, tl + q * NT, sy_in);
-        } else if constexpr (MODE == MODE_C2R_H && (FLAGS & 128) != 0) {
-          v[q] = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, o, i, tl + q * NT)];
-        } else if constexpr ((FLAGS & 4096) != 0) {
-          v[q] = sys_in.template ld<real>(idx);
-          v[q].y *= sy_in;
-        } else {
-          v[q] = tile_load<real, IOMODE, (FLAGS & 1) != 0>(d, in, in0, idx, tl + q * NT, sy_in);
-        }
-        int64_t step = q_in;
-        if (++cnt == seg_in) {
-          cnt = 0;
-          step += L_in_jump;
-        }
-        idx += step;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < R; ++q) v[q] = {0, 0};
-    }
-    after_loads();
-    // Launder the (loop-invariant) twiddle table pointer once per tile: otherwise LICM hoists every
-    // stage's twiddle loads out of the tile loop and parks them in VGPRs for the whole kernel
-    // (40 VGPRs at fp64 n=1024), costing a wave of occupancy per SIMD.
-    const cx<real> *twl = tw;
-    asm volatile("" : "+s"(twl));
-    [[maybe_unused]] const cx<real> *rtw = reinterpret_cast<const cx<real> *>(d.rtw);
-    if constexpr (HALF) asm volatile("" : "+s"(rtw));
-    if constexpr (MODE == MODE_C2R_H) {
-      // Hermitian half spectrum X[0..N] -> packed spectrum Z[0..N-1], conjugated for the
-      // inverse-by-conjugation butterflies.  Imaginary parts of X[0] and X[N] are ignored, as FFTW's
-      // c2r does.
-      cx<real> top = {0, 0};
-      if (tl == 0) {
-        if constexpr ((FLAGS & 128) != 0 && !(FLAGS & 16)) {
-          if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[uneven_offset(d, row_ub, o, i, N)].x;
-        } else if constexpr (!(FLAGS & 64)) {
-          if (valid) top.x = reinterpret_cast<const cx<real> *>(in)[in0 + (int64_t)N * d.in_es].x;
-        }
-        v[0].y = 0;
-      }
-      const cx<real> wt = rtw[tl];
-      mirror_pass<real, N, R, SPLIT>(v, tl, col, top, [&](int q, cx<real> p) {
-        const cx<real> w = mirror_twiddle<real, R>(wt, q);         // (c, s) = exp(-2 pi i e / 2N)
-        const cx<real> a = {v[q].x + p.x, v[q].y - p.y};           // X + conj P
-        const cx<real> b = {v[q].x - p.x, v[q].y + p.y};           // X - conj P
-        const cx<real> wb = {w.x * b.x + w.y * b.y, w.x * b.y - w.y * b.x};   // conj(w) b
-        v[q] = {a.x - wb.y, -(a.y + wb.x)};                        // conj(a + i conj(w) b)
-      });
-      // Pin the line here: left free, the scheduler interleaves this pass with the first butterfly
-      // stage and keeps both generations of the line alive (fp32 R = 16: 175 VGPRs -> 107).
-#pragma unroll
-      for (int q = 0; q < R; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y));
-    }
-    // (the row index `tl` is laundered for the same reason: fp32 n=1024 R=32 104 bytes of scratch
-    // -> none; fp64 n=1024 R=16 T=16 127 -> 107 VGPRs)
-    if constexpr (!(FLAGS & 4)) Stage<real, N, R, SPLIT, 1, RADS...>::run(v, tl, col, twl);
-    if constexpr (!HALF && !(FLAGS & 256)) {      // (FLAGS & 256: A/B switch, no pin)
-      // pin the line between the last stage and the stores: interleaved by the scheduler the two
-      // keep extra copies alive (fp32 n = 1024 R = 32 with the truncating store: 145 spilled VGPRs
-      // -> 11; the plain fp32 R = 32 pass: 127 VGPRs + 4 spilled -> 121, none)
-#pragma unroll
-      for (int q = 0; q < R; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y));
-    }
-    [[maybe_unused]] cx<real> z0 = v[0];
-    if constexpr (MODE == MODE_R2C_H) {
-      // packed spectrum Z[0..N-1] -> Hermitian half spectrum X[0..N-1] in place (twice the values:
-      // the factor 1/2 rides on the store scale); X[N] = Re Z[0] - Im Z[0] is stored by thread 0
-      const cx<real> wt = rtw[tl];
-      mirror_pass<real, N, R, SPLIT>(v, tl, col, v[0], [&](int q, cx<real> p) {
-        const cx<real> w = mirror_twiddle<real, R>(wt, q);
-        const cx<real> a = {v[q].x + p.x, v[q].y - p.y};           // Z + conj P
-        const cx<real> b = {v[q].x - p.x, v[q].y + p.y};           // Z - conj P
-        const cx<real> wb = cmul(w, b);
-        v[q] = {a.x + wb.y, a.y - wb.x};                           // a - i w b
-      });
-    }
-    if constexpr ((FLAGS & 16) != 0 && !(FLAGS & 64) && MODE == MODE_C2C && !HALF) {
-      // complex truncation with even N: entries h = N/2 and n - h of the padded spectrum both land
-      // on truncated entry h (libfft.py:281-284).  They live in different threads: pass the upper
-      // one through LDS.  (uniform branch: every thread of the workgroup takes it or none does)
-      if (d.tr_even) {
-        cx<real> *fold = reinterpret_cast<cx<real> *>(smem);
-        const int h = d.tr_N >> 1;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < R; ++q)
-          if (tl + q * NT == d.n - h) fold[c] = v[q];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < R; ++q)
-          if (tl + q * NT == h) v[q] = v[q] + fold[c];
-      }
-    }
-    if constexpr ((FLAGS & 32) != 0) {
-      // Transposing store.  Loads ran with lanes along T adjacent columns (T*16-byte segments of the
-      // strided input); the output of each column is one contiguous line, so storing in the same
-      // mapping would write T short runs per instruction.  Finish the element-wise work here
-      // (four-step twiddle, scale), transpose the thread grid through LDS -- thread (c, t) hands
-      // its R values to thread (c' = tid / NT, t' = tid % NT), same slots e = t' + q*NT -- and
-      // store with lanes along e: whole 64-lane rows of one output line.
-      static_assert(COLS && SPLIT && BIGTW && MODE == MODE_C2C, "transposing store: first four-step pass");
-      if constexpr (BIGTW) {
-        // four-step twiddle W^(m e), e = t + q NT: two table look-ups per THREAD -- W^(m t) and
-        // W^(m NT) -- and the powers of the second by squaring (q is a compile-time index, so entry q
-        // costs at most log2 R multiplications); one look-up pair per ELEMENT tripled the load
-        // instructions of this pass (data + 2 gathers)
-        const auto big = [&](unsigned x) {
-          const cx<real> a = reinterpret_cast<const cx<real> *>(d.tw_hi)[x >> d.tw_L];
-          const cx<real> b = reinterpret_cast<const cx<real> *>(d.tw_lo)[x & ((1u << d.tw_L) - 1)];
-          return cmul(a, b);
-        };
-        constexpr int LG = R >= 32 ? 5 : (R >= 16 ? 4 : (R >= 8 ? 3 : 2));
-        static_assert((1 << LG) >= R, "powers of the step twiddle");
-        const cx<real> w0 = big(m * (unsigned)tl);
-        cx<real> sp[LG];
-        sp[0] = big(m * (unsigned)NT);
-#pragma unroll
-        for (int k = 1; k < LG; ++k) sp[k] = cmul(sp[k - 1], sp[k - 1]);
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-          cx<real> w = w0;
-#pragma unroll
-          for (int k = 0; k < LG; ++k)
-            if ((q >> k) & 1) w = cmul(w, sp[k]);
-          v[q] = cmul(v[q], w);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < R; ++q) {
-        v[q].x *= sx_out;
-        v[q].y *= sy_out;
-      }
-      constexpr bool PAD = is_pow2_c(N);
-      const int c2 = tid / NT, t2 = tid % NT;
-      real *w = reinterpret_cast<real *>(col);
-      real *r = reinterpret_cast<real *>(smem + (size_t)c2 * CS * WORD);
-      const int wb = pad_slot<PAD>(t), rb = pad_slot<PAD>(t2);
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < R; ++q) w[wb + pad_slot<PAD>(q * NT)] = v[q].x;
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < R; ++q) v[q].x = r[rb + pad_slot<PAD>(q * NT)];
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < R; ++q) w[wb + pad_slot<PAD>(q * NT)] = v[q].y;
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < R; ++q) v[q].y = r[rb + pad_slot<PAD>(q * NT)];
-      // the column this thread now stores (flat tiling, as the BIGTW passes use)
-      const unsigned b2 = tile * T + c2;
-      if (b2 < batch) {
-        const unsigned bm2 = b2 / inner, i2 = b2 - bm2 * inner, o2 = bm2 / mid, m2 = bm2 - o2 * mid;
-        int64_t idx = (int64_t)o2 * d.out_os + (int64_t)m2 * d.out_ms + (int64_t)i2 * d.out_is +
-                      (int64_t)t2 * d.out_es;
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-          if constexpr ((FLAGS & 2048) != 0) sys_out.template st<real>(idx, v[q]);
-          else stc<real, false>(reinterpret_cast<cx<real> *>(out) + idx, v[q]);
-          idx += q_out;
-        }
-      }
-    } else if (valid_st) {
-      int64_t idx = out0 + t_out;
-      int cnt = 0;
-#pragma unroll
-      for (int q = 0; q < R; ++q) {
-        if constexpr ((FLAGS & 16) != 0) {
-          if constexpr (HALF && !(FLAGS & 64)) {
-            // truncated half spectrum (libfft.py:286-296): keep entries < tr_n; the last one of an
-            // even truncated length becomes a real Nyquist value of twice the weight
-            const int e = tl + q * NT;
-            if (e < d.tr_n) {
-              const bool nyq = d.tr_even && e == d.tr_n - 1;
-              int64_t at = idx;
-              if constexpr ((FLAGS & 128) != 0) at = uneven_offset(d, row_ub, o, i, e);
-              reinterpret_cast<cx<real> *>(out)[at] = {v[q].x * (nyq ? 2 * sx_out : sx_out), nyq ? (real)0 : v[q].y * sy_out};
-            }
-          } else if constexpr (!(FLAGS & 64)) tile_store_trunc<real, IOMODE>(d, out, idx, pad_shift_out, tl + q * NT, v[q], sx_out, sy_out);
-          else tile_store<real, IOMODE, false, false>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
-        } else if constexpr (MODE == MODE_R2C_H && (FLAGS & 128) != 0) {
-          reinterpret_cast<cx<real> *>(out)[uneven_offset(d, row_ub, o, i, tl + q * NT)] = {v[q].x * sx_out, v[q].y * sy_out};
-        } else if constexpr ((FLAGS & 2048) != 0) {
-          static_assert(!(FLAGS & 2048) || !BIGTW || (FLAGS & 32), "hand-off store: no per-element four-step twiddle");
-          sys_out.template st<real>(idx, cx<real>{v[q].x * sx_out, v[q].y * sy_out});
-        } else {
-          tile_store<real, IOMODE, BIGTW, (FLAGS & 2) != 0>(d, out, idx, tl + q * NT, m, v[q], sx_out, sy_out);
-        }
-        int64_t step = q_out;
-        if (++cnt == seg_out) {
-          cnt = 0;
-          step += L_out_jump;
-        }
-        idx += step;
-      }
-      if constexpr (MODE == MODE_R2C_H && (FLAGS & 128) != 0 && !(FLAGS & 16)) {
-        if (tl == 0)
-          reinterpret_cast<cx<real> *>(out)[uneven_offset(d, row_ub, o, i, N)] = {(z0.x - z0.y) * 2 * sx_out, 0};
-      } else if constexpr (MODE == MODE_R2C_H && !(FLAGS & 16)) {
-        // X[N] from thread 0, followed by L_out_pad zeros from its neighbours: one coalesced store
-        // that completes the row's last 128-byte line when the output rows are pitched
-        if (tl <= L_out_pad)
-          reinterpret_cast<cx<real> *>(out)[out0 + (int64_t)(N + tl) * d.out_es] =
-              {tl == 0 ? (z0.x - z0.y) * 2 * sx_out : (real)0, 0};
-      }
-    }
-  }
+                                          unsigned xcd_base, double scale, HOOK &&after_loads = HOOK()) {
+#define GFFT_SCALE scale
+#define GFFT_TILE_LOOP for (unsigned k = k_first; k < k_end; k += k_step)
+#define GFFT_TILE_INDEX const unsigned tile = xcd_base + k;
+#define GFFT_AFTER_LOADS after_loads();
+#include "fft_pow2_body.inc"
+#undef GFFT_TILE_LOOP
+#undef GFFT_TILE_INDEX
+#undef GFFT_AFTER_LOADS
+#undef GFFT_SCALE
 }
 
 template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int MODE, bool BIGTW, int... RADS>
@@ -1129,12 +806,17 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
   // the dispatcher (block b -> XCD b % 8), so XCD x walks its own contiguous eighth of the tiles:
   // neighbouring column chunks then share one L2, which merges their partial cache lines when
   // rows are not line aligned (e.g. 513-wide half spectra).  Placement only affects speed.
-  const unsigned ntiles = pow2_ntiles<T, COLS, BIGTW>(d);
-  const unsigned per_xcd = (ntiles + 7) / 8;
+  const unsigned per_xcd = (pow2_ntiles<T, COLS, BIGTW>(d) + 7) / 8;
   const unsigned kstep = d.swizzle ? gridDim.x / 8 : gridDim.x;
-  const unsigned kend = d.swizzle ? per_xcd : ntiles;
-  pow2_body<real, N, R, T, COLS, SPLIT, FLAGS, MODE, BIGTW, RADS...>(
-      d, in, out, smem, d.swizzle ? blockIdx.x / 8 : blockIdx.x, kstep, kend, d.swizzle ? (blockIdx.x % 8) * per_xcd : 0u);
+#define GFFT_TILE_LOOP for (unsigned k = d.swizzle ? blockIdx.x / 8 : blockIdx.x; k < (d.swizzle ? per_xcd : ntiles); k += kstep)
+#define GFFT_TILE_INDEX const unsigned tile = d.swizzle ? (blockIdx.x % 8) * per_xcd + k : k;
+#define GFFT_AFTER_LOADS
+#define GFFT_SCALE d.scale
+#include "fft_pow2_body.inc"
+#undef GFFT_TILE_LOOP
+#undef GFFT_TILE_INDEX
+#undef GFFT_AFTER_LOADS
+#undef GFFT_SCALE
 }
 
 // ---- two dependent passes in ONE persistent launch, handed over through the Infinity Cache -----------
@@ -1163,8 +845,9 @@ struct PassCfg {
   static constexpr int threads = T * (N / R);
   static constexpr size_t lds = (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real_) == 4)>::CS * (SPLIT ? sizeof(real_) : 2 * sizeof(real_));
   template <typename HOOK>
-  static __device__ __forceinline__ void tile(const PassDesc &d, const void *in, void *out, unsigned char *smem, unsigned t, HOOK &&hook) {
-    pow2_body<real_, N, R, T, COLS, SPLIT, FLAGS, MODE, BIGTW, RADS...>(d, in, out, smem, t, 1u, t + 1u, 0u, hook);
+  static __device__ __forceinline__ void tile(const PassDesc &d, const void *in, void *out, unsigned char *smem, unsigned t,
+                                              double scale, HOOK &&hook) {
+    pow2_body<real_, N, R, T, COLS, SPLIT, FLAGS, MODE, BIGTW, RADS...>(d, in, out, smem, t, 1u, t + 1u, 0u, scale, hook);
   }
   static unsigned ntiles(const PassDesc &d) { return pow2_ntiles<T, COLS, BIGTW>(d); }
 };
@@ -1194,8 +877,12 @@ __device__ __forceinline__ void fused_wait(const unsigned *flag, unsigned want, 
 // register budget must allow: at most 128 VGPRs, i.e. 4 waves per SIMD)
 template <typename A, typename B>
 __global__ void __launch_bounds__(A::threads, A::threads <= 512 ? 4 : 1)
-fft_fused2_kernel(PassDesc dA, PassDesc dB, FusedDesc f, const void *__restrict__ in, void *__restrict__ ring, void *__restrict__ out) {
+fft_fused2_kernel(const PassDesc *__restrict__ descs, FusedDesc f, double scale_a, double scale_b, const void *__restrict__ in,
+                  void *__restrict__ ring, void *__restrict__ out) {
   static_assert(A::threads == B::threads, "both passes of a fused pair run on one workgroup shape");
+  // (the two pass descriptors live in device memory: as by-value kernel arguments handed on by reference the
+  // compiler materialised them whole, 200 spilled SGPRs; from memory every field is a scalar load at its use)
+  const PassDesc &dA = descs[0], &dB = descs[1];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ unsigned tk[4];          // [0], [1]: the ticket being worked on and the next one, drawn a tile ahead; [2]: a poll's result
   unsigned *done_a = f.ctr + 16, *done_b = f.ctr + 16 + f.planes;
@@ -1267,14 +954,14 @@ fft_fused2_kernel(PassDesc dA, PassDesc dB, FusedDesc f, const void *__restrict_
       if (p >= (unsigned)f.ring) await(&done_b[p - f.ring], tb);
       if (f.debug != 3 && f.debug != 5)
         for (unsigned g = 0; g < grp; ++g)
-          A::tile(dA, static_cast<const char *>(in) + (size_t)p * f.a_in_plane, slot, smem, t * grp + g, settle);
+          A::tile(dA, static_cast<const char *>(in) + (size_t)p * f.a_in_plane, slot, smem, t * grp + g, scale_a, settle);
       owed = (int)p;
       if (!f.defer) settle();
     } else {
       await(&done_a[p], ta);
       if (f.debug != 3 && f.debug != 4)
         for (unsigned g = 0; g < grp; ++g)
-          B::tile(dB, slot, static_cast<char *>(out) + (size_t)p * f.b_out_plane, smem, t * grp + g, settle);
+          B::tile(dB, slot, static_cast<char *>(out) + (size_t)p * f.b_out_plane, smem, t * grp + g, scale_b, settle);
       __syncthreads();
       if (wave_of_thread0()) {
         if (threadIdx.x == 0) __hip_atomic_fetch_add(&done_b[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1292,8 +979,8 @@ __global__ void fused2_check_kernel(const unsigned *ctr) {
 }
 
 template <typename A, typename B>
-hipError_t launch_fused2(const PassDesc &dA, const PassDesc &dB, const FusedDesc &f, const void *in, void *ring, void *out,
-                         hipStream_t s) {
+hipError_t launch_fused2(const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs, const FusedDesc &f, const void *in,
+                         void *ring, void *out, hipStream_t s) {
   constexpr size_t lds = A::lds > B::lds ? A::lds : B::lds;
   static_assert(lds <= 160 * 1024, "LDS budget");
   if (f.lag < 1 || f.ring <= f.lag || f.planes < 1 || f.tiles_a != (int)A::ntiles(dA) || f.tiles_b != (int)B::ntiles(dB) ||
@@ -1317,7 +1004,7 @@ hipError_t launch_fused2(const PassDesc &dA, const PassDesc &dB, const FusedDesc
   // as many workgroups as fit the CUs at once (the exchange tile of a 1024-thread workgroup fills the LDS,
   // two 512-thread ones share it): persistent, tickets do the load balancing
   const int per_cu = (A::threads <= 512 && 2 * lds + 1024 <= 160 * 1024) ? 2 : 1;
-  hipLaunchKernelGGL(kern, dim3(cus * per_cu), dim3(A::threads), lds, s, dA, dB, f, in, ring, out);
+  hipLaunchKernelGGL(kern, dim3(cus * per_cu), dim3(A::threads), lds, s, dev_descs, f, dA.scale, dB.scale, in, ring, out);
   if (!f.debug) hipLaunchKernelGGL(fused2_check_kernel<A>, dim3(1), dim3(1), 0, s, f.ctr);
   return hipGetLastError();
 }

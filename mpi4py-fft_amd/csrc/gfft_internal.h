@@ -168,8 +168,9 @@ enum FusedKind { FUSED_ROWS_COLS = 0, FUSED_COLS_ROWS = 1, FUSED_FOURSTEP = 2, F
 // workgroups per CU
 bool fused2_supported_f64(int kind, int variant, int n_a, int n_b);
 int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b);
-hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, const FusedDesc &f, const void *in,
-                             void *ring, void *out, hipStream_t s);
+// dev_descs: {dA, dB} in device memory (uploaded when the plan was made; the scale factors travel as arguments)
+hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs,
+                             const FusedDesc &f, const void *in, void *ring, void *out, hipStream_t s);
 
 // packed-real row kernels (fft_real_*.hip): d.n = complex length = half the real length
 bool real_half_supported(int n_complex);

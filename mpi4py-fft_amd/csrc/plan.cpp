@@ -213,6 +213,7 @@ struct Pass {
   PassDesc d2{};
   FusedDesc fused{};
   int fused_kind = 0, fused_variant = 1;
+  PassDesc *dev_descs = nullptr;     // {d, d2} in device memory (owned by the plan: gfft_plan_s::device_allocs)
   double bytes2 = 0;                 // algorithmic bytes of pass B (gfft_plan_pass_info reports A + B)
 };
 
@@ -353,6 +354,8 @@ struct gfft_plan_s {
   bool fused3 = false;
   std::vector<int64_t> trunc;                  // gfft_plan_create_padded: kept entries per axis (else empty)
   std::vector<std::vector<hipEvent_t>> prof;   // per execute: events before pass 0 and after each pass
+  std::vector<void *> device_allocs;            // small device buffers the plan owns (descriptors of fused launches)
+  ~gfft_plan_s() { for (void *q : device_allocs) (void)hipFree(q); }
 };
 
 namespace {
@@ -395,6 +398,13 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   f.fused.spin_limit = 1u << 24;
   f.fused.debug = 0;
   need(pl, BUF_RING, (size_t)ring * (size_t)f.fused.slot_bytes + align256((size_t)(16 + 2 * planes) * sizeof(unsigned)));
+  // the kernel reads the two descriptors from device memory (the scale factors travel as kernel arguments)
+  const PassDesc both[2] = {dA, dB};
+  void *dev = nullptr;
+  if (hipMalloc(&dev, sizeof both) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipMemcpy(dev, both, sizeof both, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dev); return false; }
+  pl->device_allocs.push_back(dev);
+  f.dev_descs = static_cast<PassDesc *>(dev);
   *out = f;
   return true;
 }
@@ -1518,7 +1528,7 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
       f.ctr = reinterpret_cast<unsigned *>(ring + (size_t)f.ring * (size_t)f.slot_bytes);
       static const int debug = getenv("GFFT_FUSE2_DEBUG") ? atoi(getenv("GFFT_FUSE2_DEBUG")) : 0;
       if (debug) { f.spin_limit = 1u << 12; f.debug = (unsigned)debug; }
-      HIP_TRY(launch_fused2_f64(p.fused_kind, p.fused_variant, d, d2, f, bufs[p.src], ring, bufs[p.dst], s));
+      HIP_TRY(launch_fused2_f64(p.fused_kind, p.fused_variant, d, d2, p.dev_descs, f, bufs[p.src], ring, bufs[p.dst], s));
       if (debug) {      // developer aid: the launch's counters (tickets drawn, waits given up, tiles per plane)
         HIP_TRY(hipStreamSynchronize(s));
         std::vector<unsigned> h(16 + 2 * (size_t)f.planes);
