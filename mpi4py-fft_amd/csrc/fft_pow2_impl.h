@@ -590,9 +590,11 @@ __device__ __forceinline__ cx<real> tile_load_pad(const PassDesc &d, const void 
     const int h = d.tr_N >> 1;
     const bool lo = e <= h, hi = h > 0 && e >= d.n - h;
     const bool half = d.tr_even && (e == h || e == d.n - h);
-    int64_t at = lo ? idx : (hi ? idx - shift : base);
-    // kept entries stored as equal blocks of an all-to-all buffer (PassDesc::tr_jump)
-    if (d.tr_jump && (lo || hi)) at += (int64_t)((lo ? e : e - (d.n - d.tr_N)) >> d.tr_lgper) * d.tr_jump;
+    // kept entries stored as equal blocks of an all-to-all buffer (PassDesc::tr_jump): a 32-bit block offset
+    // (gfft_plan_set_split / gfft_plan_create_guru_padded keep it below 2^31 elements) -- computed in 64 bits
+    // behind a test of tr_jump it cost the zero-padding kernels 16 VGPRs
+    const int blk = ((lo ? e : e - (d.n - d.tr_N)) >> d.tr_lgper) * (int)d.tr_jump;
+    const int64_t at = (lo ? idx : (hi ? idx - shift : base)) + ((lo || hi) ? blk : 0);
     v = reinterpret_cast<const cx<real> *>(in)[at];
     const real f = (lo || hi) ? (half ? (real)0.5 : (real)1) : (real)0;
     v.x *= f;
@@ -616,9 +618,8 @@ __device__ __forceinline__ void tile_store_trunc(const PassDesc &d, void *__rest
     const bool lo = e <= h, hi = h > 0 && e >= d.n - h;
     if (d.tr_even && e == d.n - h) return;            // folded onto entry h by the kernel body
     if (lo || hi) {
-      int64_t at = lo ? idx : idx - shift;
-      if (d.tr_jump) at += (int64_t)((lo ? e : e - (d.n - d.tr_N)) >> d.tr_lgper) * d.tr_jump;
-      p[at] = {v.x * sx, v.y * sy};
+      const int blk = ((lo ? e : e - (d.n - d.tr_N)) >> d.tr_lgper) * (int)d.tr_jump;
+      p[(lo ? idx : idx - shift) + blk] = {v.x * sx, v.y * sy};
     }
   }
 }

@@ -1705,6 +1705,8 @@ int gfft_plan_set_split(gfft_plan pl, int side, int nblocks) {
     if (nblocks > 1 && !is_pow2(per)) return fail(GFFT_ERR_UNSUPPORTED, "kept entries per block must be a power of two");
     int lgper = 0;
     while (((int64_t)1 << lgper) < per) ++lgper;
+    if (nblocks > 1 && (double)(outer - 1) * per * inner * (nblocks - 1) >= 2147483648.0)
+      return fail(GFFT_ERR_UNSUPPORTED, "blocked truncated side beyond 2^31 elements");      // (32-bit block offsets in the kernels)
     p.d.tr_lgper = nblocks > 1 ? lgper : 0;
     p.d.tr_jump = nblocks > 1 ? (outer - 1) * per * inner : 0;
     (side == 0 ? p.d.in_os : p.d.out_os) = per * inner;
@@ -1804,6 +1806,10 @@ int gfft_plan_create_guru_padded(gfft_plan *plan, int precision, int kind, const
       const int64_t per = n_keep / nb;
       d.tr_lgper = lg2((int)per);
       d.tr_jump = (tr_side == 1 ? out_block_stride - per * dim->os : in_block_stride - per * dim->is);
+      if (std::fabs((double)d.tr_jump) * (nb - 1) >= 2147483648.0) {        // (32-bit block offsets in the kernels)
+        delete pl;
+        return fail(GFFT_ERR_UNSUPPORTED, "blocked truncated side beyond 2^31 elements");
+      }
     }
   }
   p.blocks[0] = in_blocks;   p.bstride[0] = in_block_stride;
