@@ -30,11 +30,11 @@ template <> struct FusedCfgs<double, 1024> {
 // CU leaves between load, butterflies and store; measured slower (21.0 / 20.4 ms against 18.5 / 19.1 per
 // 1024^3 direction: its hand-off accesses are 128-byte pieces at system scope)
 struct Fused1024x8 {
-  typedef PassCfg<double, 1024, 16, 8, false, true, 2048 | 8192, MODE_C2C, false, 16, 16, 4> RowsToRing;
-  typedef PassCfg<double, 1024, 16, 8, false, true, 4096 | 8192, MODE_C2C, false, 16, 16, 4> RowsFromRing;
-  typedef PassCfg<double, 1024, 16, 8, true, true, 8 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> ColsToRing;
-  typedef PassCfg<double, 1024, 16, 8, true, true, 8 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> ColsFromRing;
-  typedef PassCfg<double, 1024, 16, 8, true, true, 32 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirst;
+  typedef PassCfg<double, 1024, 16, 8, false, true, 1 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> RowsToRing;
+  typedef PassCfg<double, 1024, 16, 8, false, true, 2 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> RowsFromRing;
+  typedef PassCfg<double, 1024, 16, 8, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> ColsToRing;
+  typedef PassCfg<double, 1024, 16, 8, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> ColsFromRing;
+  typedef PassCfg<double, 1024, 16, 8, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirst;
 };
 #endif
 

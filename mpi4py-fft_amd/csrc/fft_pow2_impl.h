@@ -396,14 +396,49 @@ __device__ __forceinline__ void twiddle(cx<real> *v, int k, const cx<real> *__re
 }
 
 // ---- one Stockham stage + exchange, recursing over the radix list -------------------------
-template <typename real, int N, int R, bool SPLIT, int Ns, int... RADS> struct Stage;
+// (trace builds, GFFT_FUSE2_TRACE: thread 0 of a fused launch's workgroup stamps the wall clock at phase
+// boundaries inside the tile as well -- see GFFT_TRACE_STAMP below, tools/fused2_trace.py)
+#ifdef GFFT_FUSE2_TRACE
+static __shared__ unsigned long long *gfft_trace_slot;
+#define GFFT_PHASE(i)                                                                  \
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x) == 0) {                               \
+    if (threadIdx.x == 0 && gfft_trace_slot) gfft_trace_slot[i] = wall_clock64();      \
+  }
+#else
+#define GFFT_PHASE(i)
+#endif
 
-template <typename real, int N, int R, bool SPLIT, int Ns> struct Stage<real, N, R, SPLIT, Ns> {
+// Synchronisation between the write and the read side of an LDS exchange.  A row pass whose rows are at most
+// one wavefront wide (N / R threads per row, 64 % (N / R) == 0) keeps every row -- its registers AND its LDS
+// region -- inside ONE wave: DS instructions of a wave execute in order, so the exchange needs no s_barrier
+// at all, only the compiler kept from reordering (WL = true).  The waves of the workgroup then drift apart
+// and one wave's loads / stores overlap another's butterflies and exchanges -- which the lock step of 14
+// barriers per tile forbade (tools/fused2_trace.py: 2 x 4-5 us of a 22 us tile sat in the exchanges).
+template <bool WL> __device__ __forceinline__ void tile_sync() {
+  if constexpr (WL) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
+// (Strided passes -- lanes along T adjacent columns, a column spread over all waves -- keep their barriers.
+// Their LAST exchange alone can be made wave local -- it only moves values inside groups of r_last threads
+// N / R / r_last apart, so with a wave's 64 / T row-threads chosen that far apart three of its four barriers go
+// -- and was, as a compile-time variant: same-box A/B on fp64, far-axis stand-alone passes 2-7 % faster
+// ((1024,256,512) axis 0 0.98 -> 0.89-0.95 ms), the near-stride pass of 1024^3 8 % slower (a wave's four
+// 256-byte rows then lie 16 rows apart), fp32 and the fused pair slower; as a per-launch choice inside one
+// kernel it cost 16 VGPRs + 100 bytes of scratch.  Not kept.)
+template <int N, int R, bool COLS> struct WaveLocal { static constexpr bool value = !COLS && (64 % (N / R)) == 0; };
+
+template <typename real, int N, int R, bool SPLIT, bool WL, int Ns, int... RADS> struct Stage;
+
+template <typename real, int N, int R, bool SPLIT, bool WL, int Ns> struct Stage<real, N, R, SPLIT, WL, Ns> {
   static __device__ __forceinline__ void run(cx<real> *, int, void *, const cx<real> *) {}
 };
 
-template <typename real, int N, int R, bool SPLIT, int Ns, int r, int... REST>
-struct Stage<real, N, R, SPLIT, Ns, r, REST...> {
+template <typename real, int N, int R, bool SPLIT, bool WL, int Ns, int r, int... REST>
+struct Stage<real, N, R, SPLIT, WL, Ns, r, REST...> {
   static constexpr int NT = N / R;   // threads per column
   static constexpr int NB = R / r;   // butterflies per thread in this stage
   static __device__ __forceinline__ void run(cx<real> *v, int t, void *col,
@@ -418,6 +453,8 @@ struct Stage<real, N, R, SPLIT, Ns, r, REST...> {
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) dft<real, r, NB>(v + i);
+    [[maybe_unused]] constexpr int PH = Ns == 1 ? 8 : (Ns <= 32 ? 10 : 12);
+    GFFT_PHASE(PH)
     if constexpr (sizeof...(REST) > 0) {
       // scatter: butterfly j = t + i*NT, output m -> index j0 + m*Ns, j0 = (j/Ns)*Ns*r + j%Ns.
       // pad_slot(j0 + m*Ns) == pad_slot(j0) + woff(m) and pad_slot(t + q*NT) == pad_slot(t) + roff(q)
@@ -432,31 +469,31 @@ struct Stage<real, N, R, SPLIT, Ns, r, REST...> {
       const int rbase = pad_slot<PAD>(t);
       if constexpr (SPLIT) {
         real *w = reinterpret_cast<real *>(col);
-        __syncthreads();
+        tile_sync<WL>();
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
           for (int m = 0; m < r; ++m) w[wbase[i] + pad_slot<PAD>(m * Ns)] = v[i + m * NB].x;
-        __syncthreads();
+        tile_sync<WL>();
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q].x = w[rbase + pad_slot<PAD>(q * NT)];
-        __syncthreads();
+        tile_sync<WL>();
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
           for (int m = 0; m < r; ++m) w[wbase[i] + pad_slot<PAD>(m * Ns)] = v[i + m * NB].y;
-        __syncthreads();
+        tile_sync<WL>();
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q].y = w[rbase + pad_slot<PAD>(q * NT)];
       } else {
         float2 *w = reinterpret_cast<float2 *>(col);
-        __syncthreads();
+        tile_sync<WL>();
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
           for (int m = 0; m < r; ++m)
             w[wbase[i] + pad_slot<PAD>(m * Ns)] = make_float2(v[i + m * NB].x, v[i + m * NB].y);
-        __syncthreads();
+        tile_sync<WL>();
 #pragma unroll
         for (int q = 0; q < R; ++q) {
           float2 f = w[rbase + pad_slot<PAD>(q * NT)];
@@ -464,7 +501,8 @@ struct Stage<real, N, R, SPLIT, Ns, r, REST...> {
           v[q].y = f.y;
         }
       }
-      Stage<real, N, R, SPLIT, Ns * r, REST...>::run(v, t, col, tw);
+      GFFT_PHASE(PH + 1)
+      Stage<real, N, R, SPLIT, WL, Ns * r, REST...>::run(v, t, col, tw);
     }
   }
 };
@@ -675,25 +713,25 @@ template <typename real, int R> __device__ __forceinline__ cx<real> mirror_twidd
   return {wt.x * c - wt.y * s, wt.x * s + wt.y * c};
 }
 
-template <typename real, int N, int R, bool SPLIT, typename F>
+template <typename real, int N, int R, bool SPLIT, bool WL, typename F>
 __device__ __forceinline__ void mirror_pass(cx<real> *v, int t, void *col, cx<real> top, F &&combine) {
   constexpr int NT = N / R;
   constexpr bool PAD = is_pow2_c(N);
   if constexpr (SPLIT) {
     real *w = reinterpret_cast<real *>(col);
     real px[R];
-    __syncthreads();
+    tile_sync<WL>();
 #pragma unroll
     for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = v[q].x;
     if (t == 0) w[pad_slot<PAD>(N)] = top.x;
-    __syncthreads();
+    tile_sync<WL>();
 #pragma unroll
     for (int q = 0; q < R; ++q) px[q] = w[pad_slot<PAD>(N - (t + q * NT))];
-    __syncthreads();
+    tile_sync<WL>();
 #pragma unroll
     for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = v[q].y;
     if (t == 0) w[pad_slot<PAD>(N)] = top.y;
-    __syncthreads();
+    tile_sync<WL>();
 #pragma unroll
     for (int q = 0; q < R; ++q) {
       const real py = w[pad_slot<PAD>(N - (t + q * NT))];
@@ -701,11 +739,11 @@ __device__ __forceinline__ void mirror_pass(cx<real> *v, int t, void *col, cx<re
     }
   } else {
     float2 *w = reinterpret_cast<float2 *>(col);
-    __syncthreads();
+    tile_sync<WL>();
 #pragma unroll
     for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = make_float2(v[q].x, v[q].y);
     if (t == 0) w[pad_slot<PAD>(N)] = make_float2(top.x, top.y);
-    __syncthreads();
+    tile_sync<WL>();
 #pragma unroll
     for (int q = 0; q < R; ++q) {
       const float2 p = w[pad_slot<PAD>(N - (t + q * NT))];
@@ -874,6 +912,18 @@ __device__ __forceinline__ void fused_wait(const unsigned *flag, unsigned want, 
   __syncthreads();
 }
 
+// GFFT_FUSE2_TRACE (a developer build, `make TRACE=1`): every workgroup stamps the 100 MHz wall clock at the
+// phase boundaries of its first 96 tickets into a buffer behind the counters (tools/fused2_trace.py).
+#ifdef GFFT_FUSE2_TRACE
+#define GFFT_TRACE_SLOTS 96
+#define GFFT_TRACE_STAMP(i)                                                                                    \
+  if (it < GFFT_TRACE_SLOTS && wave_of_thread0()) {                                                              \
+    if (threadIdx.x == 0) trace[((size_t)blockIdx.x * GFFT_TRACE_SLOTS + it) * 16 + (i)] = wall_clock64();      \
+  }
+#else
+#define GFFT_TRACE_STAMP(i)
+#endif
+
 // (workgroups of <= 512 threads: two per CU -- one computes while the other loads / stores --, which the
 // register budget must allow: at most 128 VGPRs, i.e. 4 waves per SIMD)
 template <typename A, typename B>
@@ -892,6 +942,10 @@ fft_fused2_kernel(const PassDesc *__restrict__ descs, FusedDesc f, double scale_
   const unsigned ta = (unsigned)f.tiles_a / grp, tb = (unsigned)f.tiles_b / grp, per_pair = ta + tb;
   const unsigned head = (unsigned)f.lag * ta, pairs = (unsigned)(f.planes - f.lag);
   const unsigned total = (unsigned)f.planes * per_pair;
+#ifdef GFFT_FUSE2_TRACE
+  unsigned long long *trace = reinterpret_cast<unsigned long long *>(f.ctr + ((16 + 2 * (size_t)f.planes + 63) & ~(size_t)63));
+  unsigned it = 0;
+#endif
   // The next ticket is drawn while the current tile is being worked on (the atomic's round trip, ~2 us,
   // would otherwise sit between two tiles with the CU idle).  A workgroup then holds two tickets, the
   // lower one in work: the lowest unfinished ticket of the launch is still always in work somewhere, so
@@ -928,10 +982,26 @@ fft_fused2_kernel(const PassDesc *__restrict__ descs, FusedDesc f, double scale_
     }
     fused_wait(flag, want, &f.ctr[1], f.spin_limit);
   };
+#ifdef GFFT_FUSE2_TRACE
+  auto hook = [&]() {
+    settle();
+    __builtin_amdgcn_s_waitcnt(0);           // (trace builds: the stamp marks the loads' ARRIVAL)
+    GFFT_TRACE_STAMP(2)
+  };
+  for (it = 0;; ++it) {
+#else
+  auto &hook = settle;
   for (unsigned it = 0;; ++it) {
+#endif
+#ifdef GFFT_FUSE2_TRACE
+    if (wave_of_thread0()) {
+      if (threadIdx.x == 0) gfft_trace_slot = it < GFFT_TRACE_SLOTS ? trace + ((size_t)blockIdx.x * GFFT_TRACE_SLOTS + it) * 16 : nullptr;
+    }
+#endif
     __syncthreads();
     const unsigned k = __builtin_amdgcn_readfirstlane(tk[it & 1]);
     if (k >= total) break;
+    GFFT_TRACE_STAMP(0)
     if (wave_of_thread0()) {
       if (threadIdx.x == 0) tk[(it + 1) & 1] = atomicAdd(&f.ctr[0], 1u);
     }
@@ -951,26 +1021,46 @@ fft_fused2_kernel(const PassDesc *__restrict__ descs, FusedDesc f, double scale_
     }
     char *slot = static_cast<char *>(ring) + (size_t)(p % (unsigned)f.ring) * f.slot_bytes;
     if (f.debug == 2) continue;
+#ifdef GFFT_FUSE2_TRACE
+    if (it < GFFT_TRACE_SLOTS && wave_of_thread0()) {
+      if (threadIdx.x == 0) trace[((size_t)blockIdx.x * GFFT_TRACE_SLOTS + it) * 16 + 7] = ((unsigned long long)k << 1) | (is_a ? 1u : 0u);
+    }
+#endif
     if (is_a) {
       if (p >= (unsigned)f.ring) await(&done_b[p - f.ring], tb);
+      GFFT_TRACE_STAMP(1)
       if (f.debug != 3 && f.debug != 5)
         for (unsigned g = 0; g < grp; ++g)
-          A::tile(dA, static_cast<const char *>(in) + (size_t)p * f.a_in_plane, slot, smem, t * grp + g, scale_a, settle);
+          A::tile(dA, static_cast<const char *>(in) + (size_t)p * f.a_in_plane, slot, smem, t * grp + g, scale_a, hook);
+      GFFT_TRACE_STAMP(3)
       owed = (int)p;
       if (!f.defer) settle();
+      GFFT_TRACE_STAMP(4)
     } else {
       await(&done_a[p], ta);
+      GFFT_TRACE_STAMP(1)
       if (f.debug != 3 && f.debug != 4)
         for (unsigned g = 0; g < grp; ++g)
-          B::tile(dB, slot, static_cast<char *>(out) + (size_t)p * f.b_out_plane, smem, t * grp + g, scale_b, settle);
+          B::tile(dB, slot, static_cast<char *>(out) + (size_t)p * f.b_out_plane, smem, t * grp + g, scale_b, hook);
+      GFFT_TRACE_STAMP(3)
       __syncthreads();
       if (wave_of_thread0()) {
         if (threadIdx.x == 0) __hip_atomic_fetch_add(&done_b[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      GFFT_TRACE_STAMP(4)
     }
   }
   settle();
 }
+
+// (Tried and not kept: the same launch with every WAVE on its own clock -- wave 0 draws tickets and polls the
+// plane counters and posts both in a ring of LDS slots, each wave counts its arrived loads / acknowledged
+// stores into the slot and the last one raises the plane counter, no workgroup barrier outside the strided
+// tiles' exchanges -- so that a wave that is done starts the next tile's loads while its neighbours compute.
+// Correct, 124 VGPRs, and 6 % SLOWER per step (34.33 -> 36.48 ms, profiles/r03_ab_fuse2_perwave.txt): the
+// strided tiles' first exchange barrier just absorbs the drift (8.8 -> 11.2 us), i.e. the CU is not waiting
+// for latency that overlap could hide.  A first form with every wave polling and raising the plane counters
+// itself took 136 ms per step: sixteen memory-side atomics per tile on one hot word.)
 
 // A wait that gave up means a plane was read before it was complete: make that loud.  One thread, enqueued
 // behind the fused launch; the trap surfaces as a launch failure at the stream's next synchronisation.

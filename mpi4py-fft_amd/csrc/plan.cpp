@@ -397,9 +397,13 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   f.fused.ctr = nullptr;
   f.fused.spin_limit = 1u << 24;
   f.fused.debug = 0;
-  need(pl, BUF_RING, (size_t)ring * (size_t)f.fused.slot_bytes + align256((size_t)(16 + 2 * planes) * sizeof(unsigned)));
+  size_t ctr_bytes = align256((size_t)(16 + 2 * planes) * sizeof(unsigned));
+#ifdef GFFT_FUSE2_TRACE
+  ctr_bytes += 256 + (size_t)1024 * 96 * 16 * sizeof(unsigned long long);       // (fft_pow2_impl.h, GFFT_TRACE_STAMP)
+#endif
+  need(pl, BUF_RING, (size_t)ring * (size_t)f.fused.slot_bytes + ctr_bytes);
   // the kernel reads the two descriptors from device memory (the scale factors travel as kernel arguments)
-  const PassDesc both[2] = {dA, dB};
+  const PassDesc both[2] = {f.d, f.d2};
   void *dev = nullptr;
   if (hipMalloc(&dev, sizeof both) != hipSuccess) { (void)hipGetLastError(); return false; }
   if (hipMemcpy(dev, both, sizeof both, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(dev); return false; }
@@ -1537,6 +1541,14 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
         for (int i = 0; i < f.planes; ++i) { sa += h[16 + i]; sb += h[16 + f.planes + i]; }
         fprintf(stderr, "[gfft fuse2] kind %d planes %d tiles %d+%d ring %d lag %d: tickets %u, waits given up %u, A tiles %llu, B tiles %llu\n",
                 p.fused_kind, f.planes, f.tiles_a, f.tiles_b, f.ring, f.lag, h[0], h[1], sa, sb);
+#ifdef GFFT_FUSE2_TRACE
+        if (const char *path = getenv("GFFT_FUSE2_TRACE_FILE")) {
+          std::vector<unsigned long long> tr((size_t)1024 * 96 * 16);
+          const size_t off = ((16 + 2 * (size_t)f.planes + 63) & ~(size_t)63) * sizeof(unsigned);
+          HIP_TRY(hipMemcpy(tr.data(), reinterpret_cast<char *>(f.ctr) + off, tr.size() * sizeof(tr[0]), hipMemcpyDeviceToHost));
+          if (FILE *fp = fopen(path, "wb")) { fwrite(tr.data(), sizeof(tr[0]), tr.size(), fp); fclose(fp); }
+        }
+#endif
       }
       HIP_TRY(mark());
       continue;
