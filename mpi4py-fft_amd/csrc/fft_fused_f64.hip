@@ -2,7 +2,7 @@
 // handed over through a ring buffer that lives in the Infinity Cache (fft_pow2_impl.h, fft_fused2_kernel).
 //   [rows n] -> [strided n]   passes 1 + 2 of a complex 3-D schedule, forward order (plan.cpp plan_fused3; built, not the default)
 //   [strided n] -> [rows n]   passes 2 + 3 of the complex 3-D schedule as both directions run it
-//   four-step n x n           both passes of a length-n^2 transform (n = 1024: BASELINE config C2)
+//   four-step n x n           both passes of a length-n^2 transform (n = 1024: BASELINE config C2), second pass strided or rows
 // Every pass is the plan of the stand-alone tables (fft_pow2_f64.hip) on 1024-thread workgroups -- the row
 // pass therefore takes 16 rows per workgroup instead of 4 -- with the hand-off side at system scope.
 #include "fft_fused_impl.h"
@@ -18,6 +18,10 @@ template <> struct FusedCfgs<double, 1024> {
   typedef PassCfg<double, 1024, 16, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> ColsToRing;
   typedef PassCfg<double, 1024, 16, 16, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> ColsFromRing;
   typedef PassCfg<double, 1024, 16, 16, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirst;
+  // the four-step pair the other way round: the first pass stores its columns where they are (twiddled), the
+  // second one reads the intermediate as ROWS -- exchanges inside the wave, no barriers -- and transposes on store
+  typedef PassCfg<double, 1024, 16, 16, true, true, 1 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirstNat;
+  typedef PassCfg<double, 1024, 16, 16, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> RowsFromRingT;
 };
 // Measured and NOT kept (tools/ab_option_probe.py fuse2 0,1 <dtype> <n>, fwd + bwd per step): fp64 n = 512
 // (512^3: 5.03 ms unfused, 7.01 fused; four-step 2^18: 0.90 -> 1.32 ms) -- a 128 KiB tile is over in ~10 us, so
@@ -42,7 +46,7 @@ bool fused2_supported_f64(int kind, int variant, int n_a, int n_b) {
   (void)kind;
   if (n_a != n_b) return false;
 #ifdef GFFT_VARIANTS
-  if (variant == 2) return n_a == 1024;
+  if (variant == 2) return n_a == 1024 && kind != FUSED_FOURSTEP_ROWS;
 #endif
   return variant == 1 && n_a == 1024;
 }

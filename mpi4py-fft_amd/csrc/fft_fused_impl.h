@@ -19,6 +19,7 @@ static hipError_t launch_fused2_kind(int kind, const PassDesc &dA, const PassDes
     case FUSED_ROWS_COLS: return launch_fused2<typename C::RowsToRing, typename C::ColsFromRing>(dA, dB, dev, f, in, ring, out, s);
     case FUSED_COLS_ROWS: return launch_fused2<typename C::ColsToRing, typename C::RowsFromRing>(dA, dB, dev, f, in, ring, out, s);
     case FUSED_FOURSTEP: return launch_fused2<typename C::FourStepFirst, typename C::ColsFromRing>(dA, dB, dev, f, in, ring, out, s);
+    case FUSED_FOURSTEP_ROWS: return launch_fused2<typename C::FourStepFirstNat, typename C::RowsFromRingT>(dA, dB, dev, f, in, ring, out, s);
   }
   return hipErrorInvalidValue;
 }
@@ -32,6 +33,7 @@ static int fused2_tiles_kind(int kind, const PassDesc &dA, const PassDesc &dB, i
     case FUSED_ROWS_COLS: *tiles_a = (int)C::RowsToRing::ntiles(dA); *tiles_b = (int)C::ColsFromRing::ntiles(dB); return 0;
     case FUSED_COLS_ROWS: *tiles_a = (int)C::ColsToRing::ntiles(dA); *tiles_b = (int)C::RowsFromRing::ntiles(dB); return 0;
     case FUSED_FOURSTEP: *tiles_a = (int)C::FourStepFirst::ntiles(dA); *tiles_b = (int)C::ColsFromRing::ntiles(dB); return 0;
+    case FUSED_FOURSTEP_ROWS: *tiles_a = (int)C::FourStepFirstNat::ntiles(dA); *tiles_b = (int)C::RowsFromRingT::ntiles(dB); return 0;
   }
   return -1;
 }

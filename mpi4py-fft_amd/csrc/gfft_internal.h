@@ -163,7 +163,7 @@ struct FusedDesc {
   unsigned spin_limit;               // polls of a counter before a waiting workgroup gives up (never hang a device)
   unsigned *ctr;                     // [0] ticket, [1] watchdog, [16 + p] A tiles of plane p stored, [16 + planes + p] B tiles done
 };
-enum FusedKind { FUSED_ROWS_COLS = 0, FUSED_COLS_ROWS = 1, FUSED_FOURSTEP = 2, FUSED_PLANES_2D = 3 };   // (3: the kernels of 0)
+enum FusedKind { FUSED_ROWS_COLS = 0, FUSED_COLS_ROWS = 1, FUSED_FOURSTEP = 2, FUSED_PLANES_2D = 3, FUSED_FOURSTEP_ROWS = 4 };   // (3: the kernels of 0; 4: four-step with a row second pass)
 // variant: 1 = one 1024-thread workgroup per CU; 2 = (make VARIANTS=1, fp64 n = 1024) 8 lines per tile, two 512-thread
 // workgroups per CU
 bool fused2_supported_f64(int kind, int variant, int n_a, int n_b);

@@ -77,7 +77,7 @@ struct Options {
   int fuse2_group = 1;       // tiles per ticket
   int fuse2_defer = 0;       // settle an A tile's counter behind the next tile's loads (A/B)
   int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
-  int fuse2_kinds = 14;      // which pairs (bit = FusedKind): measured per kind, see make_fused2
+  int fuse2_kinds = 30;      // which pairs (bit = FusedKind): measured per kind, see make_fused2
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
   int64_t fused3_min_bytes = 32 << 20;
@@ -517,10 +517,27 @@ int plan_fourstep(gfft_plan_s *pl, const Line &L, int64_t n1, int64_t n2) {
   // Both passes in one persistent launch, a signal's intermediate handed over inside the Infinity Cache
   // (FUSED_FOURSTEP): plane = one signal, slot = its [n2][S2] intermediate.
   if (a.regk && b.regk && inner == 1 && outer < ((int64_t)1 << 30)) {
+    Pass f;
+    {
+      // FUSED_FOURSTEP_ROWS: the intermediate the other way round, tmp[k1][i2] (rows of n2 entries, pitch S1): the
+      // first pass stores its 16 columns i2 .. i2 + 15 side by side where they are, the second reads rows
+      int64_t S1 = n2;
+      if ((S1 * esz) % 2048 == 0) S1 += 256 / esz;
+      PassDesc dA = a.d, dB = b.d;
+      dA.batch = n2;
+      dA.out_os = n1 * S1;  dA.out_ms = 1;  dA.out_is = 1;  dA.out_es = S1;
+      dB.batch = n1;
+      dB.mid = n1;  dB.inner = 1;
+      dB.in_os = n1 * S1;  dB.in_ms = S1;  dB.in_is = 1;  dB.in_es = 1;
+      dB.out_os = n;  dB.out_ms = 1;  dB.out_is = 1;  dB.out_es = n1;
+      if (make_fused2(pl, FUSED_FOURSTEP_ROWS, a, b, dA, dB, (int)outer, n * esz, n * esz, n1 * S1 * esz, &f)) {
+        pl->passes.push_back(f);
+        return GFFT_OK;
+      }
+    }
     PassDesc dA = a.d, dB = b.d;
     dA.batch = n2;           // (o, i2, i) with o = 0
     dB.batch = n1;
-    Pass f;
     if (make_fused2(pl, FUSED_FOURSTEP, a, b, dA, dB, (int)outer, n * esz, n * esz, n2 * S2 * esz, &f)) {
       pl->passes.push_back(f);
       return GFFT_OK;
@@ -1590,7 +1607,7 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
   static const char *kinds[] = {"", "embed", "mul-B", "extract"};
   if (p.kind == PK_FUSED2) {
     // two axis passes in one launch: the algorithmic bytes of both (one read + one write of the array each)
-    static const char *fk[] = {"fused rows+cols", "fused cols+rows", "fused four-step", "fused 2-D rows+cols"};
+    static const char *fk[] = {"fused rows+cols", "fused cols+rows", "fused four-step", "fused 2-D rows+cols", "fused four-step (rows)"};
     snprintf(buf, len, "%s n=%dx%d", fk[p.fused_kind], p.d.n, p.d2.n);
     if (bytes) *bytes = (double)p.fused.planes * 2.0 * pl->precision *
                         ((double)p.d.batch * 2.0 * p.d.n + (double)p.d2.batch * 2.0 * p.d2.n);
@@ -1949,7 +1966,7 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
   static const char *bufn[] = {"IN", "OUT", "WS", "FS", "AUX", "RING"};
   for (const Pass &p : pl->passes) {
     if (p.kind == PK_FUSED2) {
-      static const char *fk[] = {"rows -> strided", "strided -> rows", "four-step", "2-D planes: rows -> strided"};
+      static const char *fk[] = {"rows -> strided", "strided -> rows", "four-step", "2-D planes: rows -> strided", "four-step: strided -> rows, transposed on store"};
       snprintf(line, sizeof line, "  fused pair (%s) n=%d then n=%d: %d planes, %d + %d tiles per plane, ring of %d slots x %lld KiB, one persistent launch%s  %s -> %s\n",
                fk[p.fused_kind], p.d.n, p.d2.n, p.fused.planes, p.fused.tiles_a, p.fused.tiles_b, p.fused.ring,
                (long long)(p.fused.slot_bytes >> 10), p.carries_scale ? " [scale]" : "", bufn[p.src], bufn[p.dst]);
