@@ -73,7 +73,7 @@ struct Options {
   int debug_flat = 0;        // gfft_debug_pass: tiles over the flattened (mid, inner) index
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
   int fuse2 = 1;             // pass pairs in one persistent launch, handed over through the Infinity Cache (fft_fused_f64.hip)
-  int fuse2_ring = 8, fuse2_lag = 4;
+  int fuse2_ring = 0, fuse2_lag = 0;   // slots of the hand-off ring / planes the producer runs ahead; 0 = auto (make_fused2)
   int fuse2_group = 1;       // tiles per ticket
   int fuse2_defer = 0;       // settle an A tile's counter behind the next tile's loads (A/B)
   int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
@@ -366,7 +366,13 @@ void need(gfft_plan_s *pl, int buf, size_t bytes) {
 
 bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const PassDesc &dA, const PassDesc &dB, int planes,
                  int64_t a_in_plane, int64_t b_out_plane, int64_t slot_bytes, Pass *out) {
-  const int ring = opts().fuse2_ring, lag = opts().fuse2_lag;
+  // auto: 8 slots / 4 planes ahead (the optimum of the 3-D pair, profiles/r03_fused2_probe.txt); the four-step pairs
+  // -- whose other streams are short -- do better on 12 / 6 when there are planes enough (C2: 0.748 -> 0.710 ms,
+  // 16 / 8: 0.70; tools/survey.py under GFFT_FUSE2_RING / _LAG)
+  const bool fourstep = kind == FUSED_FOURSTEP || kind == FUSED_FOURSTEP_ROWS;
+  int ring = opts().fuse2_ring, lag = opts().fuse2_lag;
+  if (ring <= 0) ring = (fourstep && planes >= 24) ? 12 : 8;
+  if (lag <= 0) lag = ring / 2;
   if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1) || planes < 2 * ring || lag < 1 || ring <= lag) return false;
   const int variant = opts().fuse2 == 2 ? 2 : 1;
   // (fp64 only: the fp32 pairs measured slower than their stand-alone passes, fft_fused_f64.hip)
@@ -1104,7 +1110,7 @@ int plan_fused3(gfft_plan_s *pl) {
   // rows 16 MiB apart), which costs nothing, where the mirror pair [rows -> axis 0] READS them scattered and
   // loses what the fusion gains (1024^3 c128, tools/fused2_probe.py: 20.0 ms against 18.4 ms).
   const bool pair_cols_rows = !real && !tr && !flat_out && Pu == nc && opts().fuse2 &&
-                              ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && n1 >= 2 * opts().fuse2_ring &&
+                              ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && n1 >= 2 * (opts().fuse2_ring > 0 ? opts().fuse2_ring : 8) &&
                               prec == GFFT_F64 && fused2_supported_f64(FUSED_COLS_ROWS, opts().fuse2 == 2 ? 2 : 1, (int)n0, (int)n2);
   const bool cols_first = !inverse && pair_cols_rows;
   // ... and the workspace then is W[i0][k1][c]: the stand-alone axis-1 pass stores on NEAR strides (stores are

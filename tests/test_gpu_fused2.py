@@ -19,7 +19,7 @@ def _opts(**kw):
 @pytest.fixture(autouse=True)
 def _restore():
     yield
-    _opts(fuse2=1, fuse2_ring=8, fuse2_lag=4, fuse2_kinds=14)
+    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=30)
 
 
 def _plans(shape, axes, fuse, ring=8, lag=4, kinds=15, dt='D'):
@@ -84,13 +84,14 @@ def test_fused_four_step_matches_the_two_launch_form(shape, dt):
     assert np.abs(want[:2] - ref).max() <= (2e-10 if dt == 'D' else 2e-4) * np.abs(ref).max()
     f0.destroy()
     b0.destroy()
-    for ring, lag in ((8, 4), (4, 1), (16, 8)):
-        a1, f1, b1 = _plans(shape, (1,), 1, ring, lag, dt=dt)
-        assert 'fused pair (four-step)' in _lib.engine().plan_describe(f1._plan)
+    # kinds 15: [strided + transposing store] -> [strided]; 31: [strided] -> [rows + transposing store] (the default)
+    for ring, lag, kinds in ((8, 4, 15), (4, 1, 15), (16, 8, 15), (8, 4, 31), (4, 1, 31), (12, 6, 31), (0, 0, 31)):
+        a1, f1, b1 = _plans(shape, (1,), 1, ring, lag, kinds, dt=dt)
+        assert ('fused pair (four-step)' if kinds == 15 else 'fused pair (four-step: strided -> rows') in _lib.engine().plan_describe(f1._plan)
         a1[...] = x
         for rep in range(3):
             got = np.asarray(f1.execute_scaled(a1, f1.output_array, 1.0))
-            assert np.abs(got - want).max() <= eps * np.abs(want).max(), (ring, lag, rep)
+            assert np.abs(got - want).max() <= eps * np.abs(want).max(), (ring, lag, kinds, rep)
             back = np.asarray(b1.execute_scaled(f1.output_array, b1.output_array, 1.0 / shape[1]))
             assert np.abs(back - x).max() <= 10 * eps * np.abs(x).max()
         f1.destroy()
