@@ -73,7 +73,7 @@ int gfft_device_name(int device, char *buf, size_t len);
  * "force_generic", "fused3", "profile" (also readable from the environment as GFFT_<UPPERCASE NAME>);
  * "fuse2" (1: pass pairs as one persistent launch through the Infinity Cache where a pair exists and pays,
  * 0: stand-alone passes), with "fuse2_ring" / "fuse2_lag" (slots of the hand-off ring / planes the producer
- * runs ahead; 0 = auto: 8 / 4, four-step pairs 12 / 6), "fuse2_kinds" (bit mask of pair kinds) and the A/B switches "fuse2_wlayout",
+ * runs ahead; 0 = auto: 12 / 6, launches of fewer than 24 planes 8 / 4), "fuse2_kinds" (bit mask of pair kinds) and the A/B switches "fuse2_wlayout",
  * "fuse2_group", "fuse2_defer" (DESIGN.md section 4.7); GFFT_FUSE2_DEBUG=1 prints a fused launch's counters */
 int gfft_set_option(const char *key, int value);
 

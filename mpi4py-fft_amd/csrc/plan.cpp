@@ -366,12 +366,13 @@ void need(gfft_plan_s *pl, int buf, size_t bytes) {
 
 bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const PassDesc &dA, const PassDesc &dB, int planes,
                  int64_t a_in_plane, int64_t b_out_plane, int64_t slot_bytes, Pass *out) {
-  // auto: 8 slots / 4 planes ahead (the optimum of the 3-D pair, profiles/r03_fused2_probe.txt); the four-step pairs
-  // -- whose other streams are short -- do better on 12 / 6 when there are planes enough (C2: 0.748 -> 0.710 ms,
-  // 16 / 8: 0.70; tools/survey.py under GFFT_FUSE2_RING / _LAG)
-  const bool fourstep = kind == FUSED_FOURSTEP || kind == FUSED_FOURSTEP_ROWS;
+  // auto: 12 slots with the producer 6 planes ahead where there are planes enough, else 8 / 4.  Swept on one box, plans
+  // alternating on the same arrays (tools/fused2_ring_sweep.py, profiles/r03_fused2_ring_sweep_final.txt): 1024^3
+  // complex128 per step 34.3 (8 / 4) -> 32.4 (12 / 6), 32.2 (14 / 7), 31.8 (13 / 6, 11 / 6); lag 3 or ring 6: 37.9;
+  // C2 0.748 -> 0.710 ms (16 / 8: 0.70).  (Before the row tiles lost their barriers 8 / 4 was the optimum: a
+  // faster consumer wants the producer further ahead.)
   int ring = opts().fuse2_ring, lag = opts().fuse2_lag;
-  if (ring <= 0) ring = (fourstep && planes >= 24) ? 12 : 8;
+  if (ring <= 0) ring = planes >= 24 ? 12 : 8;
   if (lag <= 0) lag = ring / 2;
   if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1) || planes < 2 * ring || lag < 1 || ring <= lag) return false;
   const int variant = opts().fuse2 == 2 ? 2 : 1;

@@ -2,8 +2,8 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
 from mpi4py_fft_amd import PFFT, comm, _lib
-_lib.set_option('fuse2', 3)
-combos = [(8, 4), (10, 5), (12, 6), (14, 7), (16, 8), (12, 4), (12, 8), (16, 6), (16, 10), (20, 10)]
+_lib.set_option('fuse2', 1)
+combos = [(8, 4), (12, 6), (12, 5), (12, 7), (14, 7), (14, 6), (14, 8), (13, 6), (11, 6)]
 from mpi4py_fft_amd import newDistArray
 # (a PFFT owns its planned arrays: three at a time, all on the SAME caller arrays, the first combination in every batch)
 base = PFFT(comm.COMM_SELF, (1024,) * 3, dtype='D')
