@@ -591,6 +591,19 @@ def run(args, guard, state):
                         avg_launch_ms=round(avg_ms, 4), launches=k['launches'],
                         algorithmic_bytes_per_launch=k['bytes'],
                         all_kernels={kk: round(v['ms'] / v['launches'], 4) for kk, v in kern.items()})
+        # The PHYSICAL figure beside SURVEY 8d's: a fused pair runs two axis passes (4 S algorithmic bytes) but its
+        # intermediate is handed over inside the Infinity Cache, so HBM has to carry one read and one write of the
+        # array only (2 S).  `frac` above prices the launch against the algorithmic bytes and may exceed the copy
+        # ceiling -- or 1 -- for that reason; `frac_hbm_min` prices what HBM actually must move.
+        fused = 'fused pair' in name
+        hbm_min = k['bytes'] / 2 if fused else k['bytes']
+        roofline['hbm_min_bytes_per_launch'] = hbm_min
+        roofline['frac_hbm_min'] = round(hbm_min / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline['note'] = ('frac = SURVEY 8d algorithmic bytes (one read + one write of the array per transformed axis) / '
+                            'launch time / 8 TB/s; ' +
+                            ('this launch is a fused pair of axis passes whose intermediate stays in the Infinity Cache, so '
+                             'values above the copy ceiling (and above 1) are expected; ' if fused else '') +
+                            'frac_hbm_min = the bytes HBM must carry for the launch / time / 8 TB/s')
 
     # streaming-copy ceiling of this very box and run (same byte count per launch as one pass of the
     # dominant kernel when it fits): what "100 % of achievable HBM" means next to roofline.frac
@@ -611,7 +624,8 @@ def run(args, guard, state):
             gbs = 2 * nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
             copy_ceiling = {'gbs': round(gbs, 1), 'frac_of_peak': round(gbs / HBM_PEAK_GBS, 4),
                             'bytes_per_launch': 2 * nbytes,
-                            'what': 'dst[i] = src[i], 16 B per lane x 4 in flight (gfft_probe_copy), HIP events'}
+                            'what': 'dst[i] = src[i], 1024-thread workgroups, 8 x 16 B per lane in flight, non-temporal loads and stores '
+                                    '(gfft_probe_copy; the best of the sweep in profiles/r04_copy_sweep.txt), HIP events'}
         except Exception as e:
             copy_ceiling = {'gbs': None, 'what': 'failed: %r' % (e,)}
     world.barrier()
@@ -631,6 +645,13 @@ def run(args, guard, state):
         # SURVEY.md 8d also asks for the read-only variant (3 S per transform instead of 6 S)
         whole['read_only_gbs'] = round(whole['gbs'] / 2, 1)
         whole['read_only_frac_of_peak_per_gpu'] = round(whole['gbs'] / 2 / size / HBM_PEAK_GBS, 4)
+        # physical floor: an array far larger than the 256 MiB Infinity Cache cannot be transformed along three
+        # axes in fewer than TWO HBM round trips (a 256 KiB on-chip tile holds 14 of the 30 radix-2 levels of
+        # 1024^3), i.e. 4 S per direction against the 6 S SURVEY 8d counts
+        if size == 1 and len(shape) == 3:
+            whole['min_bytes'] = int(2 * bytes_f * 2 // 3)
+            whole['min_gbs'] = round(whole['min_bytes'] / (secs / args.steps) / 1e9, 1)
+            whole['min_frac_of_peak'] = round(whole['min_gbs'] / HBM_PEAK_GBS, 4)
         return {
             'metric': 'pfft_3d_c2c_%dcubed_fp64_gflops' % n,
             'value': round(flops / (secs / args.steps) / 1e9, 1),
@@ -652,6 +673,11 @@ def run(args, guard, state):
         out['hbm_copy_ceiling'] = copy_ceiling
         if roofline and copy_ceiling and copy_ceiling.get('gbs'):
             roofline['frac_of_copy_ceiling'] = round(roofline['achieved'] / copy_ceiling['gbs'], 4)
+            roofline['frac_hbm_min_of_copy_ceiling'] = round(
+                roofline['hbm_min_bytes_per_launch'] / (roofline['avg_launch_ms'] * 1e-3) / 1e9 / copy_ceiling['gbs'], 4)
+            wh = out['whole_transform_hbm']
+            if wh.get('min_gbs'):
+                wh['min_frac_of_copy_ceiling'] = round(wh['min_gbs'] / copy_ceiling['gbs'], 4)
         if not args.no_cpu and size == 1:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
             try:

@@ -98,6 +98,16 @@ int gfft_plan_create_r2r(gfft_plan *plan, int ndims, const int64_t *sizes, int n
 int gfft_execute(gfft_plan plan, const void *d_in, void *d_out, double scale, void *stream);
 int gfft_plan_destroy(gfft_plan plan);
 int gfft_scratch_release(void);           /* frees the shared per-stream workspaces, pinned ones included */
+/* Errors of launches that have already returned GFFT_OK (execution is asynchronous): a fused pass-pair launch
+ * whose workgroups waited longer than option "fuse2_wait_ms" (default 2000) for one another -- a device shared
+ * with a long foreign kernel, a debugger -- voids itself instead of hanging or trapping.  GFFT_OK, or
+ * GFFT_ERR_HIP once per event with the plan named in gfft_last_error(): the results of that plan's last execution
+ * are invalid, and the plan runs the pair as stand-alone launches from then on.  Does not synchronise -- call it
+ * after synchronising the stream to learn whether what was waited for is valid; gfft_execute() reports a pending
+ * event the same way, before enqueueing anything.  (The reference raises RuntimeError where FFTW fails to plan,
+ * mpi4py_fft/fftw/fftw_xfftn.pyx:152-153, and cannot fail afterwards; this is the analogue for a failure mode only
+ * a persistent launch has.) */
+int gfft_async_error(void);
 /* Fuse FFTBase._truncation_forward / _padding_backward (libfft.py:263-311) into a single-axis plan:
  * afterwards gfft_execute writes (forward kinds) / reads (backward kinds) the TRUNCATED array,
  * n_keep entries along the axis (N on a complex axis, N/2+1 on the real half-axis), with the

@@ -83,6 +83,7 @@ def _declare(lib):
         'gfft_plan_profile': (c.c_int, [vp, c.POINTER(c.c_float), c.c_int, ip]),
         'gfft_plan_pass_info': (c.c_int, [vp, c.c_int, c.c_char_p, c.c_size_t, c.POINTER(c.c_double)]),
         'gfft_probe_copy': (c.c_int, [vp, vp, c.c_size_t, vp]),
+        'gfft_async_error': (c.c_int, []),
         'gfft_rccl_load': (c.c_int, [c.c_char_p]),
         'gfft_rccl_info': (c.c_int, [c.c_char_p, c.c_size_t]),
         'gfft_exchange_last_error': (c.c_char_p, []),
@@ -120,6 +121,13 @@ def lib():
         _lib = ctypes.CDLL(LIBPATH)
         EXPORTS = _declare(_lib)
     return _lib
+
+
+def check_async():
+    """Raise if a launch that already returned has failed since the last look (gfft_async_error: a fused pass pair
+    that gave up a wait).  Called where the host is about to READ results, after the synchronisation."""
+    if _lib is not None:
+        check(_lib.gfft_async_error())
 
 
 def check(rc):

@@ -34,6 +34,11 @@ _pinned_lock = __import__('threading').Lock()     # the bounce buffers are share
 _pool = None
 
 
+def _check_async():
+    from . import _lib
+    _lib.check_async()
+
+
 def _bounce(device):
     key = str(device)
     b = _pinned.get(key)
@@ -174,9 +179,11 @@ class DeviceArray:
         elif out is not None:
             assert out.shape == self._shape and out.dtype == self._dtype and out.flags.c_contiguous
             torch.from_numpy(out.reshape(-1).view(np.uint8)).copy_(_bytes_view(t.contiguous()))
+            _check_async()
             return out
         else:
             a = d2h(t.contiguous()).view(self._dtype).reshape(self._shape)
+            _check_async()            # (the copy synchronised: were the launches it waited for valid?)
         if out is not None:
             out[...] = a
             return out

@@ -3,8 +3,8 @@
 //   [rows n] -> [strided n]   passes 1 + 2 of a complex 3-D schedule, forward order (plan.cpp plan_fused3; built, not the default)
 //   [strided n] -> [rows n]   passes 2 + 3 of the complex 3-D schedule as both directions run it
 //   four-step n x n           both passes of a length-n^2 transform (n = 1024: BASELINE config C2), second pass strided or rows
-// Every pass is the plan of the stand-alone tables (fft_pow2_f64.hip) on 1024-thread workgroups -- the row
-// pass therefore takes 16 rows per workgroup instead of 4 -- with the hand-off side at system scope.
+// Every pass works on 16 lines per workgroup -- the row pass therefore takes 16 rows per tile instead of the stand-alone
+// table's 4 -- with the hand-off side at system scope.
 #include "fft_fused_impl.h"
 
 namespace gfft {
@@ -39,33 +39,66 @@ struct Fused1024x8 {
   typedef PassCfg<double, 1024, 16, 8, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> ColsToRing;
   typedef PassCfg<double, 1024, 16, 8, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> ColsFromRing;
   typedef PassCfg<double, 1024, 16, 8, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirst;
+  typedef PassCfg<double, 1024, 16, 8, true, true, 1 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirstNat;
+  typedef PassCfg<double, 1024, 16, 8, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> RowsFromRingT;
+};
+// variant 4: the two ideas together -- 8 lines per tile AND one exchange (32 values per thread): 256-thread workgroups of
+// up to 256 VGPRs, two per CU
+struct Fused1024x8R32 {
+  typedef PassCfg<double, 1024, 32, 8, false, true, 1 | 2048 | 8192, MODE_C2C, false, 32, 32> RowsToRing;
+  typedef PassCfg<double, 1024, 32, 8, false, true, 2 | 4096 | 8192, MODE_C2C, false, 32, 32> RowsFromRing;
+  typedef PassCfg<double, 1024, 32, 8, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 32, 32> ColsToRing;
+  typedef PassCfg<double, 1024, 32, 8, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 32, 32> ColsFromRing;
+  typedef PassCfg<double, 1024, 32, 8, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 32, 32> FourStepFirst;
+  typedef PassCfg<double, 1024, 32, 8, true, true, 1 | 2048 | 8192, MODE_C2C, true, 32, 32> FourStepFirstNat;
+  typedef PassCfg<double, 1024, 32, 8, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 32, 32> RowsFromRingT;
 };
 #endif
 
+// The default since round 4: 32 values per thread, radices 32 x 32 -- ONE LDS exchange per tile instead of two (4
+// barriers on the strided tiles instead of 8), on 512-thread workgroups (8 waves, up to 256 VGPRs each); same 16 lines
+// per tile, same 256-byte hand-off segments
+struct Fused1024R32 {
+  typedef PassCfg<double, 1024, 32, 16, false, true, 1 | 2048 | 8192, MODE_C2C, false, 32, 32> RowsToRing;
+  typedef PassCfg<double, 1024, 32, 16, false, true, 2 | 4096 | 8192, MODE_C2C, false, 32, 32> RowsFromRing;
+  typedef PassCfg<double, 1024, 32, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 32, 32> ColsToRing;
+  typedef PassCfg<double, 1024, 32, 16, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 32, 32> ColsFromRing;
+  typedef PassCfg<double, 1024, 32, 16, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 32, 32> FourStepFirst;
+  typedef PassCfg<double, 1024, 32, 16, true, true, 1 | 2048 | 8192, MODE_C2C, true, 32, 32> FourStepFirstNat;
+  typedef PassCfg<double, 1024, 32, 16, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 32, 32> RowsFromRingT;
+};
+
+// variant: 1 = the default, 32 values per thread / one exchange (Fused1024R32); 3 = 16 values per thread / two exchanges
+// on 1024 threads (FusedCfgs: the round-3 kernels, kept for A/B: 1024^3 per step 33.4 -> 32.6 ms, C2 0.707 -> 0.677 ms
+// with variant 1, tools/ab_combo_probe.py, profiles/r04_ab_fuse2_variants.txt); 2 / 4 = (make VARIANTS=1) 8 lines per tile,
+// two workgroups per CU, with 16 / 32 values per thread: 40.6 / 39.7 ms per step, a quarter SLOWER -- what bounds the fused
+// launch is the traffic its CUs can move across the L2 boundary, and 128-byte pieces move less of it
 bool fused2_supported_f64(int kind, int variant, int n_a, int n_b) {
   (void)kind;
   if (n_a != n_b) return false;
 #ifdef GFFT_VARIANTS
-  if (variant == 2) return n_a == 1024 && kind != FUSED_FOURSTEP_ROWS;
+  if (variant == 2 || variant == 4) return n_a == 1024;
 #endif
-  return variant == 1 && n_a == 1024;
+  return (variant == 1 || variant == 3) && n_a == 1024;
 }
 
 int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b) {
 #ifdef GFFT_VARIANTS
   if (variant == 2) return fused2_tiles_kind<Fused1024x8>(kind, dA, dB, tiles_a, tiles_b);
+  if (variant == 4) return fused2_tiles_kind<Fused1024x8R32>(kind, dA, dB, tiles_a, tiles_b);
 #endif
-  (void)variant;
-  return fused2_tiles_kind<FusedCfgs<double, 1024>>(kind, dA, dB, tiles_a, tiles_b);
+  if (variant == 3) return fused2_tiles_kind<FusedCfgs<double, 1024>>(kind, dA, dB, tiles_a, tiles_b);
+  return fused2_tiles_kind<Fused1024R32>(kind, dA, dB, tiles_a, tiles_b);
 }
 
 hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs,
                              const FusedDesc &f, const void *in, void *ring, void *out, hipStream_t s) {
 #ifdef GFFT_VARIANTS
   if (variant == 2) return launch_fused2_kind<Fused1024x8>(kind, dA, dB, dev_descs, f, in, ring, out, s);
+  if (variant == 4) return launch_fused2_kind<Fused1024x8R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);
 #endif
-  (void)variant;
-  return launch_fused2_kind<FusedCfgs<double, 1024>>(kind, dA, dB, dev_descs, f, in, ring, out, s);
+  if (variant == 3) return launch_fused2_kind<FusedCfgs<double, 1024>>(kind, dA, dB, dev_descs, f, in, ring, out, s);
+  return launch_fused2_kind<Fused1024R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);
 }
 
 }  // namespace gfft

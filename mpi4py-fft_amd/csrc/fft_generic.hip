@@ -247,12 +247,13 @@ static hipError_t launch_generic_t(const PassDesc &d, const Factors &f, const vo
   // keep the chip busy: prefer >= 1024 tiles when the batch allows
   while (T > 8 && (d.batch + T - 1) / T < 1024) T /= 2;
   size_t lds = 2 * (size_t)T * d.n * esz + 3 * (size_t)T * sizeof(int64_t);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[kMaxDevices] = {};       // (per device)
+  const int dev = current_device();
+  if (!attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fft_generic_kernel<real>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev] = true;
   }
   int64_t tiles = (d.batch + T - 1) / T;
   int grid = (int)(tiles < 4096 ? tiles : 4096);

@@ -882,6 +882,7 @@ template <typename real_, int N, int R, int T, bool COLS, bool SPLIT, int FLAGS,
 struct PassCfg {
   typedef real_ real;
   static constexpr int threads = T * (N / R);
+  static constexpr int regs_per_thread = R * 2 * (int)(sizeof(real_) / 4);     // the column's values alone, in VGPRs
   static constexpr size_t lds = (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real_) == 4)>::CS * (SPLIT ? sizeof(real_) : 2 * sizeof(real_));
   template <typename HOOK>
   static __device__ __forceinline__ void tile(const PassDesc &d, const void *in, void *out, unsigned char *smem, unsigned t,
@@ -899,13 +900,40 @@ struct PassCfg {
 // version of this kernel hung exactly so, with the barriers of the tile code in the loop.)
 __device__ __forceinline__ bool wave_of_thread0() { return __builtin_amdgcn_readfirstlane(threadIdx.x) == 0; }
 
-__device__ __forceinline__ void fused_wait(const unsigned *flag, unsigned want, unsigned *watchdog, unsigned limit) {
+// A wait that takes longer than f.wait_ticks of the 100 MHz wall clock (a device shared with a long foreign kernel, a
+// debugger single-stepping a workgroup) VOIDS the launch instead of hanging the device or poisoning the HIP context:
+// the waiter raises the sticky word ctr[1], writes the plan's id into the host-visible word f.host_flag (pinned host
+// memory: the library reads it at its next entry and re-plans the pair as two stand-alone passes, plan.cpp
+// poll_async_error), and pushes the ticket counter past the last ticket so that every workgroup leaves at its next
+// draw; the other waiters look at ctr[1] every 64 polls and leave too.  The output of such a launch is garbage and
+// is reported as such -- GFFT_ERR_HIP from the library's next call -- but the process and its other plans live on.
+// (wait_ticks == 0: every wait gives up at once -- the test hook for exactly this path.)
+__device__ __forceinline__ void fused_give_up(const FusedDesc &f) {
+  if (atomicAdd(&f.ctr[1], 1u) == 0u) {
+    atomicAdd(&f.ctr[0], 0x80000000u);
+    if (f.host_flag) {
+      __hip_atomic_store(f.host_flag, f.plan_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
+  }
+}
+__device__ __forceinline__ void fused_wait(const unsigned *flag, unsigned want, const FusedDesc &f) {
   if (wave_of_thread0()) {
     if (threadIdx.x == 0) {
-      unsigned spins = 0;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > limit) { atomicAdd(watchdog, 1u); break; }     // (never hang a device: wrong results instead)
+      if (f.wait_ticks == 0u) {
+        fused_give_up(f);
+      } else {
+        unsigned spins = 0;
+        unsigned long long t0 = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          __builtin_amdgcn_s_sleep(8);
+          if ((++spins & 63u) == 0u) {
+            if (__hip_atomic_load(&f.ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // the launch is void already
+            const unsigned long long now = wall_clock64();
+            if (!t0) t0 = now;
+            else if (now - t0 > (unsigned long long)f.wait_ticks) { fused_give_up(f); break; }
+          }
+        }
       }
     }
   }
@@ -927,7 +955,7 @@ __device__ __forceinline__ void fused_wait(const unsigned *flag, unsigned want, 
 // (workgroups of <= 512 threads: two per CU -- one computes while the other loads / stores --, which the
 // register budget must allow: at most 128 VGPRs, i.e. 4 waves per SIMD)
 template <typename A, typename B>
-__global__ void __launch_bounds__(A::threads, A::threads <= 512 ? 4 : 1)
+__global__ void __launch_bounds__(A::threads, A::threads > 512 ? 1 : (A::regs_per_thread > 64 ? 2 : 4))
 fft_fused2_kernel(const PassDesc *__restrict__ descs, FusedDesc f, double scale_a, double scale_b, const void *__restrict__ in,
                   void *__restrict__ ring, void *__restrict__ out) {
   static_assert(A::threads == B::threads, "both passes of a fused pair run on one workgroup shape");
@@ -977,10 +1005,12 @@ fft_fused2_kernel(const PassDesc *__restrict__ descs, FusedDesc f, double scale_
       }
       __syncthreads();
       const bool there = __builtin_amdgcn_readfirstlane(tk[2]) != 0;
-      if (there) return;
+      // (f.defer == 2: the debt is settled HERE, behind the next ticket's pick-up and the first look at its counter
+      // -- the acknowledgements had those two round trips to arrive -- and before the tile's own loads)
+      if (there) { if (f.defer == 2) settle(); return; }
       settle();
     }
-    fused_wait(flag, want, &f.ctr[1], f.spin_limit);
+    fused_wait(flag, want, f);
   };
 #ifdef GFFT_FUSE2_TRACE
   auto hook = [&]() {
@@ -1028,6 +1058,7 @@ fft_fused2_kernel(const PassDesc *__restrict__ descs, FusedDesc f, double scale_
 #endif
     if (is_a) {
       if (p >= (unsigned)f.ring) await(&done_b[p - f.ring], tb);
+      else if (f.defer == 2) settle();
       GFFT_TRACE_STAMP(1)
       if (f.debug != 3 && f.debug != 5)
         for (unsigned g = 0; g < grp; ++g)
@@ -1062,13 +1093,6 @@ fft_fused2_kernel(const PassDesc *__restrict__ descs, FusedDesc f, double scale_
 // for latency that overlap could hide.  A first form with every wave polling and raising the plane counters
 // itself took 136 ms per step: sixteen memory-side atomics per tile on one hot word.)
 
-// A wait that gave up means a plane was read before it was complete: make that loud.  One thread, enqueued
-// behind the fused launch; the trap surfaces as a launch failure at the stream's next synchronisation.
-template <typename A>
-__global__ void fused2_check_kernel(const unsigned *ctr) {
-  if (ctr[1] != 0) __builtin_trap();
-}
-
 template <typename A, typename B>
 hipError_t launch_fused2(const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs, const FusedDesc &f, const void *in,
                          void *ring, void *out, hipStream_t s) {
@@ -1078,25 +1102,27 @@ hipError_t launch_fused2(const PassDesc &dA, const PassDesc &dB, const PassDesc 
       f.group < 1 || f.tiles_a % f.group || f.tiles_b % f.group)
     return hipErrorInvalidValue;
   auto kern = fft_fused2_kernel<A, B>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  // (per device: a process may drive several GPUs, and both the function attribute and the CU count belong to one)
+  static bool attr_set[kMaxDevices] = {};
+  static int cus_of[kMaxDevices] = {};
+  const int dev = current_device();
+  if (!attr_set[dev] && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev] = true;
   }
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-      cus = 256;
+  if (!cus_of[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 256; }
+    cus_of[dev] = n;
   }
+  const int cus = cus_of[dev];
   hipError_t e = hipMemsetAsync(f.ctr, 0, (size_t)(16 + 2 * f.planes) * sizeof(unsigned), s);
   if (e != hipSuccess) return e;
   // as many workgroups as fit the CUs at once (the exchange tile of a 1024-thread workgroup fills the LDS,
   // two 512-thread ones share it): persistent, tickets do the load balancing
   const int per_cu = (A::threads <= 512 && 2 * lds + 1024 <= 160 * 1024) ? 2 : 1;
   hipLaunchKernelGGL(kern, dim3(cus * per_cu), dim3(A::threads), lds, s, dev_descs, f, dA.scale, dB.scale, in, ring, out);
-  if (!f.debug) hipLaunchKernelGGL(fused2_check_kernel<A>, dim3(1), dim3(1), 0, s, f.ctr);
   return hipGetLastError();
 }
 
@@ -1123,12 +1149,15 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   if (!COLS && ((d.in_tlg && (NT & ((1 << d.in_tlg) - 1))) || (d.out_tlg && (NT & ((1 << d.out_tlg) - 1)))))
     return hipErrorInvalidValue;
   auto kern = fft_pow2_kernel<real, N, R, T, COLS, SPLIT, MINW, FLAGS, MODE, BIGTW, RADS...>;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
+  if constexpr (lds > 64 * 1024) {
+    static bool attr_set[kMaxDevices] = {};       // (per device, see launch_fused2)
+    const int dev = current_device();
+    if (!attr_set[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      attr_set[dev] = true;
+    }
   }
   const int64_t flat_cols = d.mid * d.inner;
   const int64_t ntiles = (COLS && !BIGTW) ? (d.flat ? (d.batch / flat_cols) * ((flat_cols + T - 1) / T)

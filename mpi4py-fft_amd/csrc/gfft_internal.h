@@ -5,6 +5,15 @@
 
 namespace gfft {
 
+// ordinal of the calling thread's current device, as an index into per-device state: function attributes, CU
+// counts and the twiddle-table caches belong to ONE device, and a process may drive several
+constexpr int kMaxDevices = 64;
+inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; }
+  return (d < 0 || d >= kMaxDevices) ? 0 : d;
+}
+
 // ---- complex helpers (device) ------------------------------------------------------------
 template <typename T> struct cx { T x, y; };
 
@@ -160,12 +169,14 @@ struct FusedDesc {
   int64_t a_in_plane, b_out_plane;   // BYTES from one plane to the next on A's input / B's output side
   int64_t slot_bytes;
   unsigned debug;                    // developer aid (GFFT_FUSE2_DEBUG): 2 tickets only, 3 + waits, 4 + A tiles, 5 + B tiles instead
-  unsigned spin_limit;               // polls of a counter before a waiting workgroup gives up (never hang a device)
-  unsigned *ctr;                     // [0] ticket, [1] watchdog, [16 + p] A tiles of plane p stored, [16 + planes + p] B tiles done
+  unsigned wait_ticks;               // 100 MHz wall-clock ticks a workgroup waits for a counter before it voids the launch (0: at once)
+  unsigned plan_id;                  // what a launch that gave up writes to *host_flag
+  unsigned *host_flag;               // pinned host word the library polls (plan.cpp poll_async_error); may be null
+  unsigned *ctr;                     // [0] ticket, [1] launch void (a wait gave up), [16 + p] A tiles of plane p stored, [16 + planes + p] B tiles done
 };
 enum FusedKind { FUSED_ROWS_COLS = 0, FUSED_COLS_ROWS = 1, FUSED_FOURSTEP = 2, FUSED_PLANES_2D = 3, FUSED_FOURSTEP_ROWS = 4 };   // (3: the kernels of 0; 4: four-step with a row second pass)
-// variant: 1 = one 1024-thread workgroup per CU; 2 = (make VARIANTS=1, fp64 n = 1024) 8 lines per tile, two 512-thread
-// workgroups per CU
+// variant: 1 = the default kernels (32 values per thread, one exchange, one 512-thread workgroup per CU); 3 = the round-3
+// kernels (16 values per thread, two exchanges, 1024 threads); 2 / 4 = (make VARIANTS=1) 8 lines per tile, two workgroups per CU
 bool fused2_supported_f64(int kind, int variant, int n_a, int n_b);
 int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b);
 // dev_descs: {dA, dB} in device memory (uploaded when the plan was made; the scale factors travel as arguments)

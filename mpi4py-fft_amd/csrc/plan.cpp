@@ -78,6 +78,7 @@ struct Options {
   int fuse2_defer = 0;       // settle an A tile's counter behind the next tile's loads (A/B)
   int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
   int fuse2_kinds = 30;      // which pairs (bit = FusedKind): measured per kind, see make_fused2
+  int fuse2_wait_ms = 2000;  // wall-clock limit of one wait inside a fused launch before the launch is voided (0: at once -- test hook)
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
   int64_t fused3_min_bytes = 32 << 20;
@@ -96,6 +97,7 @@ struct Options {
     if (const char *s = getenv("GFFT_FUSE2_WLAYOUT")) fuse2_wlayout = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_GROUP")) fuse2_group = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_DEFER")) fuse2_defer = atoi(s);
+    if (const char *s = getenv("GFFT_FUSE2_WAIT_MS")) fuse2_wait_ms = atoi(s);
   }
 };
 Options &opts() {
@@ -104,6 +106,8 @@ Options &opts() {
 }
 
 // ---- twiddle tables (device resident, shared by plans) ------------------------------------
+// (per device: the key's precision slot also carries the ordinal of the device the table lives on)
+int dev_prec(int precision) { return precision + (current_device() << 8); }
 std::mutex g_tw_mutex;
 std::map<std::pair<int64_t, int>, void *> g_tw_cache;       // (n, precision) -> W_n^k, k<n
 struct BigTw { void *hi, *lo; int L; };
@@ -145,7 +149,7 @@ int upload_twiddles(int64_t n, int64_t step, int64_t count, int precision, void 
 
 int get_twiddles(int64_t n, int precision, const void **out) {
   std::lock_guard<std::mutex> lock(g_tw_mutex);
-  auto key = std::make_pair(n, precision);
+  auto key = std::make_pair(n, dev_prec(precision));
   auto it = g_tw_cache.find(key);
   if (it == g_tw_cache.end()) {
     void *d = nullptr;
@@ -159,7 +163,7 @@ int get_twiddles(int64_t n, int precision, const void **out) {
 
 int get_bigtw(int64_t big_n, int precision, BigTw *out) {
   std::lock_guard<std::mutex> lock(g_tw_mutex);
-  auto key = std::make_pair(big_n, precision);
+  auto key = std::make_pair(big_n, dev_prec(precision));
   auto it = g_bigtw_cache.find(key);
   if (it == g_bigtw_cache.end()) {
     int L = 0;
@@ -214,6 +218,11 @@ struct Pass {
   FusedDesc fused{};
   int fused_kind = 0, fused_variant = 1;
   PassDesc *dev_descs = nullptr;     // {d, d2} in device memory (owned by the plan: gfft_plan_s::device_allocs)
+  // the same two passes as stand-alone launches (gfft_plan_s::alt[alt_first], [alt_first + 1]): what the plan runs
+  // once a fused launch has given up a wait; alt_buf / alt_bytes = the scratch region only that form needs
+  int alt_first = -1;
+  int alt_buf = -1;
+  size_t alt_bytes = 0;
   double bytes2 = 0;                 // algorithmic bytes of pass B (gfft_plan_pass_info reports A + B)
 };
 
@@ -355,8 +364,75 @@ struct gfft_plan_s {
   std::vector<int64_t> trunc;                  // gfft_plan_create_padded: kept entries per axis (else empty)
   std::vector<std::vector<hipEvent_t>> prof;   // per execute: events before pass 0 and after each pass
   std::vector<void *> device_allocs;            // small device buffers the plan owns (descriptors of fused launches)
-  ~gfft_plan_s() { for (void *q : device_allocs) (void)hipFree(q); }
+  std::vector<Pass> alt;                        // stand-alone forms of the fused pairs (Pass::alt_first)
+  unsigned id = 0;                              // what a voided fused launch reports (async_errors)
+  int device = 0;                               // the device the plan's tables and descriptors live on
+  std::atomic<bool> fused_off{false};           // a fused launch gave up a wait: the pairs run as stand-alone passes from now on
+  gfft_plan_s();
+  ~gfft_plan_s();
 };
+
+// ---- fused launches that gave up a wait (fft_pow2_impl.h fused_give_up) --------------------------------
+// The kernel writes the plan's id into one pinned host word; the library looks at it on entry to gfft_execute and
+// in gfft_async_error(): the plan named there switches its pairs to stand-alone passes, and the call reports
+// GFFT_ERR_HIP once -- the results of that plan's last execution are invalid, everything else is untouched.
+namespace {
+struct AsyncErrors {
+  std::mutex m;
+  unsigned *flag = nullptr;                    // pinned, device-visible
+  std::map<unsigned, gfft_plan_s *> live;
+  unsigned next_id = 1;
+  unsigned *word() {
+    if (!flag) {
+      void *p = nullptr;
+      if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      flag = static_cast<unsigned *>(p);
+      *flag = 0;
+    }
+    return flag;
+  }
+};
+AsyncErrors &async_errors() {
+  static AsyncErrors a;
+  return a;
+}
+int poll_async_error() {
+  AsyncErrors &a = async_errors();
+  if (!a.flag) return GFFT_OK;
+  const unsigned id = __atomic_load_n(a.flag, __ATOMIC_ACQUIRE);
+  if (!id) return GFFT_OK;
+  std::lock_guard<std::mutex> lock(a.m);
+  __atomic_store_n(a.flag, 0u, __ATOMIC_RELEASE);
+  auto it = a.live.find(id);
+  if (it != a.live.end()) {
+    gfft_plan_s *pl = it->second;
+    pl->fused_off = true;
+    for (const Pass &p : pl->passes)
+      if (p.kind == PK_FUSED2 && p.alt_buf >= 0 && p.alt_bytes > pl->region_bytes[p.alt_buf]) pl->region_bytes[p.alt_buf] = p.alt_bytes;
+  }
+  char msg[256];
+  snprintf(msg, sizeof msg, "a fused launch of plan #%u waited longer than %d ms for another workgroup and gave up (device shared or stalled?): "
+           "the results of that plan's last execution are INVALID; the plan runs its pass pairs as stand-alone launches from now on", id,
+           opts().fuse2_wait_ms);
+  return fail(GFFT_ERR_HIP, msg);
+}
+}  // namespace
+gfft_plan_s::gfft_plan_s() {
+  device = current_device();
+  AsyncErrors &a = async_errors();
+  std::lock_guard<std::mutex> lock(a.m);
+  id = a.next_id++;
+  if (!a.next_id) a.next_id = 1;
+  a.live[id] = this;
+}
+gfft_plan_s::~gfft_plan_s() {
+  {
+    AsyncErrors &a = async_errors();
+    std::lock_guard<std::mutex> lock(a.m);
+    a.live.erase(id);
+  }
+  for (void *q : device_allocs) (void)hipFree(q);
+}
 
 namespace {
 
@@ -375,13 +451,13 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   if (ring <= 0) ring = planes >= 24 ? 12 : 8;
   if (lag <= 0) lag = ring / 2;
   if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1) || planes < 2 * ring || lag < 1 || ring <= lag) return false;
-  const int variant = opts().fuse2 == 2 ? 2 : 1;
+  const int variant = (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1;
   // (fp64 only: the fp32 pairs measured slower than their stand-alone passes, fft_fused_f64.hip)
   if (pl->precision != GFFT_F64 || !fused2_supported_f64(kind, variant, dA.n, dB.n)) return false;
   int ta = 0, tb = 0;
   if (fused2_tiles_f64(kind, variant, dA, dB, &ta, &tb) || ta < 1 || tb < 1) return false;
   // (hand-off accesses carry 32-bit byte offsets inside a slot; tickets are 32-bit)
-  if (slot_bytes >= ((int64_t)1 << 31) || (double)planes * (ta + tb) >= 4.0e9) return false;
+  if (slot_bytes >= ((int64_t)1 << 31) || (double)planes * (ta + tb) >= 1.0e9) return false;     // (tickets < 2^30: a launch that gives up pushes the counter 2^31 on)
   Pass f = a;
   f.kind = PK_FUSED2;
   f.fused_kind = kind;
@@ -396,14 +472,23 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   f.fused.tiles_b = tb;
   f.fused.ring = ring;
   f.fused.lag = lag;
-  f.fused.defer = opts().fuse2_defer ? 1 : 0;
+  f.fused.defer = opts().fuse2_defer;     // 0: at the end of the tile; 1: behind the next tile's loads; 2: behind the next ticket's poll
   f.fused.group = (opts().fuse2_group >= 1 && ta % opts().fuse2_group == 0 && tb % opts().fuse2_group == 0) ? opts().fuse2_group : 1;
   f.fused.a_in_plane = a_in_plane;
   f.fused.b_out_plane = b_out_plane;
   f.fused.slot_bytes = (int64_t)align256((size_t)slot_bytes);
   f.fused.ctr = nullptr;
-  f.fused.spin_limit = 1u << 24;
+  f.fused.wait_ticks = 0;            // (filled in at execution: option fuse2_wait_ms)
+  f.fused.plan_id = pl->id;
+  f.fused.host_flag = nullptr;
   f.fused.debug = 0;
+  f.alt_first = (int)pl->alt.size();
+  pl->alt.push_back(a);
+  pl->alt.push_back(b);
+  for (const Pass *q : {&a, &b})
+    for (int side : {q->src, q->dst})
+      if (side >= BUF_WS && side != BUF_RING) f.alt_buf = side;     // (at most one scratch region: WS of the 3-D schedule, FS of a four-step pair)
+
   size_t ctr_bytes = align256((size_t)(16 + 2 * planes) * sizeof(unsigned));
 #ifdef GFFT_FUSE2_TRACE
   ctr_bytes += 256 + (size_t)1024 * 96 * 16 * sizeof(unsigned long long);       // (fft_pow2_impl.h, GFFT_TRACE_STAMP)
@@ -538,6 +623,7 @@ int plan_fourstep(gfft_plan_s *pl, const Line &L, int64_t n1, int64_t n2) {
       dB.in_os = n1 * S1;  dB.in_ms = S1;  dB.in_is = 1;  dB.in_es = 1;
       dB.out_os = n;  dB.out_ms = 1;  dB.out_is = 1;  dB.out_es = n1;
       if (make_fused2(pl, FUSED_FOURSTEP_ROWS, a, b, dA, dB, (int)outer, n * esz, n * esz, n1 * S1 * esz, &f)) {
+        f.alt_bytes = (size_t)outer * n2 * S2 * esz;
         pl->passes.push_back(f);
         return GFFT_OK;
       }
@@ -546,6 +632,7 @@ int plan_fourstep(gfft_plan_s *pl, const Line &L, int64_t n1, int64_t n2) {
     dA.batch = n2;           // (o, i2, i) with o = 0
     dB.batch = n1;
     if (make_fused2(pl, FUSED_FOURSTEP, a, b, dA, dB, (int)outer, n * esz, n * esz, n2 * S2 * esz, &f)) {
+      f.alt_bytes = (size_t)outer * n2 * S2 * esz;
       pl->passes.push_back(f);
       return GFFT_OK;
     }
@@ -616,7 +703,7 @@ void host_fft_pow2(std::vector<long double> &re, std::vector<long double> &im) {
 
 int get_bluestein(int64_t n, int64_t M, int prec, const void **chirp, const void **B) {
   std::lock_guard<std::mutex> lock(g_tw_mutex);
-  auto key = std::make_pair(n, prec);
+  auto key = std::make_pair(n, dev_prec(prec));
   auto it = g_blue_cache.find(key);
   if (it == g_blue_cache.end()) {
     const long double PI = 3.14159265358979323846264338327950288L;
@@ -742,7 +829,7 @@ int64_t r2r_logical_n(int kind, int64_t n) {
 
 int get_r2r_tables(int kind, int64_t n, int prec, R2RTables *out) {
   std::lock_guard<std::mutex> lock(g_tw_mutex);
-  auto key = std::make_tuple(kind, n, prec);
+  auto key = std::make_tuple(kind, n, dev_prec(prec));
   auto it = g_r2r_cache.find(key);
   if (it == g_r2r_cache.end()) {
     const long double PI = 3.14159265358979323846264338327950288L;
@@ -1112,7 +1199,7 @@ int plan_fused3(gfft_plan_s *pl) {
   // loses what the fusion gains (1024^3 c128, tools/fused2_probe.py: 20.0 ms against 18.4 ms).
   const bool pair_cols_rows = !real && !tr && !flat_out && Pu == nc && opts().fuse2 &&
                               ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && n1 >= 2 * (opts().fuse2_ring > 0 ? opts().fuse2_ring : 8) &&
-                              prec == GFFT_F64 && fused2_supported_f64(FUSED_COLS_ROWS, opts().fuse2 == 2 ? 2 : 1, (int)n0, (int)n2);
+                              prec == GFFT_F64 && fused2_supported_f64(FUSED_COLS_ROWS, (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1, (int)n0, (int)n2);
   const bool cols_first = !inverse && pair_cols_rows;
   // ... and the workspace then is W[i0][k1][c]: the stand-alone axis-1 pass stores on NEAR strides (stores are
   // what far strides hurt), the fused pair's axis-0 tiles read the far (pitched) ones
@@ -1292,6 +1379,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "fuse2_wlayout")) opts().fuse2_wlayout = value;
   else if (!strcmp(key, "fuse2_group")) opts().fuse2_group = value;
   else if (!strcmp(key, "fuse2_defer")) opts().fuse2_defer = value;
+  else if (!strcmp(key, "fuse2_wait_ms")) opts().fuse2_wait_ms = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
@@ -1511,6 +1599,13 @@ int gfft_plan_create_r2r(gfft_plan *plan, int ndims, const int64_t *sizes, int n
 
 int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void *stream) {
   if (!pl || !d_in || !d_out) return fail(GFFT_ERR_INVALID, "null argument");
+  {
+    // a fused launch of an earlier execution gave up a wait: report it now, once (the plan named in the message
+    // has been switched to stand-alone passes; calling again runs it that way)
+    int rc = poll_async_error();
+    if (rc) return rc;
+  }
+  if (current_device() != pl->device) return fail(GFFT_ERR_INVALID, "the plan was made on another device than the calling thread's current one");
   if ((pl->kind == GFFT_R2C || pl->kind == GFFT_C2R) && d_in == d_out)
     return fail(GFFT_ERR_INVALID, "in-place real transforms are not supported");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1548,14 +1643,33 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
   }
   for (const Pass &p : pl->passes) {
     PassDesc d = p.d;
+    if (p.kind == PK_FUSED2 && pl->fused_off) {
+      // the pair as its two stand-alone passes (a fused launch of this plan gave up a wait, poll_async_error)
+      for (int k = 0; k < 2; ++k) {
+        const Pass &q = pl->alt[p.alt_first + k];
+        PassDesc dq = q.d;
+        const bool sc = k == 1 && p.carries_scale;
+        if (sc) dq.scale = scale;
+        HIP_TRY(run_pass(pl, q, dq, bufs[q.src], bufs[q.dst], sc ? scale : 1.0, s));
+      }
+      HIP_TRY(mark());
+      continue;
+    }
     if (p.kind == PK_FUSED2) {
       PassDesc d2 = p.d2;
       if (p.carries_scale) d2.scale = scale;
       FusedDesc f = p.fused;
       char *ring = static_cast<char *>(bufs[BUF_RING]);
       f.ctr = reinterpret_cast<unsigned *>(ring + (size_t)f.ring * (size_t)f.slot_bytes);
+      {
+        AsyncErrors &ae = async_errors();
+        if (!ae.flag) { std::lock_guard<std::mutex> lock(ae.m); (void)ae.word(); }
+        f.host_flag = ae.flag;
+        const int ms = opts().fuse2_wait_ms;
+        f.wait_ticks = ms <= 0 ? 0u : (ms > 40000 ? 4000000000u : (unsigned)ms * 100000u);      // 100 MHz ticks
+      }
       static const int debug = getenv("GFFT_FUSE2_DEBUG") ? atoi(getenv("GFFT_FUSE2_DEBUG")) : 0;
-      if (debug) { f.spin_limit = 1u << 12; f.debug = (unsigned)debug; }
+      if (debug) { f.wait_ticks = 100000u; f.host_flag = nullptr; f.debug = (unsigned)debug; }      // (1 ms; counters printed below)
       HIP_TRY(launch_fused2_f64(p.fused_kind, p.fused_variant, d, d2, p.dev_descs, f, bufs[p.src], ring, bufs[p.dst], s));
       if (debug) {      // developer aid: the launch's counters (tickets drawn, waits given up, tiles per plane)
         HIP_TRY(hipStreamSynchronize(s));
@@ -1954,6 +2068,11 @@ int gfft_plan_set_split_slabs(gfft_plan pl, int side, int nblocks, int64_t rows_
 /* free the shared scratch buffers (they are otherwise kept for the life of the process) */
 int gfft_scratch_release(void) { return scratch_pool().release(true); }
 
+/* Did a fused launch give up a wait since the last look?  GFFT_OK, or GFFT_ERR_HIP once per event with the plan
+ * named in gfft_last_error().  Does not synchronise: call it after the stream (or device) has been synchronised to
+ * learn whether the results that synchronisation waited for are valid. */
+int gfft_async_error(void) { return poll_async_error(); }
+
 int gfft_plan_destroy(gfft_plan pl) {
   if (!pl) return GFFT_OK;
   delete pl;
@@ -1974,6 +2093,10 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
   for (const Pass &p : pl->passes) {
     if (p.kind == PK_FUSED2) {
       static const char *fk[] = {"rows -> strided", "strided -> rows", "four-step", "2-D planes: rows -> strided", "four-step: strided -> rows, transposed on store"};
+      if (pl->fused_off)
+        snprintf(line, sizeof line, "  pair (%s) n=%d then n=%d as two stand-alone passes (a fused launch gave up a wait)%s  %s -> %s\n",
+                 fk[p.fused_kind], p.d.n, p.d2.n, p.carries_scale ? " [scale]" : "", bufn[p.src], bufn[p.dst]);
+      else
       snprintf(line, sizeof line, "  fused pair (%s) n=%d then n=%d: %d planes, %d + %d tiles per plane, ring of %d slots x %lld KiB, one persistent launch%s  %s -> %s\n",
                fk[p.fused_kind], p.d.n, p.d2.n, p.fused.planes, p.fused.tiles_a, p.fused.tiles_b, p.fused.ring,
                (long long)(p.fused.slot_bytes >> 10), p.carries_scale ? " [scale]" : "", bufn[p.src], bufn[p.dst]);

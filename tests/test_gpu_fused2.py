@@ -19,7 +19,7 @@ def _opts(**kw):
 @pytest.fixture(autouse=True)
 def _restore():
     yield
-    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=30)
+    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=30, fuse2_wait_ms=2000)
 
 
 def _plans(shape, axes, fuse, ring=8, lag=4, kinds=15, dt='D'):
@@ -186,3 +186,80 @@ def test_fused_plans_execute_in_place(shape, axes):
         got = np.asarray(f1.execute_scaled(a, a, 1.0))
         assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), rep
     f1.destroy()
+
+
+@pytest.mark.parametrize('shape,axes', [((1024, 40, 1024), (0, 1, 2)), ((32, 1 << 20), (1,))])
+def test_a_fused_launch_that_gives_up_a_wait_is_an_error_and_the_plan_recovers(shape, axes):
+    """A wait inside a fused launch that outlasts `fuse2_wait_ms` (a device shared with a long foreign kernel, a
+    debugger) voids the launch: no hang, no trap that would poison the HIP context and every other plan of the
+    process.  The library reports it from its next call as a RuntimeError -- the reference's error contract,
+    mpi4py_fft/fftw/fftw_xfftn.pyx:152-153 -- and the SAME plan then runs the pair as stand-alone passes."""
+    import torch
+    from mpi4py_fft_amd import _lib
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    ref = np.fft.fftn(x, axes=axes)
+    a, f, b = _plans(shape, axes, 1, 8, 4, 31)
+    assert 'fused pair' in _lib.engine().plan_describe(f._plan)
+    a[...] = x
+    good = np.asarray(f.execute_scaled(a, f.output_array, 1.0)).copy()       # the healthy launch first
+    assert np.abs(good - ref).max() <= 2e-10 * np.abs(ref).max()
+    _opts(fuse2_wait_ms=0)                         # every wait gives up at once
+    f.execute_scaled(a, f.output_array, 1.0)       # enqueues; the launch voids itself on the device
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='gave up'):
+        np.asarray(f.output_array)                 # reading results: the failure surfaces here ...
+    _lib.check_async()                             # ... once
+    _opts(fuse2_wait_ms=2000)
+    desc = _lib.engine().plan_describe(f._plan)
+    assert 'fused pair' not in desc and 'two stand-alone passes' in desc, desc
+    for rep in range(2):
+        got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
+        assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max()
+    # the process, the context and the other plans are alive: the backward plan still runs fused
+    assert 'fused pair' in _lib.engine().plan_describe(b._plan)
+    back = np.asarray(b.execute_scaled(f.output_array, b.output_array, 1.0 / np.prod([shape[i] for i in axes])))
+    assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
+    f.destroy()
+    b.destroy()
+
+
+def test_a_pending_failure_is_reported_by_the_next_execute():
+    import torch
+    from mpi4py_fft_amd import _lib
+    shape = (1024, 32, 1024)
+    a, f, b = _plans(shape, (0, 1, 2), 1, 8, 4, 15)
+    _opts(fuse2_wait_ms=0)
+    f.execute_scaled(a, f.output_array, 1.0)
+    torch.cuda.synchronize()
+    _opts(fuse2_wait_ms=2000)
+    with pytest.raises(RuntimeError, match='stand-alone launches from now on'):
+        f.execute_scaled(a, f.output_array, 1.0)
+    f.execute_scaled(a, f.output_array, 1.0)        # and then it just works
+    torch.cuda.synchronize()
+    _lib.check_async()
+    f.destroy()
+    b.destroy()
+
+
+def test_the_round3_kernel_set_is_still_selectable_and_agrees():
+    """fuse2 = 3: the pairs on 16 values per thread / two LDS exchanges (the default, 1, runs 32 values per thread and
+    one exchange): same results to rounding, both against numpy."""
+    shape = (1024, 16, 1024)
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    ref = np.fft.fftn(x)
+    outs = []
+    for fuse in (1, 3):
+        a, f, b = _plans(shape, (0, 1, 2), fuse, 8, 4, 15)
+        from mpi4py_fft_amd import _lib
+        assert 'fused pair (strided -> rows)' in _lib.engine().plan_describe(f._plan)
+        a[...] = x
+        got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
+        assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max()
+        back = np.asarray(b.execute_scaled(f.output_array, b.output_array, 1.0 / x.size))
+        assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
+        outs.append(got.copy())
+        f.destroy()
+        b.destroy()
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-13 * np.abs(ref).max()
