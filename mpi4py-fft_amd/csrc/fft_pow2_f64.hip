@@ -103,6 +103,8 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
       case 1024:
         switch (variant) {
           default: return P64F(1024, 16, 16, true, 4, 8, 16, 16, 4);  // 256-B segments, 1024 threads, <=128 VGPRs
+          case 15: return P64F(1024, 32, 16, true, 2, 8, 32, 32);     // 32 values per thread, ONE exchange, 512 threads, <=256 VGPRs
+          case 16: return P64F(1024, 32, 16, true, 2, 8 | 3, 32, 32); // ... with non-temporal loads and stores
 #ifdef GFFT_VARIANTS
           case 1: return P64F(1024, 8, 8, true, 1, 8, 8, 8, 8, 2);    // 128-B segments, 1024 threads, 86 VGPRs
           case 2: return P64F(1024, 16, 8, true, 1, 8, 16, 16, 4);    // 512 threads, ~134 VGPRs: 1 tile/CU

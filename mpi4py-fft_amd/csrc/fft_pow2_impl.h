@@ -952,10 +952,17 @@ __device__ __forceinline__ void fused_wait(const unsigned *flag, unsigned want, 
 #define GFFT_TRACE_STAMP(i)
 #endif
 
+// workgroups of one fused launch resident per CU: two where both the LDS and the register file (128 VGPRs per thread
+// then) allow it, else one -- which may use 256 VGPRs per thread when it has at most 512 threads
+template <typename A, typename B> constexpr int fused2_per_cu() {
+  constexpr size_t lds = A::lds > B::lds ? A::lds : B::lds;
+  constexpr int budget = (A::regs_per_thread > 64 || B::regs_per_thread > 64) ? 256 : 128;       // VGPRs per thread the tiles want
+  return (2 * A::threads / 256 * budget <= 512 && 2 * lds + 1024 <= 160 * 1024) ? 2 : 1;
+}
 // (workgroups of <= 512 threads: two per CU -- one computes while the other loads / stores --, which the
 // register budget must allow: at most 128 VGPRs, i.e. 4 waves per SIMD)
 template <typename A, typename B>
-__global__ void __launch_bounds__(A::threads, A::threads > 512 ? 1 : (A::regs_per_thread > 64 ? 2 : 4))
+__global__ void __launch_bounds__(A::threads, (fused2_per_cu<A, B>() * A::threads / 256))
 fft_fused2_kernel(const PassDesc *__restrict__ descs, FusedDesc f, double scale_a, double scale_b, const void *__restrict__ in,
                   void *__restrict__ ring, void *__restrict__ out) {
   static_assert(A::threads == B::threads, "both passes of a fused pair run on one workgroup shape");
@@ -1121,7 +1128,7 @@ hipError_t launch_fused2(const PassDesc &dA, const PassDesc &dB, const PassDesc 
   if (e != hipSuccess) return e;
   // as many workgroups as fit the CUs at once (the exchange tile of a 1024-thread workgroup fills the LDS,
   // two 512-thread ones share it): persistent, tickets do the load balancing
-  const int per_cu = (A::threads <= 512 && 2 * lds + 1024 <= 160 * 1024) ? 2 : 1;
+  constexpr int per_cu = fused2_per_cu<A, B>();
   hipLaunchKernelGGL(kern, dim3(cus * per_cu), dim3(A::threads), lds, s, dev_descs, f, dA.scale, dB.scale, in, ring, out);
   return hipGetLastError();
 }

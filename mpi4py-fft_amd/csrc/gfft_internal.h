@@ -174,7 +174,10 @@ struct FusedDesc {
   unsigned *host_flag;               // pinned host word the library polls (plan.cpp poll_async_error); may be null
   unsigned *ctr;                     // [0] ticket, [1] launch void (a wait gave up), [16 + p] A tiles of plane p stored, [16 + planes + p] B tiles done
 };
-enum FusedKind { FUSED_ROWS_COLS = 0, FUSED_COLS_ROWS = 1, FUSED_FOURSTEP = 2, FUSED_PLANES_2D = 3, FUSED_FOURSTEP_ROWS = 4 };   // (3: the kernels of 0; 4: four-step with a row second pass)
+enum FusedKind { FUSED_ROWS_COLS = 0, FUSED_COLS_ROWS = 1, FUSED_FOURSTEP = 2, FUSED_PLANES_2D = 3, FUSED_FOURSTEP_ROWS = 4,   // (3: the kernels of 0; 4: four-step with a row second pass)
+                 // real transforms (fft_fused_real_f64.hip): [packed-real r2c rows -> strided] on the contiguous planes of a 3-D
+                 // r2c schedule, and [strided -> packed-real c2r rows] of the c2r schedule
+                 FUSED_R2C_PLANES = 5, FUSED_COLS_C2R = 6 };
 // variant: 1 = the default kernels (32 values per thread, one exchange, one 512-thread workgroup per CU); 3 = the round-3
 // kernels (16 values per thread, two exchanges, 1024 threads); 2 / 4 = (make VARIANTS=1) 8 lines per tile, two workgroups per CU
 bool fused2_supported_f64(int kind, int variant, int n_a, int n_b);
@@ -182,6 +185,11 @@ int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &
 // dev_descs: {dA, dB} in device memory (uploaded when the plan was made; the scale factors travel as arguments)
 hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs,
                              const FusedDesc &f, const void *in, void *ring, void *out, hipStream_t s);
+// ... the two real kinds (n_a / n_b: the passes' lengths -- COMPLEX length of the packed-real rows)
+bool fused2_real_supported_f64(int kind, int n_a, int n_b);
+int fused2_real_tiles_f64(int kind, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b);
+hipError_t launch_fused2_real_f64(int kind, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs, const FusedDesc &f,
+                                  const void *in, void *ring, void *out, hipStream_t s);
 
 // packed-real row kernels (fft_real_*.hip): d.n = complex length = half the real length
 bool real_half_supported(int n_complex);

@@ -77,7 +77,7 @@ struct Options {
   int fuse2_group = 1;       // tiles per ticket
   int fuse2_defer = 0;       // settle an A tile's counter behind the next tile's loads (A/B)
   int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
-  int fuse2_kinds = 30;      // which pairs (bit = FusedKind): measured per kind, see make_fused2
+  int fuse2_kinds = 126;     // which pairs (bit = FusedKind): measured per kind, see make_fused2
   int fuse2_wait_ms = 2000;  // wall-clock limit of one wait inside a fused launch before the launch is voided (0: at once -- test hook)
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
@@ -453,9 +453,11 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1) || planes < 2 * ring || lag < 1 || ring <= lag) return false;
   const int variant = (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1;
   // (fp64 only: the fp32 pairs measured slower than their stand-alone passes, fft_fused_f64.hip)
-  if (pl->precision != GFFT_F64 || !fused2_supported_f64(kind, variant, dA.n, dB.n)) return false;
+  const bool real_kind = kind == FUSED_R2C_PLANES || kind == FUSED_COLS_C2R;
+  if (pl->precision != GFFT_F64) return false;
+  if (real_kind ? !fused2_real_supported_f64(kind, dA.n, dB.n) : !fused2_supported_f64(kind, variant, dA.n, dB.n)) return false;
   int ta = 0, tb = 0;
-  if (fused2_tiles_f64(kind, variant, dA, dB, &ta, &tb) || ta < 1 || tb < 1) return false;
+  if ((real_kind ? fused2_real_tiles_f64(kind, dA, dB, &ta, &tb) : fused2_tiles_f64(kind, variant, dA, dB, &ta, &tb)) || ta < 1 || tb < 1) return false;
   // (hand-off accesses carry 32-bit byte offsets inside a slot; tickets are 32-bit)
   if (slot_bytes >= ((int64_t)1 << 31) || (double)planes * (ta + tb) >= 1.0e9) return false;     // (tickets < 2^30: a launch that gives up pushes the counter 2^31 on)
   Pass f = a;
@@ -1200,6 +1202,13 @@ int plan_fused3(gfft_plan_s *pl) {
   const bool pair_cols_rows = !real && !tr && !flat_out && Pu == nc && opts().fuse2 &&
                               ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && n1 >= 2 * (opts().fuse2_ring > 0 ? opts().fuse2_ring : 8) &&
                               prec == GFFT_F64 && fused2_supported_f64(FUSED_COLS_ROWS, (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1, (int)n0, (int)n2);
+  // Real transforms: forward [r2c rows -> axis 1] on the contiguous planes i0 of the flat_out schedule (FUSED_R2C_PLANES),
+  // backward [axis 0 -> c2r rows] on the planes i1 (FUSED_COLS_C2R), as the complex schedule runs its last two passes
+  const int ring_min = 2 * (opts().fuse2_ring > 0 ? opts().fuse2_ring : 8);
+  const bool pair_real = real && !tr && opts().fuse2 && prec == GFFT_F64 && n2 % 2 == 0 && opts().real_half &&
+                         (inverse ? (((opts().fuse2_kinds >> FUSED_COLS_C2R) & 1) && n1 >= ring_min && fused2_real_supported_f64(FUSED_COLS_C2R, (int)n0, (int)(n2 / 2)))
+                                  : (((opts().fuse2_kinds >> FUSED_R2C_PLANES) & 1) && flat_out && n0 >= ring_min && fused2_real_supported_f64(FUSED_R2C_PLANES, (int)(n2 / 2), (int)n1)));
+  if (pair_real && inverse && opts().fuse2_wlayout) { w_i0 = n1 * P; w_i1 = P; }     // (as under the complex pair, below)
   const bool cols_first = !inverse && pair_cols_rows;
   // ... and the workspace then is W[i0][k1][c]: the stand-alone axis-1 pass stores on NEAR strides (stores are
   // what far strides hurt), the fused pair's axis-0 tiles read the far (pitched) ones
@@ -1257,6 +1266,43 @@ int plan_fused3(gfft_plan_s *pl) {
       if (ok) { f.bytes2 = 1; pl->passes[base + 1] = f; pl->passes.erase(pl->passes.begin() + base + 2); }
     }
   }
+  if (pair_real && pl->passes.size() >= 3) {
+    const size_t base = pl->passes.size() - 3;
+    // algorithmic bytes of a pass, as the loop above counts them
+    auto alg = [&](const Pass &p) {
+      const bool half = p.d.mode == MODE_R2C_H || p.d.mode == MODE_C2R_H;
+      const double lines = p.data_inner ? (double)p.d.batch / (double)p.d.inner * (double)p.data_inner : (double)p.d.batch;
+      const double n = half ? 2.0 * p.d.n : p.d.n;
+      const bool r2c = p.d.mode == MODE_R2C || p.d.mode == MODE_R2C_H, c2r = p.d.mode == MODE_C2R || p.d.mode == MODE_C2R_H;
+      return lines * ((c2r ? (double)nc_full : n) * (r2c ? prec : esz) + (r2c ? (double)nc_full : n) * (c2r ? prec : esz));
+    };
+    Pass f;
+    if (!inverse) {
+      Pass &p1 = pl->passes[base], &p2 = pl->passes[base + 1];
+      if (p1.d.mode == MODE_R2C_H && p2.cols) {
+        PassDesc dA = p1.d, dB = p2.d;                // r2c rows of plane i0: IN -> slot[i1][c];  axis 1: slot -> W[i0][k1][c]
+        dA.batch = n1; dA.inner = 1; dA.in_os = n2 / 2; dA.in_is = 0; dA.out_os = P; dA.out_is = 0;
+        dB.batch = Pu; dB.in_os = 0; dB.out_os = 0; dB.in_es = P;
+        if (make_fused2(pl, FUSED_R2C_PLANES, p1, p2, dA, dB, (int)n0, n1 * n2 * prec, w_i0 * esz, n1 * P * esz, &f)) {
+          f.bytes2 = alg(p1) + alg(p2);
+          pl->passes[base] = f;
+          pl->passes.erase(pl->passes.begin() + base + 1);
+        }
+      }
+    } else {
+      Pass &p2 = pl->passes[base + 1], &p3 = pl->passes[base + 2];
+      if (p3.d.mode == MODE_C2R_H && p2.cols) {
+        PassDesc dA = p2.d, dB = p3.d;                // axis 0 of plane i1: W -> slot[i0][c];  c2r rows: slot -> OUT
+        dA.batch = Pu; dA.in_os = 0; dA.out_os = 0; dA.out_es = P;
+        dB.batch = n0; dB.inner = 1; dB.in_is = 0; dB.out_is = 0; dB.in_os = P; dB.out_os = n1 * n2 / 2;
+        if (make_fused2(pl, FUSED_COLS_C2R, p2, p3, dA, dB, (int)n1, w_i1 * esz, n2 * prec, n0 * P * esz, &f)) {
+          f.bytes2 = alg(p2) + alg(p3);
+          pl->passes[base + 1] = f;
+          pl->passes.erase(pl->passes.begin() + base + 2);
+        }
+      }
+    }
+  }
   pl->fused3 = true;
   // fp32 strided passes of this schedule run between pitched rows, where two 512-thread workgroups
   // per CU on 128-byte segments (variant 2 of the n = 512 / 1024 tables: one computes while the other
@@ -1265,6 +1311,10 @@ int plan_fused3(gfft_plan_s *pl) {
   // 512^3 c64 1.39 / 1.35 -> 1.30 / 1.30 ms, 1024^3 c64 10.7 / 10.9 -> 10.6 / 11.0 ms.  (On natural
   // power-of-two strides -- the stage arrays of multi-GPU transforms -- the wide tile stays ahead.)
   if (prec == GFFT_F32 && pl->variant_cols == 0) pl->variant_cols = 2;
+  // fp64 strided passes of length 1024 in this schedule: 32 values per thread and ONE LDS exchange on 512 threads,
+  // non-temporal loads and stores (variant 16 of the table) -- the CU is back at its memory work sooner: same arrays,
+  // plans alternating, 1024^3 c128 per step 32.85 -> 32.51 ms, the pass 6.62 -> 6.45 ms (profiles/r04_ab_cols_r32.txt)
+  if (prec == GFFT_F64 && !real && pl->variant_cols == 0) pl->variant_cols = 16;
   // Workgroups per launch.  Each walks tiles block, block + grid, ...; more, shorter walks balance the
   // tail better, too many lose the overlap of one tile's stores with the next one's loads.  Clean A/B
   // on fixed caller arrays (tools/ab_option_probe.py grid_cap ...), fwd + bwd per step: 1024^3 c128
@@ -1670,7 +1720,10 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
       }
       static const int debug = getenv("GFFT_FUSE2_DEBUG") ? atoi(getenv("GFFT_FUSE2_DEBUG")) : 0;
       if (debug) { f.wait_ticks = 100000u; f.host_flag = nullptr; f.debug = (unsigned)debug; }      // (1 ms; counters printed below)
-      HIP_TRY(launch_fused2_f64(p.fused_kind, p.fused_variant, d, d2, p.dev_descs, f, bufs[p.src], ring, bufs[p.dst], s));
+      if (p.fused_kind == FUSED_R2C_PLANES || p.fused_kind == FUSED_COLS_C2R)
+        HIP_TRY(launch_fused2_real_f64(p.fused_kind, d, d2, p.dev_descs, f, bufs[p.src], ring, bufs[p.dst], s));
+      else
+        HIP_TRY(launch_fused2_f64(p.fused_kind, p.fused_variant, d, d2, p.dev_descs, f, bufs[p.src], ring, bufs[p.dst], s));
       if (debug) {      // developer aid: the launch's counters (tickets drawn, waits given up, tiles per plane)
         HIP_TRY(hipStreamSynchronize(s));
         std::vector<unsigned> h(16 + 2 * (size_t)f.planes);
@@ -1728,9 +1781,10 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
   static const char *kinds[] = {"", "embed", "mul-B", "extract"};
   if (p.kind == PK_FUSED2) {
     // two axis passes in one launch: the algorithmic bytes of both (one read + one write of the array each)
-    static const char *fk[] = {"fused rows+cols", "fused cols+rows", "fused four-step", "fused 2-D rows+cols", "fused four-step (rows)"};
+    static const char *fk[] = {"fused rows+cols", "fused cols+rows", "fused four-step", "fused 2-D rows+cols", "fused four-step (rows)",
+                               "fused r2c-rows+cols", "fused cols+c2r-rows"};
     snprintf(buf, len, "%s n=%dx%d", fk[p.fused_kind], p.d.n, p.d2.n);
-    if (bytes) *bytes = (double)p.fused.planes * 2.0 * pl->precision *
+    if (bytes) *bytes = p.bytes2 > 1 ? p.bytes2 : (double)p.fused.planes * 2.0 * pl->precision *
                         ((double)p.d.batch * 2.0 * p.d.n + (double)p.d2.batch * 2.0 * p.d2.n);
     return GFFT_OK;
   }
@@ -2092,7 +2146,8 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
   static const char *bufn[] = {"IN", "OUT", "WS", "FS", "AUX", "RING"};
   for (const Pass &p : pl->passes) {
     if (p.kind == PK_FUSED2) {
-      static const char *fk[] = {"rows -> strided", "strided -> rows", "four-step", "2-D planes: rows -> strided", "four-step: strided -> rows, transposed on store"};
+      static const char *fk[] = {"rows -> strided", "strided -> rows", "four-step", "2-D planes: rows -> strided", "four-step: strided -> rows, transposed on store",
+                                 "r2c rows -> strided", "strided -> c2r rows"};
       if (pl->fused_off)
         snprintf(line, sizeof line, "  pair (%s) n=%d then n=%d as two stand-alone passes (a fused launch gave up a wait)%s  %s -> %s\n",
                  fk[p.fused_kind], p.d.n, p.d2.n, p.carries_scale ? " [scale]" : "", bufn[p.src], bufn[p.dst]);

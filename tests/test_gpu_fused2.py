@@ -19,7 +19,7 @@ def _opts(**kw):
 @pytest.fixture(autouse=True)
 def _restore():
     yield
-    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=30, fuse2_wait_ms=2000)
+    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=126, fuse2_wait_ms=2000)
 
 
 def _plans(shape, axes, fuse, ring=8, lag=4, kinds=15, dt='D'):
@@ -263,3 +263,44 @@ def test_the_round3_kernel_set_is_still_selectable_and_agrees():
         f.destroy()
         b.destroy()
     assert np.abs(outs[0] - outs[1]).max() <= 1e-13 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('shape', [(40, 1024, 1024), (1024, 40, 1024), (48, 1024, 2048), (1024, 48, 2048)])
+def test_fused_pairs_of_real_transforms(shape):
+    """r2c: [packed-real rows -> axis 1] on the contiguous planes i0; c2r: [axis 0 -> packed-real rows] on the planes
+    i1 (csrc/fft_fused_real_f64.hip) -- the reference's default dtype is real (mpifft.py:202, fftw/xfftn.py:173-326).
+    Against numpy, against the unfused plans of the same library, and reproducible run to run."""
+    from mpi4py_fft_amd import _lib, fftw, zeros
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(shape)
+    ref = np.fft.rfftn(x)
+    cshape = ref.shape
+    res = {}
+    for fuse in (0, 1):
+        _opts(fuse2=fuse, fuse2_ring=8, fuse2_lag=4, fuse2_kinds=126)
+        a = zeros(shape, 'd')
+        f = fftw.rfftn(a, axes=(0, 1, 2))
+        c = zeros(cshape, 'D')
+        b = fftw.irfftn(c, s=shape, axes=(0, 1, 2))
+        df, db = _lib.engine().plan_describe(f._plan), _lib.engine().plan_describe(b._plan)
+        if fuse:
+            assert ('fused pair (r2c rows -> strided)' in df) == (shape[1] == 1024), df
+            assert ('fused pair (strided -> c2r rows)' in db) == (shape[0] == 1024 and shape[2] == 1024), db
+        else:
+            assert 'fused pair' not in df + db
+        a[...] = x
+        for rep in range(3):
+            got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
+            assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max(), (fuse, rep)
+            if rep == 0:
+                first = got.copy()
+            assert np.array_equal(got, first), ('forward not reproducible', fuse, rep)
+        c[...] = ref
+        for rep in range(3):
+            back = np.asarray(b.execute_scaled(c, b.output_array, 1.0 / x.size))
+            assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max(), (fuse, rep)
+        res[fuse] = (first, back.copy())
+        f.destroy()
+        b.destroy()
+    assert np.abs(res[0][0] - res[1][0]).max() <= 1e-13 * np.abs(ref).max()
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-13 * np.abs(x).max()
