@@ -131,3 +131,132 @@ def test_single_rank_3d_schedule_vs_oracle(shape, dt):
         fft.destroy()
     finally:
         _lib.set_option('fused3_min_mib', 32)
+
+
+# ---- the multi-rank BASELINE configurations at FULL size, as thread-ranks on one GPU ------------------------
+# C3 (512^3 complex128 on 2 ranks, slab) and C4 (1024^3 complex128 on 8 ranks: pencil grid (4,2,1), and the slab
+# grid (8,1,1)) fit one 288 GB device with every rank a thread and tests/fake_rccl as the wire.  What this catches
+# before the first real multi-GPU run: 32-bit offsets, pitches and chunk plans at the real sizes of every stage
+# (csrc/plan.cpp refuses a side beyond 2^31 elements: none of the stages here may hit that).  The reference runs its
+# distributed tests the same way at 2 and 4 ranks, tests/runtests.sh:21-36, tests/test_mpifft.py:144-177.
+def _line_partial(x, start, k0, k1, n0, n1):
+    """sum over the LOCAL (i0, i1) of x[i0, i1, :] e^{-2 pi i (k0 I0 / n0 + k1 I1 / n1)}, I = global indices: this
+    rank's share of the (k0, k1) line before its transform along axis 2 (float64 on the device)."""
+    import torch
+    l0, l1 = x.shape[0], x.shape[1]
+    i0 = torch.arange(start[0], start[0] + l0, device='cuda', dtype=torch.float64)
+    i1 = torch.arange(start[1], start[1] + l1, device='cuda', dtype=torch.float64)
+    w0 = torch.polar(torch.ones_like(i0), -2 * np.pi * ((k0 * i0) % n0) / n0)
+    w1 = torch.polar(torch.ones_like(i1), -2 * np.pi * ((k1 * i1) % n1) / n1)
+    acc = torch.zeros(x.shape[2], device='cuda', dtype=torch.complex128)
+    for a in range(0, l0, 32):
+        acc += torch.einsum('a,b,abc->c', w0[a:a + 32], w1, x[a:a + 32])
+    return acc.cpu().numpy()
+
+
+@pytest.mark.parametrize('name,P,n,grid', [('C3', 2, 512, None), ('C4', 8, 1024, None), ('C4-slab', 8, 1024, [8, 1, 1])])
+def test_multi_rank_baseline_configs_at_full_size_on_thread_ranks(name, P, n, grid):
+    import torch
+    from tests import cases, thread_comm
+    from tests.test_gpu_c5 import _c_dft
+    import os, subprocess
+    from mpi4py_fft_amd import PFFT, newDistArray, _lib
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    _lib.lib().gfft_scratch_release()           # (workspaces earlier tests left in libgfft's per-stream pool)
+    free, _ = torch.cuda.mem_get_info()
+    need = 40 if n == 512 else 200
+    if free < need * 2 ** 30:
+        pytest.skip('needs ~%d GiB of HBM, %d free' % (need, free >> 30))
+    here = os.path.dirname(os.path.abspath(__file__))
+    src, so = os.path.join(here, 'fake_rccl', 'fake_rccl.cpp'), os.path.join(here, 'fake_rccl', 'libfake_rccl.so')
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(['/opt/rocm/bin/hipcc', '-O2', '-std=c++17', '-fPIC', '-shared', '-x', 'hip', '--offload-arch=gfx950', src, '-o', so])
+    _lib.check_wire(_lib.lib().gfft_rccl_load(so.encode()))
+    shape = (n, n, n)
+    kw = {} if grid is None else {'grid': grid}
+    lines = [(3, 5), (n - 1, n - 1), (n // 2, 1), (n // 2 + 7, n // 4 + 3), (0, n // 2), (17, 0)]
+
+    def body(comm):
+        r = comm.Get_rank()
+        staged = PFFT(comm, shape, dtype='D', wire='torch', exchange='direct', **{k: list(v) for k, v in kw.items()})
+        pin, pout = staged.pencil
+        geo = dict(dims=[c.Get_size() for c in staged.subcomm], in_shape=tuple(pin.subshape), in_start=tuple(pin.substart),
+                   mid_shape=tuple(staged.transfer[0].subshapeB) if staged.transfer else None,
+                   out_shape=tuple(pout.subshape), out_start=tuple(pout.substart))
+        u = newDistArray(staged, False)
+        g = torch.Generator(device='cuda').manual_seed(4321 + r)
+        ur = torch.view_as_real(u.tensor)
+        for i in range(0, ur.shape[0], 32):
+            ur[i:i + 32].copy_(torch.randn(ur[i:i + 32].shape, generator=g, device='cuda', dtype=torch.float64))
+        def fingerprint(t):        # bit-exact: wrap-around sum and xor-fold of the raw 64-bit words
+            w = torch.view_as_real(t).view(torch.int64).reshape(-1)
+            return int(w.sum().item()), int((w ^ (w >> 17)).sum().item())
+        u0 = u.tensor.clone()
+        e_phys = float((torch.view_as_real(u0) ** 2).sum().item())
+        # this rank's share of six output lines (before their transform along axis 2)
+        parts = [_line_partial(u0, pin.substart, k0, k1, n, n) for k0, k1 in lines]
+        a = staged.forward(u).tensor
+        e_spec = float((torch.view_as_real(a) ** 2).sum().item())
+        fa = fingerprint(a)
+        pieces = []                # ... and the pieces of those lines this rank holds
+        for k0, k1 in lines:
+            j1 = k1 - pout.substart[1]
+            pieces.append((pout.substart[2], a[k0, j1].cpu().numpy()) if 0 <= j1 < pout.subshape[1] else None)
+        sb = staged.backward().tensor
+        num = float(((torch.view_as_real(sb) - torch.view_as_real(u0)) ** 2).sum().item())
+        fb = fingerprint(sb)
+        assert staged.pipeline is None
+        staged.destroy()
+        del sb, a, u0, staged, pin, pout
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        comm.barrier()
+        piped = PFFT(comm, shape, dtype='D', wire='native', exchange='direct', **{k: list(v) for k, v in kw.items()})
+        assert piped.pipeline is not None
+        info = piped.pipeline.describe()
+        same_f = fingerprint(piped.forward(u).tensor) == fa
+        same_b = fingerprint(piped.backward().tensor) == fb
+        piped.destroy()
+        return geo, e_phys, e_spec, num, same_f, same_b, parts, pieces, info
+
+    try:
+        res = cases.run_ranks(P, body)
+    finally:
+        _lib.lib().gfft_rccl_load(None)
+    # geometry: the reference's own (tests/golden/geometry.npz, Appendix A of SURVEY.md), or the oracle's for the slab grid
+    ref = O.OPFFT(P, shape, dtype='D', **kw)
+    gold = cases.load('geometry')[name + '_P%d' % P] if grid is None else None
+    for r, (geo, *_rest) in enumerate(res):
+        assert geo['in_shape'] == tuple(ref.pencil_in[r].subshape) and geo['in_start'] == tuple(ref.pencil_in[r].substart)
+        assert geo['out_shape'] == tuple(ref.pencil_out[r].subshape) and geo['out_start'] == tuple(ref.pencil_out[r].substart)
+        if gold is not None:
+            assert list(gold[r][8]) == geo['dims']
+            assert tuple(gold[r][0]) == geo['in_shape'] and tuple(gold[r][1]) == geo['in_start']
+            if P > 2:
+                assert tuple(gold[r][4]) == geo['mid_shape']
+            assert tuple(gold[r][6]) == geo['out_shape'] and tuple(gold[r][7]) == geo['out_start']
+    N = float(n) ** 3
+    e_phys = sum(x[1] for x in res)
+    e_spec = sum(x[2] for x in res)
+    assert abs(e_phys / N - e_spec) <= 1e-10 * e_phys / N, (e_phys / N, e_spec)                # Parseval (forward carries 1/N)
+    rt = np.sqrt(sum(x[3] for x in res) / e_phys)
+    assert rt <= 1e-10 and rt < 1e-14, rt                                                      # the north-star round trip
+    assert all(x[4] for x in res) and all(x[5] for x in res), 'pipelined path differs from the staged one'
+    assert all(any(e['chunks'] > 1 for e in x[8]) for x in res), res[0][8]
+    # six lines of the forward transform against the DFT by definition in long double (oracle/dft_oracle.c)
+    dft = _c_dft()
+    for li, (k0, k1) in enumerate(lines):
+        y = sum(x[6][li] for x in res)
+        want = dft(y, -1, n, 'D') / N
+        got = np.zeros(n, dtype='D')
+        seen = np.zeros(n, dtype=bool)
+        for x in res:
+            if x[7][li] is not None:
+                s2, piece = x[7][li]
+                got[s2:s2 + piece.shape[0]] = piece
+                seen[s2:s2 + piece.shape[0]] = True
+        assert seen.all()
+        assert np.abs(got - want).max() <= 2e-10 * np.abs(want).max(), (name, k0, k1, np.abs(got - want).max() / np.abs(want).max())
