@@ -447,6 +447,24 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   // complex128 per step 34.3 (8 / 4) -> 32.4 (12 / 6), 32.2 (14 / 7), 31.8 (13 / 6, 11 / 6); lag 3 or ring 6: 37.9;
   // C2 0.748 -> 0.710 ms (16 / 8: 0.70).  (Before the row tiles lost their barriers 8 / 4 was the optimum: a
   // faster consumer wants the producer further ahead.)
+  // The hand-off protocol leans on gfx94x / gfx950 specifics: raw-buffer cache policy sc0 | sc1 = system scope (written
+  // through / never served from a stale L2 line), stores counted by vmcnt -- so that s_waitcnt(0) means "write-through
+  // acknowledged" --, relaxed agent-scope atomics as the only ordering.  On a target with another memory model (a
+  // separate store counter, other policy bits) the pairs stay off: the stand-alone passes are always correct.
+  {
+    static int arch_ok[kMaxDevices] = {};          // 0 unknown, 1 yes, -1 no
+    const int dev = current_device();
+    if (!arch_ok[dev]) {
+      hipDeviceProp_t prop;
+      arch_ok[dev] = -1;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+        if (!strncmp(prop.gcnArchName, "gfx942", 6) || !strncmp(prop.gcnArchName, "gfx950", 6)) arch_ok[dev] = 1;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    if (arch_ok[dev] < 0) return false;
+  }
   int ring = opts().fuse2_ring, lag = opts().fuse2_lag;
   if (ring <= 0) ring = planes >= 24 ? 12 : 8;
   if (lag <= 0) lag = ring / 2;
@@ -1921,6 +1939,10 @@ int gfft_plan_set_split(gfft_plan pl, int side, int nblocks) {
   if (nblocks > max_blocks || n % nblocks) return fail(GFFT_ERR_UNSUPPORTED, "block count not supported for this length");
   const int64_t nb = n / nblocks;
   const int64_t os = nb * inner, jump = nblocks > 1 ? (outer - 1) * nb * inner : 0;
+  // (what gfft_plan_create_guru would have recorded for the same layout: gfft_plan_set_tiles re-derives the block
+  // jump from these)
+  p.blocks[side] = nblocks;
+  p.bstride[side] = nblocks > 1 ? outer * nb * inner : 0;
   if (side == 0) {
     p.d.in_os = os;
     p.d.in_jump = jump;
@@ -2099,15 +2121,27 @@ int gfft_plan_set_split_slabs(gfft_plan pl, int side, int nblocks, int64_t rows_
   Pass &p = pl->passes[0];
   if (!((p.d.mode == MODE_R2C_H && side == 1) || (p.d.mode == MODE_C2R_H && side == 0)))
     return fail(GFFT_ERR_UNSUPPORTED, "slab-wise split: the half-spectrum side of packed-real rows only");
-  if (p.d.tr_dir || p.d.mid != 1 || p.d.inner != 1) return fail(GFFT_ERR_UNSUPPORTED, "slab-wise split: plain packed-real rows only");
+  // Every failure below leaves the plan as it was; a repeated call starts from the natural row strides again (the
+  // slab form multiplies them), and one block switches the slab form off altogether.
+  const PassDesc saved = p.d;
+  auto bail = [&](int code, const char *msg) { p.d = saved; return fail(code, msg); };
+  if (p.d.ub_n1 > 0) {
+    p.d.inner = 1;
+    p.d.in_os = p.d.in_is;   p.d.in_is = 1;
+    p.d.out_os = p.d.out_is; p.d.out_is = 1;
+    p.d.ub_n1 = 0;
+    p.d.ub_tlg = 0;
+  }
+  if (p.d.tr_dir || p.d.mid != 1 || p.d.inner != 1) return bail(GFFT_ERR_UNSUPPORTED, "slab-wise split: plain packed-real rows only");
   int lg = 0;
   while ((1 << lg) < tile) ++lg;
-  if (tile < 2 || (1 << lg) != tile) return fail(GFFT_ERR_INVALID, "tile must be a power of two >= 2");
-  if (rows_per_slab < 1 || p.d.batch % rows_per_slab) return fail(GFFT_ERR_INVALID, "rows per slab must divide the number of rows");
+  if (tile < 2 || (1 << lg) != tile) return bail(GFFT_ERR_INVALID, "tile must be a power of two >= 2");
+  if (rows_per_slab < 1 || p.d.batch % rows_per_slab) return bail(GFFT_ERR_INVALID, "rows per slab must divide the number of rows");
   // (the kernels address this layout with 32-bit element offsets)
-  if ((double)p.d.batch * ((double)p.d.n + 1.0) >= 2147483648.0) return fail(GFFT_ERR_UNSUPPORTED, "slab-wise split: buffer beyond 2^31 entries");
+  if ((double)p.d.batch * ((double)p.d.n + 1.0) >= 2147483648.0) return bail(GFFT_ERR_UNSUPPORTED, "slab-wise split: buffer beyond 2^31 entries");
   int rc = gfft_plan_set_split(pl, side, nblocks);
-  if (rc || nblocks == 1) return rc;
+  if (rc) { p.d = saved; return rc; }
+  if (nblocks == 1) return GFFT_OK;
   PassDesc &d = p.d;
   // rows of the batch as (slab, row in slab): the kernel's (o, i) indices
   d.inner = rows_per_slab;

@@ -135,25 +135,30 @@ class DistArray(DeviceArray):
     def redistribute(self, axis=None, out=None):
         """Global redistribution so that `axis` (or `out`'s aligned axis) becomes undivided
         (distarray.py:298-363).  Vector/tensor components are moved one transfer each."""
-        if axis == self.alignment:
-            return self
-        if axis is not None and isinstance(out, DistArray):
-            assert axis == out.alignment
         if axis is not None:
+            # nothing to move: already aligned there, or the target axis is not divided either (both undivided: only
+            # the pencil's label changes) -- `self` comes back in both cases, also when `out` was given
+            if axis == self.alignment:
+                return self
+            if isinstance(out, DistArray):
+                assert axis == out.alignment, 'axis %d contradicts the alignment of out (%d)' % (axis, out.alignment)
             if self.commsizes[self.rank + axis] == 1:
                 self.pencil.axis = axis
                 return self
+        target = axis
         if out is not None:
-            assert isinstance(out, DistArray)
-            assert self.global_shape == out.global_shape
-            axis = out.alignment
-            if self.commsizes == out.commsizes:
+            assert isinstance(out, DistArray), 'out must be a DistArray'
+            target = out.alignment
+        if out is not None:
+            assert self.global_shape == out.global_shape, 'global shapes differ: %r and %r' % (self.global_shape, out.global_shape)
+            if self.commsizes == out.commsizes:          # same distribution: a plain copy
                 out[...] = self
                 return out
-            for i in range(len(self._p0.shape)):
-                if i not in (self.alignment, out.alignment):
-                    assert self.pencil.subcomm[i] == out.pencil.subcomm[i]
-                    assert self.pencil.subshape[i] == out.pencil.subshape[i]
+            # the transfer moves data between the two aligned axes only: every other axis must be cut alike
+            for i in (j for j in range(len(self._p0.shape)) if j not in (self.alignment, target)):
+                assert self.pencil.subcomm[i] == out.pencil.subcomm[i], 'axis %d is distributed over different groups' % i
+                assert self.pencil.subshape[i] == out.pencil.subshape[i], 'axis %d is cut differently' % i
+        axis = target
         p1, transfer = self._cached_transfer(axis)
         if out is None:
             out = DistArray(self.global_shape, subcomm=p1.subcomm, dtype=self.dtype,
@@ -225,14 +230,12 @@ class DistArray(DeviceArray):
 def newDistArray(pfft, forward_output=True, val=0, rank=0, view=False):
     """A new DistArray shaped and typed as the input (``forward_output=False``) or output of
     ``pfft.forward`` (distarray.py:442-485)."""
-    global_shape = pfft.global_shape(forward_output)
-    p0 = pfft.pencil[forward_output]
-    if forward_output is True:
-        dtype = pfft.forward.output_array.dtype
-    else:
-        dtype = pfft.forward.input_array.dtype
-    global_shape = (len(global_shape),) * rank + tuple(global_shape)
-    z = DistArray(global_shape, subcomm=p0.subcomm, val=val, dtype=dtype, alignment=p0.axis, rank=rank)
+    side = pfft.forward.output_array if forward_output else pfft.forward.input_array
+    pencil = pfft.pencil[1 if forward_output else 0]
+    field = tuple(pfft.global_shape(bool(forward_output)))
+    # a rank-r field carries r leading component axes of length ndim (vectors, tensors), never distributed
+    z = DistArray((len(field),) * rank + field, subcomm=pencil.subcomm, val=val, dtype=side.dtype,
+                  alignment=pencil.axis, rank=rank)
     return z.v if view else z
 
 

@@ -137,7 +137,13 @@ class FileBase(object):
         """Run body() on every rank of `comm`, one rank at a time in rank order, each inside its own
         open / close of the file (the reference's collective open under MPI-IO)."""
         if comm is None or comm.Get_size() == 1:
-            self._create_if_pending(True)
+            if self._pending_create is not None:
+                # a world of several processes, no communicator given to the constructor, and an array that is not
+                # distributed: every process would create (truncate) the file on its own -- the race _init_file
+                # exists to prevent.  Nobody can know here which process should.
+                raise RuntimeError('%s: the file still has to be created, the world has several processes and the array '
+                                   'written is not distributed; pass comm= (e.g. comm.COMM_SELF for one file per process) to '
+                                   'the constructor so that exactly one process creates it' % self.filename)
             self.open(mode)
             try:
                 return body()

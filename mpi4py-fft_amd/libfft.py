@@ -52,25 +52,33 @@ class _ShapeOnly:
         self.strides = tuple(st)
 
 
+def _as_list(x):
+    return [int(v) for v in x] if np.ndim(x) else [int(x)]
+
+
+def _normalise_axes(shape, axes):
+    """(shape, axes) as lists: every extent positive, axes wrapped into 0 .. ndim - 1, each named at most once, at
+    least one and at most ndim of them; axes=None means all, in order.  The argument contract of the reference's
+    serial transforms (mpi4py_fft/libfft.py:238-255), violations raise AssertionError as they do there."""
+    shape = _as_list(shape)
+    ndim = len(shape)
+    assert ndim > 0, 'shape must name at least one axis'
+    assert all(n > 0 for n in shape), 'every extent must be positive, got %r' % (shape,)
+    if axes is None:
+        return shape, list(range(ndim))
+    axes = [a + ndim if a < 0 else a for a in _as_list(axes)]
+    assert 0 < len(axes) <= ndim, '%d axes named for a %d-dimensional array' % (len(axes), ndim)
+    assert all(0 <= a < ndim for a in axes), 'axis out of range for a %d-dimensional array: %r' % (ndim, axes)
+    assert len(set(axes)) == len(axes), 'an axis is named twice: %r' % (axes,)
+    return shape, axes
+
+
 class FFTBase:
     """Argument normalisation shared by serial transforms (libfft.py:221-261)."""
     def __init__(self, shape, axes=None, dtype=float, padding=False):
-        shape = list(shape) if np.ndim(shape) else [shape]
-        assert len(shape) > 0
-        assert min(shape) > 0
-        if axes is not None:
-            axes = list(axes) if np.ndim(axes) else [axes]
-            for i, axis in enumerate(axes):
-                if axis < 0:
-                    axes[i] = axis + len(shape)
-        else:
-            axes = list(range(len(shape)))
-        assert min(axes) >= 0
-        assert max(axes) < len(shape)
-        assert 0 < len(axes) <= len(shape)
-        assert sorted(axes) == sorted(set(axes))
+        shape, axes = _normalise_axes(shape, axes)
         dtype = np.dtype(dtype)
-        assert dtype.char in 'fdgFDG'
+        assert dtype.char in 'fdgFDG', 'dtype must be a real or complex floating type, got %s' % dtype
         if dtype.char in 'gG':
             raise NotImplementedError('long double transforms have no MI355X type (fp32 and fp64 only)')
         self.shape = shape

@@ -92,9 +92,18 @@ def test_1024cubed_roundtrip_c128():
         ur[i:i + 64].copy_(torch.randn(ur[i:i + 64].shape, generator=g, device='cuda', dtype=torch.float64))
     u0 = u.tensor.clone()
     uh = fft.forward()
+    assert 'fused pair' in fft._fused_plans[0]._eng.plan_describe(fft._fused_plans[0]._plan)      # the headline plan itself
     e_phys = float((torch.view_as_real(u0) ** 2).sum().item()) / u0.numel()
     e_spec = float((torch.view_as_real(uh.tensor) ** 2).sum().item())
     assert abs(e_phys - e_spec) <= 1e-10 * e_phys
+    # six lines of the full-size forward against the DFT by definition: the (k0, k1) sums in float64 on the device,
+    # the transform along axis 2 in long double (oracle/dft_oracle.c)
+    from tests.test_gpu_c5 import _c_dft
+    dft = _c_dft()
+    for k0, k1 in [(3, 5), (n - 1, n - 1), (n // 2, 1), (n // 2 + 7, n // 4 + 3), (0, n // 2), (17, 0)]:
+        want = dft(_line_partial(u0, (0, 0, 0), k0, k1, n, n), -1, n, 'D') / float(n) ** 3
+        got = uh.tensor[k0, k1].cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-10 * np.abs(want).max(), (k0, k1, np.abs(got - want).max() / np.abs(want).max())
     back = fft.backward()
     num = float(((torch.view_as_real(back.tensor) - torch.view_as_real(u0)) ** 2).sum().sqrt().item())
     den = float((torch.view_as_real(u0) ** 2).sum().sqrt().item())

@@ -178,3 +178,60 @@ def test_packed_real_rows_write_and_read_slab_wise_uneven_blocks(dt, n, p, tile)
     assert np.abs(_host(c) - x).max() <= (1e-12 if dt == 'd' else 2e-5) * np.abs(x).max()
     for h in (h0, h1, h2):
         eng.plan_destroy(h)
+
+
+def test_slab_wise_split_can_be_repeated_and_switched_off():
+    """gfft_plan_set_split_slabs starts from the plan's natural row strides on every call (the slab form multiplies
+    them) and one block switches the layout off: the plan is then the natural one again, as the header promises."""
+    import torch
+    from mpi4py_fft_amd import _lib
+    eng = _lib.engine()
+    n, n0, n1, p, tile = 256, 3, 4, 3, 16
+    nh, rows = n // 2 + 1, 12
+    x = np.random.default_rng(18).standard_normal((n0, n1, n))
+    a = _dev(x)
+
+    def run(h):
+        b = torch.zeros(rows * nh, dtype=torch.complex128, device='cuda')
+        eng.execute_ptr(h, a.data_ptr(), b.data_ptr(), 1.0)
+        torch.cuda.synchronize()
+        return _host(b).copy()
+    once = eng.plan_create((rows, n), (rows, nh), (1,), _lib.R2C, 8)
+    assert eng.plan_set_split_slabs(once, 1, p, n1, tile)
+    twice = eng.plan_create((rows, n), (rows, nh), (1,), _lib.R2C, 8)
+    assert eng.plan_set_split_slabs(twice, 1, p, n1, tile) and eng.plan_set_split_slabs(twice, 1, p, n1, tile)
+    assert np.array_equal(run(once), run(twice))
+    with pytest.raises(RuntimeError):
+        eng.plan_set_split_slabs(twice, 1, p, 5, tile)              # 5 does not divide the 12 rows: refused ...
+    assert np.array_equal(run(once), run(twice))                   # ... and the plan is as it was
+    assert eng.plan_set_split_slabs(twice, 1, 1, n1, tile)          # one block: the natural layout again
+    want = np.fft.rfft(x, axis=2).reshape(rows, nh)
+    got = run(twice).reshape(rows, nh)
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    for h in (once, twice):
+        eng.plan_destroy(h)
+
+
+def test_tile_major_rows_on_top_of_a_split_set_after_planning():
+    """gfft_plan_set_split followed by gfft_plan_set_tiles on a row plan: the block jump is re-derived from the blocks
+    the split recorded (it used to be computed from the guru plan's fields only, i.e. reset to 0)."""
+    import torch
+    from mpi4py_fft_amd import _lib
+    eng = _lib.engine()
+    n, rows, nb, tile = 1024, 6, 2, 16
+    x = (np.random.default_rng(19).standard_normal((rows, n)) + 1j * np.random.default_rng(20).standard_normal((rows, n)))
+    want = np.fft.fft(x, axis=1)
+    a = _dev(x)
+    h = eng.plan_create((rows, n), (rows, n), (1,), _lib.C2C_FORWARD, 8)
+    assert eng.plan_set_split(h, 1, nb)
+    per = n // nb
+    # blocks of `per` entries per row, block b of all rows first; inside a block the line is tile-major with the
+    # tiles of one row back to back (tile stride = tile): the same bytes as the plain split layout
+    assert eng.plan_set_tiles(h, 1, tile, tile)
+    b = torch.zeros(rows * n, dtype=torch.complex128, device='cuda')
+    eng.execute_ptr(h, a.data_ptr(), b.data_ptr(), 1.0)
+    torch.cuda.synchronize()
+    got = _host(b).reshape(nb, rows, per)
+    for blk in range(nb):
+        assert np.abs(got[blk] - want[:, blk * per:(blk + 1) * per]).max() <= 1e-12 * np.abs(want).max(), blk
+    eng.plan_destroy(h)

@@ -403,3 +403,58 @@ def test_padded_transform_as_one_plan(dt, shape, padding, monkeypatch):
     assert np.abs(np.asarray(one.forward.output_array) - uh_s).max() <= 10 * tol * np.abs(uh_s).max()
     one.destroy()
     staged.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dt', 'dD')
+def test_padded_lengths_without_fused_adapters_take_the_staged_chain(dt):
+    """27 -> 40 = 5 * 2^3: the shipped library has no fused truncation / zero-padding adapters for 5^c 2^k lengths
+    (fused_pad_ok, kFusedPadMix5), so gfft_plan_create_padded answers UNSUPPORTED and PFFT keeps the staged chain
+    with the separate gfft_truncate / gfft_pad kernels (libfft.py:263-311).  The path taken is asserted, and the
+    result checked against the oracle."""
+    from mpi4py_fft_amd import PFFT, comm, _lib
+    from oracle import pfft_oracle as O
+    shape, padding = (27, 32, 64), [1.5, 1.5, 1.5]
+    _lib.set_option('fused3_min_mib', 0)
+    try:
+        fft = PFFT(comm.COMM_SELF, shape, dtype=dt, padding=list(padding))
+    finally:
+        _lib.set_option('fused3_min_mib', 32)
+    assert fft._fused_plans is None, 'a 40-long padded axis cannot be part of the one-plan form in this build'
+    by_axis = {x.axes[0]: x for x in fft.xfftn}
+    assert by_axis[0]._padded and not by_axis[0]._fused_trunc           # 27 -> 40: stand-alone truncation / padding kernels
+    assert by_axis[1]._fused_trunc and by_axis[2]._fused_trunc           # 32 -> 48, 64 -> 96: fused adapters
+    ref = O.OPFFT(1, shape, dtype=dt, padding=list(padding))
+    G = O.rng_array(ref.input_shape, dt, 12)
+    want = ref.forward(ref.scatter(G))[0]
+    uh = np.asarray(fft.forward(np.asarray(G))).copy()
+    assert uh.shape == want.shape and np.abs(uh - want).max() <= 2e-10 * np.abs(want).max()
+    back = np.asarray(fft.backward(uh))
+    again = np.asarray(fft.forward(back))
+    assert np.abs(again - uh).max() <= 2e-9 * np.abs(uh).max()
+    fft.destroy()
+
+
+@pytest.mark.gpu
+def test_padded_distributed_transform_with_a_mix5_length_keeps_the_staged_wire():
+    """The overlap pipeline needs every padded stage to carry fused adapters (pipeline.Pipeline.build); with a
+    27 -> 40 axis it declines and the transform runs staged -- still against the oracle, on 4 thread-ranks."""
+    from mpi4py_fft_amd import PFFT, newDistArray
+    from oracle import pfft_oracle as O
+    from tests import cases
+    shape, padding, P = (27, 32, 64), [1.5, 1.5, 1.5], 4
+    ref = O.OPFFT(P, shape, dtype='D', padding=list(padding))
+    G = O.rng_array(ref.input_shape, 'D', 13)
+    want = ref.forward(ref.scatter(G))
+
+    def body(comm):
+        fft = PFFT(comm, shape, dtype='D', padding=list(padding), wire='overlap', exchange='direct')
+        piped = fft.pipeline is not None
+        u = newDistArray(fft, False)
+        u[...] = G[fft.local_slice(False)]
+        uh = np.asarray(fft.forward(u)).copy()
+        fft.destroy()
+        return piped, uh
+    for r, (piped, uh) in enumerate(cases.run_ranks(P, body)):
+        assert not piped, 'a stage without fused adapters cannot be pipelined'
+        assert uh.shape == want[r].shape and np.abs(uh - want[r]).max() <= 2e-10 * np.abs(want[r]).max()
