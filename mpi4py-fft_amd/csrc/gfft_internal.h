@@ -185,6 +185,11 @@ int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &
 // dev_descs: {dA, dB} in device memory (uploaded when the plan was made; the scale factors travel as arguments)
 hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs,
                              const FusedDesc &f, const void *in, void *ring, void *out, hipStream_t s);
+// ... complex64 (fft_fused_f32.hip; off unless option fuse2_f32 is set: measured, see there)
+bool fused2_supported_f32(int kind, int n_a, int n_b);
+int fused2_tiles_f32(int kind, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b);
+hipError_t launch_fused2_f32(int kind, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs, const FusedDesc &f,
+                             const void *in, void *ring, void *out, hipStream_t s);
 // ... the two real kinds (n_a / n_b: the passes' lengths -- COMPLEX length of the packed-real rows)
 bool fused2_real_supported_f64(int kind, int n_a, int n_b);
 int fused2_real_tiles_f64(int kind, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b);

@@ -78,6 +78,7 @@ struct Options {
   int fuse2_defer = 0;       // settle an A tile's counter behind the next tile's loads (A/B)
   int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
   int fuse2_kinds = 126;     // which pairs (bit = FusedKind): measured per kind, see make_fused2
+  int fuse2_f32 = 1;         // complex64 pairs (fft_fused_f32.hip)
   int fuse2_wait_ms = 2000;  // wall-clock limit of one wait inside a fused launch before the launch is voided (0: at once -- test hook)
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
@@ -465,17 +466,29 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
     }
     if (arch_ok[dev] < 0) return false;
   }
+  // How far the producer runs ahead is a matter of BYTES, not planes: ~96 MiB of lead, twice that of ring (the
+  // Infinity Cache holds 256 MiB) -- 6 / 12 planes of 16 MiB (complex128, n = 1024: the optimum of the round-3 sweeps),
+  // 12 / 24 planes of 8 MiB (complex64: with 6 / 12 the pair LOSES, 21.1 -> 21.9 ms per 1024^3 step, with 12 / 24 it
+  // gains, -> 18.9 ms; profiles/r04_ab_fuse2_f32.txt) -- and fewer where the launch has too few planes for that.
   int ring = opts().fuse2_ring, lag = opts().fuse2_lag;
-  if (ring <= 0) ring = planes >= 24 ? 12 : 8;
+  if (ring <= 0) {
+    int64_t ahead = (((int64_t)96 << 20) + slot_bytes - 1) / (slot_bytes > 0 ? slot_bytes : 1);
+    ahead = ahead < 4 ? 4 : (ahead > 16 ? 16 : ahead);
+    ring = 2 * (int)ahead;
+    while (ring > 8 && planes < 2 * ring) ring -= 2;
+  }
   if (lag <= 0) lag = ring / 2;
   if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1) || planes < 2 * ring || lag < 1 || ring <= lag) return false;
   const int variant = (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1;
   // (fp64 only: the fp32 pairs measured slower than their stand-alone passes, fft_fused_f64.hip)
   const bool real_kind = kind == FUSED_R2C_PLANES || kind == FUSED_COLS_C2R;
-  if (pl->precision != GFFT_F64) return false;
-  if (real_kind ? !fused2_real_supported_f64(kind, dA.n, dB.n) : !fused2_supported_f64(kind, variant, dA.n, dB.n)) return false;
+  const bool f32 = pl->precision == GFFT_F32;
+  if (f32 && (!opts().fuse2_f32 || real_kind)) return false;
+  if (f32 ? !fused2_supported_f32(kind, dA.n, dB.n)
+          : (real_kind ? !fused2_real_supported_f64(kind, dA.n, dB.n) : !fused2_supported_f64(kind, variant, dA.n, dB.n))) return false;
   int ta = 0, tb = 0;
-  if ((real_kind ? fused2_real_tiles_f64(kind, dA, dB, &ta, &tb) : fused2_tiles_f64(kind, variant, dA, dB, &ta, &tb)) || ta < 1 || tb < 1) return false;
+  if ((f32 ? fused2_tiles_f32(kind, dA, dB, &ta, &tb)
+           : (real_kind ? fused2_real_tiles_f64(kind, dA, dB, &ta, &tb) : fused2_tiles_f64(kind, variant, dA, dB, &ta, &tb))) || ta < 1 || tb < 1) return false;
   // (hand-off accesses carry 32-bit byte offsets inside a slot; tickets are 32-bit)
   if (slot_bytes >= ((int64_t)1 << 31) || (double)planes * (ta + tb) >= 1.0e9) return false;     // (tickets < 2^30: a launch that gives up pushes the counter 2^31 on)
   Pass f = a;
@@ -1219,7 +1232,8 @@ int plan_fused3(gfft_plan_s *pl) {
   // loses what the fusion gains (1024^3 c128, tools/fused2_probe.py: 20.0 ms against 18.4 ms).
   const bool pair_cols_rows = !real && !tr && !flat_out && Pu == nc && opts().fuse2 &&
                               ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && n1 >= 2 * (opts().fuse2_ring > 0 ? opts().fuse2_ring : 8) &&
-                              prec == GFFT_F64 && fused2_supported_f64(FUSED_COLS_ROWS, (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1, (int)n0, (int)n2);
+                              (prec == GFFT_F64 ? fused2_supported_f64(FUSED_COLS_ROWS, (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1, (int)n0, (int)n2)
+                                                : (opts().fuse2_f32 && fused2_supported_f32(FUSED_COLS_ROWS, (int)n0, (int)n2)));
   // Real transforms: forward [r2c rows -> axis 1] on the contiguous planes i0 of the flat_out schedule (FUSED_R2C_PLANES),
   // backward [axis 0 -> c2r rows] on the planes i1 (FUSED_COLS_C2R), as the complex schedule runs its last two passes
   const int ring_min = 2 * (opts().fuse2_ring > 0 ? opts().fuse2_ring : 8);
@@ -1448,6 +1462,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "fuse2_group")) opts().fuse2_group = value;
   else if (!strcmp(key, "fuse2_defer")) opts().fuse2_defer = value;
   else if (!strcmp(key, "fuse2_wait_ms")) opts().fuse2_wait_ms = value;
+  else if (!strcmp(key, "fuse2_f32")) opts().fuse2_f32 = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
@@ -1738,7 +1753,9 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
       }
       static const int debug = getenv("GFFT_FUSE2_DEBUG") ? atoi(getenv("GFFT_FUSE2_DEBUG")) : 0;
       if (debug) { f.wait_ticks = 100000u; f.host_flag = nullptr; f.debug = (unsigned)debug; }      // (1 ms; counters printed below)
-      if (p.fused_kind == FUSED_R2C_PLANES || p.fused_kind == FUSED_COLS_C2R)
+      if (pl->precision == GFFT_F32)
+        HIP_TRY(launch_fused2_f32(p.fused_kind, d, d2, p.dev_descs, f, bufs[p.src], ring, bufs[p.dst], s));
+      else if (p.fused_kind == FUSED_R2C_PLANES || p.fused_kind == FUSED_COLS_C2R)
         HIP_TRY(launch_fused2_real_f64(p.fused_kind, d, d2, p.dev_descs, f, bufs[p.src], ring, bufs[p.dst], s));
       else
         HIP_TRY(launch_fused2_f64(p.fused_kind, p.fused_variant, d, d2, p.dev_descs, f, bufs[p.src], ring, bufs[p.dst], s));

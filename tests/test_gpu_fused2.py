@@ -100,9 +100,8 @@ def test_fused_four_step_matches_the_two_launch_form(shape, dt):
 
 def test_shapes_without_a_paying_pair_keep_the_unfused_plans():
     from mpi4py_fft_amd import _lib
-    # fewer planes than two rings: nothing to pipeline; fp32 and n = 512: measured slower fused (fft_fused_f64.hip)
-    for shape, axes, dt in (((4, 1 << 20), (1,), 'D'), ((32, 1 << 20), (1,), 'F'), ((512, 32, 512), (0, 1, 2), 'D'),
-                            ((1024, 32, 1024), (0, 1, 2), 'F')):
+    # fewer planes than two rings: nothing to pipeline; fp32 four-step and n = 512: measured slower fused (fft_fused_f64.hip)
+    for shape, axes, dt in (((4, 1 << 20), (1,), 'D'), ((32, 1 << 20), (1,), 'F'), ((512, 32, 512), (0, 1, 2), 'D')):
         a, f, b = _plans(shape, axes, 1, dt=dt)
         assert 'fused pair' not in _lib.engine().plan_describe(f._plan), (shape, dt)
         f.destroy()
@@ -304,3 +303,33 @@ def test_fused_pairs_of_real_transforms(shape):
         b.destroy()
     assert np.abs(res[0][0] - res[1][0]).max() <= 1e-13 * np.abs(ref).max()
     assert np.abs(res[0][1] - res[1][1]).max() <= 1e-13 * np.abs(x).max()
+
+
+def test_fused_pair_of_the_complex64_schedule():
+    """[axis 0 -> rows] of the complex64 3-D schedule (csrc/fft_fused_f32.hip), on a ring sized in bytes: against numpy
+    in double precision and against the unfused plans, reproducible."""
+    from mpi4py_fft_amd import _lib
+    shape = (1024, 48, 1024)
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype('F')
+    ref = np.fft.fftn(x.astype('D'))
+    res = {}
+    for fuse in (0, 1):
+        a, f, b = _plans(shape, (0, 1, 2), fuse, 0, 0, 126, dt='F')
+        desc = _lib.engine().plan_describe(f._plan)
+        assert ('fused pair (strided -> rows)' in desc) == bool(fuse), desc
+        if fuse:
+            assert 'ring of 24 slots' in desc, desc          # 8.25 MiB planes: twice the slots of the complex128 pair
+        a[...] = x
+        for rep in range(3):
+            got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
+            assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()
+            if rep == 0:
+                first = got.copy()
+            assert np.array_equal(got, first)
+        back = np.asarray(b.execute_scaled(f.output_array, b.output_array, 1.0 / x.size))
+        assert np.abs(back - x).max() <= 1e-4 * np.abs(x).max()
+        res[fuse] = first
+        f.destroy()
+        b.destroy()
+    assert np.abs(res[0] - res[1]).max() <= 1e-5 * np.abs(ref).max()
