@@ -68,19 +68,37 @@ struct Fused1024R32 {
   typedef PassCfg<double, 1024, 32, 16, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 32, 32> RowsFromRingT;
 };
 
+// n = 512: 32 values per thread, radices 32 x 16, 256-thread workgroups on 16 lines -- 128 KiB tiles, TWO workgroups per CU
+// (round 3 measured the n = 512 pairs on 1024-thread workgroups of 8 values per thread and found them 40 % slower than
+// their stand-alone passes)
+struct Fused512R32 {
+  typedef PassCfg<double, 512, 32, 16, false, true, 1 | 2048 | 8192, MODE_C2C, false, 32, 16> RowsToRing;
+  typedef PassCfg<double, 512, 32, 16, false, true, 2 | 4096 | 8192, MODE_C2C, false, 32, 16> RowsFromRing;
+  typedef PassCfg<double, 512, 32, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 32, 16> ColsToRing;
+  typedef PassCfg<double, 512, 32, 16, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 32, 16> ColsFromRing;
+  typedef PassCfg<double, 512, 32, 16, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 32, 16> FourStepFirst;
+  typedef PassCfg<double, 512, 32, 16, true, true, 1 | 2048 | 8192, MODE_C2C, true, 32, 16> FourStepFirstNat;
+  typedef PassCfg<double, 512, 32, 16, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 32, 16> RowsFromRingT;
+};
+
 // variant: 1 = the default, 32 values per thread / one exchange (Fused1024R32); 3 = 16 values per thread / two exchanges
 // on 1024 threads (FusedCfgs: the round-3 kernels, kept for A/B: 1024^3 per step 33.4 -> 32.6 ms, C2 0.707 -> 0.677 ms
 // with variant 1, tools/ab_combo_probe.py, profiles/r04_ab_fuse2_variants.txt); 2 / 4 = (make VARIANTS=1) 8 lines per tile,
 // two workgroups per CU, with 16 / 32 values per thread: 40.6 / 39.7 ms per step, a quarter SLOWER -- what bounds the fused
 // launch is the traffic its CUs can move across the L2 boundary, and 128-byte pieces move less of it
+extern int g_fuse2_n512;
 bool fused2_supported_f64(int kind, int variant, int n_a, int n_b) {
   (void)kind;
   if (n_a != n_b) return false;
 #ifdef GFFT_VARIANTS
   if (variant == 2 || variant == 4) return n_a == 1024;
 #endif
+  // (n = 512: measured for the 3-D schedule's pair only -- 512^3 per step 4.82 -> 4.27 ms with 24 planes of 4 MiB ahead,
+  // 5.34 ms with 16: profiles/r04_ab_fuse2_n512.txt)
+  if (variant == 1 && n_a == 512) return g_fuse2_n512 != 0 && kind == FUSED_COLS_ROWS;
   return (variant == 1 || variant == 3) && n_a == 1024;
 }
+int g_fuse2_n512 = 1;
 
 int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b) {
 #ifdef GFFT_VARIANTS
@@ -88,6 +106,7 @@ int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &
   if (variant == 4) return fused2_tiles_kind<Fused1024x8R32>(kind, dA, dB, tiles_a, tiles_b);
 #endif
   if (variant == 3) return fused2_tiles_kind<FusedCfgs<double, 1024>>(kind, dA, dB, tiles_a, tiles_b);
+  if (dA.n == 512) return fused2_tiles_kind<Fused512R32>(kind, dA, dB, tiles_a, tiles_b);
   return fused2_tiles_kind<Fused1024R32>(kind, dA, dB, tiles_a, tiles_b);
 }
 
@@ -98,6 +117,7 @@ hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const Pa
   if (variant == 4) return launch_fused2_kind<Fused1024x8R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);
 #endif
   if (variant == 3) return launch_fused2_kind<FusedCfgs<double, 1024>>(kind, dA, dB, dev_descs, f, in, ring, out, s);
+  if (dA.n == 512) return launch_fused2_kind<Fused512R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);
   return launch_fused2_kind<Fused1024R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);
 }
 

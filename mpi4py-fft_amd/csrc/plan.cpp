@@ -441,6 +441,32 @@ void need(gfft_plan_s *pl, int buf, size_t bytes) {
   if (bytes > pl->region_bytes[buf]) pl->region_bytes[buf] = bytes;
 }
 
+// Slots of the hand-off ring and planes the producer runs ahead (options fuse2_ring / fuse2_lag, else automatic); false:
+// this launch has too few planes for a ring on which the pair pays.
+// How far the producer runs ahead is a matter of BYTES, not planes: ~96 MiB of lead, twice that of ring (the Infinity
+// Cache holds 256 MiB) -- 6 / 12 planes of 16 MiB (complex128, n = 1024: the optimum of the round-3 sweeps), 12 / 24
+// planes of 8 MiB (complex64: with 6 / 12 the pair LOSES, 21.1 -> 21.9 ms per 1024^3 step, with 12 / 24 it gains, ->
+// 18.9 ms; profiles/r04_ab_fuse2_f32.txt), 24 / 48 planes of 4 MiB (complex128 n = 512: 16 / 32 +11 %, 24 / 48 -11 %).
+bool fused2_ring(int precision, int n_a, int n_b, int64_t slot_bytes, int planes, int *ring_out, int *lag_out) {
+  int ring = opts().fuse2_ring, lag = opts().fuse2_lag;
+  if (ring <= 0) {
+    int64_t ahead = (((int64_t)96 << 20) + slot_bytes - 1) / (slot_bytes > 0 ? slot_bytes : 1);
+    ahead = ahead < 4 ? 4 : (ahead > 32 ? 32 : ahead);
+    ring = 2 * (int)ahead;
+    // too few planes for that: the complex128 n = 1024 pairs still pay on a shorter ring (8 / 4: 34.3 against 39.9 ms
+    // unfused, round 3); the others LOSE with less lead than this and stay unfused
+    if (planes < 2 * ring) {
+      if (!(precision == GFFT_F64 && (n_a == 1024 || n_b == 1024))) return false;      // (the real fp64 pairs: 12 / 6 ... 24 / 12 level)
+      while (ring > 8 && planes < 2 * ring) ring -= 2;
+    }
+  }
+  if (lag <= 0) lag = ring / 2;
+  if (planes < 2 * ring || lag < 1 || ring <= lag) return false;
+  *ring_out = ring;
+  *lag_out = lag;
+  return true;
+}
+
 bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const PassDesc &dA, const PassDesc &dB, int planes,
                  int64_t a_in_plane, int64_t b_out_plane, int64_t slot_bytes, Pass *out) {
   // auto: 12 slots with the producer 6 planes ahead where there are planes enough, else 8 / 4.  Swept on one box, plans
@@ -466,19 +492,9 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
     }
     if (arch_ok[dev] < 0) return false;
   }
-  // How far the producer runs ahead is a matter of BYTES, not planes: ~96 MiB of lead, twice that of ring (the
-  // Infinity Cache holds 256 MiB) -- 6 / 12 planes of 16 MiB (complex128, n = 1024: the optimum of the round-3 sweeps),
-  // 12 / 24 planes of 8 MiB (complex64: with 6 / 12 the pair LOSES, 21.1 -> 21.9 ms per 1024^3 step, with 12 / 24 it
-  // gains, -> 18.9 ms; profiles/r04_ab_fuse2_f32.txt) -- and fewer where the launch has too few planes for that.
-  int ring = opts().fuse2_ring, lag = opts().fuse2_lag;
-  if (ring <= 0) {
-    int64_t ahead = (((int64_t)96 << 20) + slot_bytes - 1) / (slot_bytes > 0 ? slot_bytes : 1);
-    ahead = ahead < 4 ? 4 : (ahead > 16 ? 16 : ahead);
-    ring = 2 * (int)ahead;
-    while (ring > 8 && planes < 2 * ring) ring -= 2;
-  }
-  if (lag <= 0) lag = ring / 2;
-  if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1) || planes < 2 * ring || lag < 1 || ring <= lag) return false;
+  int ring = 0, lag = 0;
+  if (!fused2_ring(pl->precision, dA.n, dB.n, slot_bytes, planes, &ring, &lag)) return false;
+  if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1)) return false;
   const int variant = (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1;
   // (fp64 only: the fp32 pairs measured slower than their stand-alone passes, fft_fused_f64.hip)
   const bool real_kind = kind == FUSED_R2C_PLANES || kind == FUSED_COLS_C2R;
@@ -1230,16 +1246,18 @@ int plan_fused3(gfft_plan_s *pl) {
   // then [axis 0 -> rows] plane by plane: the fused pair then WRITES the caller's rows scattered (plane i1 =
   // rows 16 MiB apart), which costs nothing, where the mirror pair [rows -> axis 0] READS them scattered and
   // loses what the fusion gains (1024^3 c128, tools/fused2_probe.py: 20.0 ms against 18.4 ms).
+  int ring_probe = 0, lag_probe = 0;
   const bool pair_cols_rows = !real && !tr && !flat_out && Pu == nc && opts().fuse2 &&
-                              ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && n1 >= 2 * (opts().fuse2_ring > 0 ? opts().fuse2_ring : 8) &&
+                              ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && fused2_ring(prec, (int)n0, (int)n2, n0 * P * esz, (int)n1, &ring_probe, &lag_probe) &&
                               (prec == GFFT_F64 ? fused2_supported_f64(FUSED_COLS_ROWS, (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1, (int)n0, (int)n2)
                                                 : (opts().fuse2_f32 && fused2_supported_f32(FUSED_COLS_ROWS, (int)n0, (int)n2)));
   // Real transforms: forward [r2c rows -> axis 1] on the contiguous planes i0 of the flat_out schedule (FUSED_R2C_PLANES),
   // backward [axis 0 -> c2r rows] on the planes i1 (FUSED_COLS_C2R), as the complex schedule runs its last two passes
-  const int ring_min = 2 * (opts().fuse2_ring > 0 ? opts().fuse2_ring : 8);
   const bool pair_real = real && !tr && opts().fuse2 && prec == GFFT_F64 && n2 % 2 == 0 && opts().real_half &&
-                         (inverse ? (((opts().fuse2_kinds >> FUSED_COLS_C2R) & 1) && n1 >= ring_min && fused2_real_supported_f64(FUSED_COLS_C2R, (int)n0, (int)(n2 / 2)))
-                                  : (((opts().fuse2_kinds >> FUSED_R2C_PLANES) & 1) && flat_out && n0 >= ring_min && fused2_real_supported_f64(FUSED_R2C_PLANES, (int)(n2 / 2), (int)n1)));
+                         (inverse ? (((opts().fuse2_kinds >> FUSED_COLS_C2R) & 1) && fused2_real_supported_f64(FUSED_COLS_C2R, (int)n0, (int)(n2 / 2)) &&
+                                     fused2_ring(prec, (int)n0, (int)(n2 / 2), n0 * P * esz, (int)n1, &ring_probe, &lag_probe))
+                                  : (((opts().fuse2_kinds >> FUSED_R2C_PLANES) & 1) && flat_out && fused2_real_supported_f64(FUSED_R2C_PLANES, (int)(n2 / 2), (int)n1) &&
+                                     fused2_ring(prec, (int)(n2 / 2), (int)n1, n1 * P * esz, (int)n0, &ring_probe, &lag_probe)));
   if (pair_real && inverse && opts().fuse2_wlayout) { w_i0 = n1 * P; w_i1 = P; }     // (as under the complex pair, below)
   const bool cols_first = !inverse && pair_cols_rows;
   // ... and the workspace then is W[i0][k1][c]: the stand-alone axis-1 pass stores on NEAR strides (stores are
@@ -1463,6 +1481,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "fuse2_defer")) opts().fuse2_defer = value;
   else if (!strcmp(key, "fuse2_wait_ms")) opts().fuse2_wait_ms = value;
   else if (!strcmp(key, "fuse2_f32")) opts().fuse2_f32 = value;
+  else if (!strcmp(key, "fuse2_n512")) gfft::g_fuse2_n512 = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;

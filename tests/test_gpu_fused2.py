@@ -102,7 +102,7 @@ def test_shapes_without_a_paying_pair_keep_the_unfused_plans():
     from mpi4py_fft_amd import _lib
     # fewer planes than two rings: nothing to pipeline; fp32 four-step and n = 512: measured slower fused (fft_fused_f64.hip)
     for shape, axes, dt in (((4, 1 << 20), (1,), 'D'), ((32, 1 << 20), (1,), 'F'), ((512, 32, 512), (0, 1, 2), 'D')):
-        a, f, b = _plans(shape, axes, 1, dt=dt)
+        a, f, b = _plans(shape, axes, 1, 0, 0, 126, dt=dt)          # (ring / lag automatic)
         assert 'fused pair' not in _lib.engine().plan_describe(f._plan), (shape, dt)
         f.destroy()
         b.destroy()
@@ -309,7 +309,7 @@ def test_fused_pair_of_the_complex64_schedule():
     """[axis 0 -> rows] of the complex64 3-D schedule (csrc/fft_fused_f32.hip), on a ring sized in bytes: against numpy
     in double precision and against the unfused plans, reproducible."""
     from mpi4py_fft_amd import _lib
-    shape = (1024, 48, 1024)
+    shape = (1024, 48, 1024)          # 48 planes: just enough for the ring of 24
     rng = np.random.default_rng(31)
     x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype('F')
     ref = np.fft.fftn(x.astype('D'))
@@ -333,3 +333,29 @@ def test_fused_pair_of_the_complex64_schedule():
         f.destroy()
         b.destroy()
     assert np.abs(res[0] - res[1]).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_fused_pair_at_n_512_and_where_it_stays_off():
+    """complex128, n0 = n2 = 512: 32 values per thread on 256-thread workgroups, two per CU, planes of 4 MiB on a ring of
+    48 -- which needs 96 planes; with fewer the pair would lose (measured) and the plan stays unfused."""
+    from mpi4py_fft_amd import _lib
+    rng = np.random.default_rng(33)
+    for shape, fused in (((512, 96, 512), True), ((512, 64, 512), False)):
+        x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+        ref = np.fft.fftn(x)
+        a, f, b = _plans(shape, (0, 1, 2), 1, 0, 0, 126)
+        desc = _lib.engine().plan_describe(f._plan)
+        assert ('fused pair (strided -> rows)' in desc) == fused, desc
+        if fused:
+            assert 'ring of 48 slots' in desc, desc
+        a[...] = x
+        for rep in range(3):
+            got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
+            assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max()
+            if rep == 0:
+                first = got.copy()
+            assert np.array_equal(got, first)
+        back = np.asarray(b.execute_scaled(f.output_array, b.output_array, 1.0 / x.size))
+        assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
+        f.destroy()
+        b.destroy()
