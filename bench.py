@@ -595,7 +595,7 @@ def run(args, guard, state):
         # intermediate is handed over inside the Infinity Cache, so HBM has to carry one read and one write of the
         # array only (2 S).  `frac` above prices the launch against the algorithmic bytes and may exceed the copy
         # ceiling -- or 1 -- for that reason; `frac_hbm_min` prices what HBM actually must move.
-        fused = 'fused pair' in name
+        fused = name.startswith('fused')
         hbm_min = k['bytes'] / 2 if fused else k['bytes']
         roofline['hbm_min_bytes_per_launch'] = hbm_min
         roofline['frac_hbm_min'] = round(hbm_min / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -274,11 +274,19 @@ __host__ __device__ constexpr bool is_pow2_c(int n) { return n > 0 && (n & (n - 
 // slot padding: power-of-two sizes insert one word per 16 (breaks the power-of-two scatter
 // strides); sizes with a factor 3 scatter with odd multiples and need none.  PAD is a
 // compile-time property of N so that pad(a + b) splits into pad(a) + constant (see Stage::run).
-template <bool PAD> __host__ __device__ constexpr int pad_slot(int e) { return PAD ? e + (e >> 4) : e; }
+template <int PADSH> __host__ __device__ constexpr int pad_slot(int e) { return PADSH ? e + (e >> PADSH) : e; }
+// ... one word per 32 where a ROW pass opens with a radix-32 stage: its threads scatter 32 slots apart, and with one pad
+// word per 16 that is 34 words = 68 dwords == 4 (mod 32 banks) between neighbouring lanes, a 2-way conflict in every
+// 16-lane group of ds_write_b64 (the fused launch on 32 values per thread: 19 % of its LDS cycles,
+// profiles/r04_bench_1024c128_pmc_lds.txt); 33 words = 66 dwords == 2 is conflict free.  Strided passes run their lanes
+// along the adjacent columns first (column stride CS, below) and keep the one-per-16 rule they were measured with.
+template <int... RADS> struct FirstRadix { static constexpr int value = 0; };
+template <int r0, int... REST> struct FirstRadix<r0, REST...> { static constexpr int value = r0; };
+template <int N, int R0, bool COLS> __host__ __device__ constexpr int pad_shift() { return is_pow2_c(N) ? ((R0 == 32 && !COLS) ? 5 : 4) : 0; }
 
-template <int N, bool COLS, int T, bool W4 = false> struct Lds {
-  static constexpr bool PAD = is_pow2_c(N);
-  static constexpr int NP = PAD ? N + N / 16 + 1 : N + 1;
+template <int N, bool COLS, int T, bool W4 = false, int R0 = 16> struct Lds {
+  static constexpr int PADSH = pad_shift<N, R0, COLS>();
+  static constexpr int NP = PADSH ? N + (N >> PADSH) + 1 : N + 1;
   // COLS: lanes run over T adjacent columns first, so the column stride CS (in words) decides the
   // banks.  8-byte words (fp64 planes, unsplit fp32 pairs; ds_*_b64, 64 banks):
   // T <= 8: CS == 2 (mod 16): 8 columns x 2 rows cover the 32 write banks.
@@ -431,14 +439,14 @@ template <bool WL> __device__ __forceinline__ void tile_sync() {
 // kernel it cost 16 VGPRs + 100 bytes of scratch.  Not kept.)
 template <int N, int R, bool COLS> struct WaveLocal { static constexpr bool value = !COLS && (64 % (N / R)) == 0; };
 
-template <typename real, int N, int R, bool SPLIT, bool WL, int Ns, int... RADS> struct Stage;
+template <typename real, int N, int R, bool SPLIT, bool WL, int PADSH, int Ns, int... RADS> struct Stage;
 
-template <typename real, int N, int R, bool SPLIT, bool WL, int Ns> struct Stage<real, N, R, SPLIT, WL, Ns> {
+template <typename real, int N, int R, bool SPLIT, bool WL, int PADSH, int Ns> struct Stage<real, N, R, SPLIT, WL, PADSH, Ns> {
   static __device__ __forceinline__ void run(cx<real> *, int, void *, const cx<real> *) {}
 };
 
-template <typename real, int N, int R, bool SPLIT, bool WL, int Ns, int r, int... REST>
-struct Stage<real, N, R, SPLIT, WL, Ns, r, REST...> {
+template <typename real, int N, int R, bool SPLIT, bool WL, int PADSH, int Ns, int r, int... REST>
+struct Stage<real, N, R, SPLIT, WL, PADSH, Ns, r, REST...> {
   static constexpr int NT = N / R;   // threads per column
   static constexpr int NB = R / r;   // butterflies per thread in this stage
   static __device__ __forceinline__ void run(cx<real> *v, int t, void *col,
@@ -459,7 +467,7 @@ struct Stage<real, N, R, SPLIT, WL, Ns, r, REST...> {
       // scatter: butterfly j = t + i*NT, output m -> index j0 + m*Ns, j0 = (j/Ns)*Ns*r + j%Ns.
       // pad_slot(j0 + m*Ns) == pad_slot(j0) + woff(m) and pad_slot(t + q*NT) == pad_slot(t) + roff(q)
       // for power-of-two Ns, NT: one address register per butterfly, the rest are DS immediates.
-      constexpr bool PAD = is_pow2_c(N);
+      constexpr int PAD = PADSH;
       int wbase[NB];
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -502,7 +510,7 @@ struct Stage<real, N, R, SPLIT, WL, Ns, r, REST...> {
         }
       }
       GFFT_PHASE(PH + 1)
-      Stage<real, N, R, SPLIT, WL, Ns * r, REST...>::run(v, t, col, tw);
+      Stage<real, N, R, SPLIT, WL, PADSH, Ns * r, REST...>::run(v, t, col, tw);
     }
   }
 };
@@ -713,10 +721,10 @@ template <typename real, int R> __device__ __forceinline__ cx<real> mirror_twidd
   return {wt.x * c - wt.y * s, wt.x * s + wt.y * c};
 }
 
-template <typename real, int N, int R, bool SPLIT, bool WL, typename F>
+template <typename real, int N, int R, bool SPLIT, bool WL, int PADSH, typename F>
 __device__ __forceinline__ void mirror_pass(cx<real> *v, int t, void *col, cx<real> top, F &&combine) {
   constexpr int NT = N / R;
-  constexpr bool PAD = is_pow2_c(N);
+  constexpr int PAD = PADSH;
   if constexpr (SPLIT) {
     real *w = reinterpret_cast<real *>(col);
     real px[R];
@@ -883,7 +891,7 @@ struct PassCfg {
   typedef real_ real;
   static constexpr int threads = T * (N / R);
   static constexpr int regs_per_thread = R * 2 * (int)(sizeof(real_) / 4);     // the column's values alone, in VGPRs
-  static constexpr size_t lds = (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real_) == 4)>::CS * (SPLIT ? sizeof(real_) : 2 * sizeof(real_));
+  static constexpr size_t lds = (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real_) == 4), FirstRadix<RADS...>::value>::CS * (SPLIT ? sizeof(real_) : 2 * sizeof(real_));
   template <typename HOOK>
   static __device__ __forceinline__ void tile(const PassDesc &d, const void *in, void *out, unsigned char *smem, unsigned t,
                                               double scale, HOOK &&hook) {
@@ -1140,7 +1148,7 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   constexpr int NT = N / R;
   constexpr int threads = T * NT;
   static_assert(threads >= 64 && threads <= 1024, "workgroup size");
-  constexpr size_t lds_x = (sizeof...(RADS) > 1 || (FLAGS & 32) || MODE == MODE_R2C_H || MODE == MODE_C2R_H) ? (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real) == 4)>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
+  constexpr size_t lds_x = (sizeof...(RADS) > 1 || (FLAGS & 32) || MODE == MODE_R2C_H || MODE == MODE_C2R_H) ? (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real) == 4), FirstRadix<RADS...>::value>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
   constexpr size_t lds_f = (FLAGS & 16) ? (size_t)T * 2 * sizeof(real) : 0;
   constexpr size_t lds = lds_x > lds_f ? lds_x : lds_f;
   static_assert(lds <= 160 * 1024, "LDS budget");

@@ -28,18 +28,26 @@ for _ in range(3):
 torch.cuda.synchronize()
 tr = np.fromfile(out, dtype=np.uint64).reshape(1024, 96, 16).astype(np.int64)
 lo, hi = 8, 95
-names = ['wait for counter', 'loads', 'stage 1 butterflies', 'exchange 1', 'stage 2 (twiddles + butterflies)', 'exchange 2',
-         'stage 3', 'issue stores', 'raise counter (A: acks)', 'to next ticket']
+# the default kernels (32 values per thread) have two butterfly stages and one exchange; GFFT_FUSE2=3 (the round-3
+# kernels, 16 values per thread) three stages and two exchanges
+three = os.environ.get('GFFT_FUSE2', '1') == '3'
+if three:
+    names = ['wait for counter', 'loads', 'stage 1 butterflies', 'exchange 1', 'stage 2 (twiddles + butterflies)', 'exchange 2',
+             'stage 3', 'issue stores', 'raise counter (A: acks)', 'to next ticket']
+    pick = lambda s, nxt: [s[0], s[1], s[2], s[8], s[9], s[10], s[11], s[12], s[3], s[4], nxt]
+else:
+    names = ['wait for counter', 'loads', 'stage 1 butterflies', 'exchange', 'stage 2 (twiddles + butterflies)',
+             'issue stores', 'raise counter (A: acks; B: slowest wave)', 'to next ticket']
+    pick = lambda s, nxt: [s[0], s[1], s[2], s[8], s[9], s[10], s[3], s[4], nxt]
 for kind, label in ((1, 'A tiles (strided, workspace -> ring)'), (0, 'B tiles (ring -> rows of the output)')):
     rows = []
     for b in range(1024):
         for it in range(lo, hi):
             if tr[b, it, 7] == 0 or tr[b, it + 1, 0] == 0 or (tr[b, it, 7] & 1) != kind:
                 continue
-            s = tr[b, it]
-            pts = [s[0], s[1], s[2], s[8], s[9], s[10], s[11], s[12], s[3], s[4], tr[b, it + 1, 0]]
-            rows.append([pts[i + 1] - pts[i] for i in range(10)] + [pts[-1] - pts[0]])
+            pts = pick(tr[b, it], tr[b, it + 1, 0])
+            rows.append([pts[i + 1] - pts[i] for i in range(len(pts) - 1)] + [pts[-1] - pts[0]])
     r = np.array(rows, dtype=np.float64) / 100.0
     print('%s: %d samples, %.2f us per tile (median %.2f)' % (label, len(r), r[:, -1].mean(), np.median(r[:, -1])))
     for i, n in enumerate(names):
-        print('   %-34s mean %6.2f  median %6.2f  p90 %6.2f us' % (n, r[:, i].mean(), np.median(r[:, i]), np.percentile(r[:, i], 90)))
+        print('   %-44s mean %6.2f  median %6.2f  p90 %6.2f us' % (n, r[:, i].mean(), np.median(r[:, i]), np.percentile(r[:, i], 90)))
