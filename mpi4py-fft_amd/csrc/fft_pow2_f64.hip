@@ -95,16 +95,27 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
       case 256: return P64F(256, 8, 16, true, 1, 8, 8, 8, 4);
       case 512:
         switch (variant) {
-          default: return P64F(512, 8, 16, true, 1, 8, 8, 8, 8);
+          // R4: 32 values per thread, radices 32 x 16 = ONE exchange, 256 threads on 16 columns (two workgroups per CU),
+          // non-temporal loads and stores.  Against the former default (17), same box, tools/variant_cols_probe.py:
+          // (512,512,512) axis 1 0.85-0.88 -> 0.79 ms, axis 0 0.95 -> 0.83 ms; the C3 stage (512,256,512) axis 0 0.47-0.48 ->
+          // 0.40 ms, (256,512,512) axis 1 0.42 -> 0.39-0.41 ms (profiles/r04_variant_cols_r32.txt)
+          default: return P64F(512, 32, 16, true, 2, 8 | 3, 32, 16);
+          case 15: return P64F(512, 32, 16, true, 2, 8, 32, 16);         // ... with plain loads and stores
+          case 17: return P64F(512, 8, 16, true, 1, 8, 8, 8, 8);         // 8 values per thread, radices 8.8.8, 1024 threads (rounds 1-3; real 3-D schedules)
 #ifdef GFFT_VARIANTS
           case 1: return P64F(512, 8, 8, true, 1, 8, 8, 8, 8);
 #endif
         }
       case 1024:
         switch (variant) {
-          default: return P64F(1024, 16, 16, true, 4, 8, 16, 16, 4);  // 256-B segments, 1024 threads, <=128 VGPRs
-          case 15: return P64F(1024, 32, 16, true, 2, 8, 32, 32);     // 32 values per thread, ONE exchange, 512 threads, <=256 VGPRs
-          case 16: return P64F(1024, 32, 16, true, 2, 8 | 3, 32, 32); // ... with non-temporal loads and stores
+          // R4: 32 values per thread, radices 32 x 32 = ONE exchange, 512 threads (<= 256 VGPRs: 181), non-temporal loads
+          // and stores.  Against the former default (17): the stand-alone pass of the complex 3-D schedule 6.62 -> 6.45 ms
+          // (profiles/r04_ab_cols_r32.txt); the C4-on-8-GPUs stages (256,1024,512) axis 1 0.87 -> 0.80-0.82 ms and
+          // (1024,256,512) axis 0 0.98-1.01 -> 0.85-0.91 ms (54 -> 59-63 % of 8 TB/s; profiles/r04_variant_cols_r32.txt).
+          // Under REAL 3-D schedules it loses 1.5-3 % (profiles/r04_real_pairs.txt): plan_fused3 asks for 17 there.
+          default: return P64F(1024, 32, 16, true, 2, 8 | 3, 32, 32);
+          case 15: return P64F(1024, 32, 16, true, 2, 8, 32, 32);     // ... with plain loads and stores
+          case 17: return P64F(1024, 16, 16, true, 4, 8, 16, 16, 4);  // 16 values per thread, radices 16.16.4, 1024 threads, <= 128 VGPRs (rounds 1-3)
 #ifdef GFFT_VARIANTS
           case 1: return P64F(1024, 8, 8, true, 1, 8, 8, 8, 8, 2);    // 128-B segments, 1024 threads, 86 VGPRs
           case 2: return P64F(1024, 16, 8, true, 1, 8, 16, 16, 4);    // 512 threads, ~134 VGPRs: 1 tile/CU

@@ -196,6 +196,10 @@ bool fused2_real_supported_f64(int kind, int n_a, int n_b);
 int fused2_real_tiles_f64(int kind, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b);
 hipError_t launch_fused2_real_f64(int kind, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs, const FusedDesc &f,
                                   const void *in, void *ring, void *out, hipStream_t s);
+bool fused2_real_supported_f32(int kind, int n_a, int n_b);
+int fused2_real_tiles_f32(int kind, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b);
+hipError_t launch_fused2_real_f32(int kind, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs, const FusedDesc &f,
+                                  const void *in, void *ring, void *out, hipStream_t s);
 
 // packed-real row kernels (fft_real_*.hip): d.n = complex length = half the real length
 bool real_half_supported(int n_complex);

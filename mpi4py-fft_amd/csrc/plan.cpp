@@ -78,7 +78,7 @@ struct Options {
   int fuse2_defer = 0;       // settle an A tile's counter behind the next tile's loads (A/B)
   int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
   int fuse2_kinds = 126;     // which pairs (bit = FusedKind): measured per kind, see make_fused2
-  int fuse2_f32 = 1;         // complex64 pairs (fft_fused_f32.hip)
+  int fuse2_f32 = 1;         // 1: complex64 pairs (fft_fused_f32.hip); 2: the real fp32 pairs too (fft_fused_real_f32.hip: measured level, off)
   int fuse2_wait_ms = 2000;  // wall-clock limit of one wait inside a fused launch before the launch is voided (0: at once -- test hook)
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
@@ -499,11 +499,11 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   // (fp64 only: the fp32 pairs measured slower than their stand-alone passes, fft_fused_f64.hip)
   const bool real_kind = kind == FUSED_R2C_PLANES || kind == FUSED_COLS_C2R;
   const bool f32 = pl->precision == GFFT_F32;
-  if (f32 && (!opts().fuse2_f32 || real_kind)) return false;
-  if (f32 ? !fused2_supported_f32(kind, dA.n, dB.n)
+  if (f32 && (!opts().fuse2_f32 || (real_kind && opts().fuse2_f32 < 2))) return false;
+  if (f32 ? (real_kind ? !fused2_real_supported_f32(kind, dA.n, dB.n) : !fused2_supported_f32(kind, dA.n, dB.n))
           : (real_kind ? !fused2_real_supported_f64(kind, dA.n, dB.n) : !fused2_supported_f64(kind, variant, dA.n, dB.n))) return false;
   int ta = 0, tb = 0;
-  if ((f32 ? fused2_tiles_f32(kind, dA, dB, &ta, &tb)
+  if ((f32 ? (real_kind ? fused2_real_tiles_f32(kind, dA, dB, &ta, &tb) : fused2_tiles_f32(kind, dA, dB, &ta, &tb))
            : (real_kind ? fused2_real_tiles_f64(kind, dA, dB, &ta, &tb) : fused2_tiles_f64(kind, variant, dA, dB, &ta, &tb))) || ta < 1 || tb < 1) return false;
   // (hand-off accesses carry 32-bit byte offsets inside a slot; tickets are 32-bit)
   if (slot_bytes >= ((int64_t)1 << 31) || (double)planes * (ta + tb) >= 1.0e9) return false;     // (tickets < 2^30: a launch that gives up pushes the counter 2^31 on)
@@ -1253,10 +1253,16 @@ int plan_fused3(gfft_plan_s *pl) {
                                                 : (opts().fuse2_f32 && fused2_supported_f32(FUSED_COLS_ROWS, (int)n0, (int)n2)));
   // Real transforms: forward [r2c rows -> axis 1] on the contiguous planes i0 of the flat_out schedule (FUSED_R2C_PLANES),
   // backward [axis 0 -> c2r rows] on the planes i1 (FUSED_COLS_C2R), as the complex schedule runs its last two passes
-  const bool pair_real = real && !tr && opts().fuse2 && prec == GFFT_F64 && n2 % 2 == 0 && opts().real_half &&
-                         (inverse ? (((opts().fuse2_kinds >> FUSED_COLS_C2R) & 1) && fused2_real_supported_f64(FUSED_COLS_C2R, (int)n0, (int)(n2 / 2)) &&
+  auto real_ok = [&](int kind, int na, int nb) {
+    // (real fp32 pairs: built and measured level to slightly slower than their stand-alone passes -- 1024^3 r2c f32 per step
+    // 11.53 ms unfused, 11.58 with both pairs, 11.78 with the r2c pair alone, 11.42 with the c2r pair alone,
+    // profiles/r04_real_pairs_f32.txt -- so they need option fuse2_f32 = 2)
+    return prec == GFFT_F64 ? fused2_real_supported_f64(kind, na, nb) : (opts().fuse2_f32 >= 2 && fused2_real_supported_f32(kind, na, nb));
+  };
+  const bool pair_real = real && !tr && opts().fuse2 && n2 % 2 == 0 && opts().real_half &&
+                         (inverse ? (((opts().fuse2_kinds >> FUSED_COLS_C2R) & 1) && real_ok(FUSED_COLS_C2R, (int)n0, (int)(n2 / 2)) &&
                                      fused2_ring(prec, (int)n0, (int)(n2 / 2), n0 * P * esz, (int)n1, &ring_probe, &lag_probe))
-                                  : (((opts().fuse2_kinds >> FUSED_R2C_PLANES) & 1) && flat_out && fused2_real_supported_f64(FUSED_R2C_PLANES, (int)(n2 / 2), (int)n1) &&
+                                  : (((opts().fuse2_kinds >> FUSED_R2C_PLANES) & 1) && flat_out && real_ok(FUSED_R2C_PLANES, (int)(n2 / 2), (int)n1) &&
                                      fused2_ring(prec, (int)(n2 / 2), (int)n1, n1 * P * esz, (int)n0, &ring_probe, &lag_probe)));
   if (pair_real && inverse && opts().fuse2_wlayout) { w_i0 = n1 * P; w_i1 = P; }     // (as under the complex pair, below)
   const bool cols_first = !inverse && pair_cols_rows;
@@ -1361,10 +1367,11 @@ int plan_fused3(gfft_plan_s *pl) {
   // 512^3 c64 1.39 / 1.35 -> 1.30 / 1.30 ms, 1024^3 c64 10.7 / 10.9 -> 10.6 / 11.0 ms.  (On natural
   // power-of-two strides -- the stage arrays of multi-GPU transforms -- the wide tile stays ahead.)
   if (prec == GFFT_F32 && pl->variant_cols == 0) pl->variant_cols = 2;
-  // fp64 strided passes of length 1024 in this schedule: 32 values per thread and ONE LDS exchange on 512 threads,
-  // non-temporal loads and stores (variant 16 of the table) -- the CU is back at its memory work sooner: same arrays,
-  // plans alternating, 1024^3 c128 per step 32.85 -> 32.51 ms, the pass 6.62 -> 6.45 ms (profiles/r04_ab_cols_r32.txt)
-  if (prec == GFFT_F64 && !real && pl->variant_cols == 0) pl->variant_cols = 16;
+  // fp64 REAL schedules keep the strided kernels of rounds 1-3 (table variant 17: 16 / 8 values per thread, two
+  // exchanges): the round-4 defaults -- 32 values per thread, one exchange, non-temporal streams -- gain on complex
+  // schedules (1024^3 c128 per step 32.85 -> 32.51 ms) and on natural-stride stage arrays, and lose 1.5-3 % here
+  // (1024^3 r2c f64 per step 18.76 -> 19.03 / 19.31 ms, profiles/r04_real_pairs.txt)
+  if (prec == GFFT_F64 && real && pl->variant_cols == 0) pl->variant_cols = 17;
   // Workgroups per launch.  Each walks tiles block, block + grid, ...; more, shorter walks balance the
   // tail better, too many lose the overlap of one tile's stores with the next one's loads.  Clean A/B
   // on fixed caller arrays (tools/ab_option_probe.py grid_cap ...), fwd + bwd per step: 1024^3 c128
@@ -1772,7 +1779,9 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
       }
       static const int debug = getenv("GFFT_FUSE2_DEBUG") ? atoi(getenv("GFFT_FUSE2_DEBUG")) : 0;
       if (debug) { f.wait_ticks = 100000u; f.host_flag = nullptr; f.debug = (unsigned)debug; }      // (1 ms; counters printed below)
-      if (pl->precision == GFFT_F32)
+      if (pl->precision == GFFT_F32 && (p.fused_kind == FUSED_R2C_PLANES || p.fused_kind == FUSED_COLS_C2R))
+        HIP_TRY(launch_fused2_real_f32(p.fused_kind, d, d2, p.dev_descs, f, bufs[p.src], ring, bufs[p.dst], s));
+      else if (pl->precision == GFFT_F32)
         HIP_TRY(launch_fused2_f32(p.fused_kind, d, d2, p.dev_descs, f, bufs[p.src], ring, bufs[p.dst], s));
       else if (p.fused_kind == FUSED_R2C_PLANES || p.fused_kind == FUSED_COLS_C2R)
         HIP_TRY(launch_fused2_real_f64(p.fused_kind, d, d2, p.dev_descs, f, bufs[p.src], ring, bufs[p.dst], s));

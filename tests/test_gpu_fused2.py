@@ -19,7 +19,7 @@ def _opts(**kw):
 @pytest.fixture(autouse=True)
 def _restore():
     yield
-    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=126, fuse2_wait_ms=2000)
+    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=126, fuse2_wait_ms=2000, fuse2_f32=1)
 
 
 def _plans(shape, axes, fuse, ring=8, lag=4, kinds=15, dt='D'):
@@ -359,3 +359,36 @@ def test_fused_pair_at_n_512_and_where_it_stays_off():
         assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
         f.destroy()
         b.destroy()
+
+
+@pytest.mark.parametrize('shape', [(96, 1024, 1024), (1024, 96, 1024)])
+def test_fused_pairs_of_real_fp32_transforms(shape):
+    """The real pairs in single precision (csrc/fft_fused_real_f32.hip), planes of 4 MiB on a ring of 46: r2c on
+    (96, 1024, 1024), c2r on (1024, 96, 1024); against numpy in double precision and against the unfused plans."""
+    from mpi4py_fft_amd import _lib, fftw, zeros
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal(shape).astype('f')
+    ref = np.fft.rfftn(x.astype('d'))
+    res = {}
+    for fuse in (0, 1):
+        _opts(fuse2=fuse, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=126, fuse2_f32=2)          # (2: the real fp32 pairs are off by default, measured level)
+        a = zeros(shape, 'f')
+        f = fftw.rfftn(a, axes=(0, 1, 2))
+        c = zeros(ref.shape, 'F')
+        b = fftw.irfftn(c, s=shape, axes=(0, 1, 2))
+        df, db = _lib.engine().plan_describe(f._plan), _lib.engine().plan_describe(b._plan)
+        if fuse:
+            assert ('fused pair (r2c rows -> strided)' in df) == (shape[1] == 1024), df
+            assert ('fused pair (strided -> c2r rows)' in db) == (shape[0] == 1024), db
+        a[...] = x
+        got = np.asarray(f.execute_scaled(a, f.output_array, 1.0)).copy()
+        assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()
+        assert np.array_equal(np.asarray(f.execute_scaled(a, f.output_array, 1.0)), got)
+        c[...] = ref.astype('F')
+        back = np.asarray(b.execute_scaled(c, b.output_array, 1.0 / x.size)).copy()
+        assert np.abs(back - x).max() <= 1e-4 * np.abs(x).max()
+        res[fuse] = (got, back)
+        f.destroy()
+        b.destroy()
+    assert np.abs(res[0][0] - res[1][0]).max() <= 1e-5 * np.abs(ref).max()
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-5 * np.abs(x).max()
