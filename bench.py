@@ -599,6 +599,12 @@ def run(args, guard, state):
         hbm_min = k['bytes'] / 2 if fused else k['bytes']
         roofline['hbm_min_bytes_per_launch'] = hbm_min
         roofline['frac_hbm_min'] = round(hbm_min / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if fused:
+            # what actually bounds a fused launch: reads + writes across the XCDs' L2 boundary, ~7.5 TB/s in total whether the
+            # Infinity Cache or HBM serves them (measured: profiles/r04_copy_sweep.txt, r04_mall_probe2.txt);
+            # the launch moves its 4 S algorithmic bytes across it
+            roofline['l2_boundary_ceiling_gbs'] = 7500.0
+            roofline['frac_of_l2_boundary'] = round(achieved / 7500.0, 4)
         roofline['note'] = ('frac = SURVEY 8d algorithmic bytes (one read + one write of the array per transformed axis) / '
                             'launch time / 8 TB/s; ' +
                             ('this launch is a fused pair of axis passes whose intermediate stays in the Infinity Cache, so '

@@ -128,6 +128,14 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
           // pitched, behind by 19 % on natural far strides: still not the default.
           case 2: return P32F(1024, 32, 16, true, true, 4, 8, 16, 16, 4);
 #ifdef GFFT_VARIANTS
+          // R4, measured and NOT kept: 64 values per thread, radices 64 x 16 = ONE exchange, 512 threads on 32 columns
+          // (256-byte segments) -- what paid in fp64 (32 values, fft_pow2_f64.hip) does not here: 64 complex64 are 128 VGPRs of
+          // data alone, the kernels take all 256 plus 130-160 bytes of scratch, and (1024,1024,1024) axis 1 goes 3.82 -> 4.72 ms
+          // (4.50 with non-temporal streams), axis 0 4.8-4.9 -> 6.44 / 4.93 ms (profiles/r04_variant_cols_f32_r64.txt)
+          case 5: return P32F(1024, 64, 32, true, true, 2, 8, 64, 16);
+          case 6: return P32F(1024, 64, 32, true, true, 2, 8 | 3, 64, 16);     // ... with non-temporal loads and stores
+#endif
+#ifdef GFFT_VARIANTS
           // A/B: two radix-32 stages = ONE exchange instead of two (LDS cycles and barriers halved), but the
           // 32-point butterfly with its 31 stage twiddles does not fit 128 VGPRs at 1024 threads
           // (116 B of scratch per lane): pitched near 4.33 ms against 3.61, far 5.18 against 4.02
@@ -137,6 +145,12 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 2048:
         switch (variant) {
           default: return P32F(2048, 32, 16, true, true, 1, 8, 16, 16, 8);
+#ifdef GFFT_VARIANTS
+          // R4, measured and NOT kept (as at n = 1024): radices 64 x 32 = ONE exchange, 512 threads on 16 columns -- the C5 stages
+          // (512,2048,513) axis 1 2.53 -> 2.80 ms (3.81 with non-temporal streams), (2048,512,513) axis 0 2.38 -> 2.65 / 2.36 ms
+          case 5: return P32F(2048, 64, 16, true, true, 2, 8, 64, 32);
+          case 6: return P32F(2048, 64, 16, true, true, 2, 8 | 3, 64, 32);
+#endif
 #ifdef GFFT_VARIANTS
           case 1: return P32(2048, 16, 8, true, true, 4, 16, 16, 8);
 #endif

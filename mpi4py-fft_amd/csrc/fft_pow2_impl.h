@@ -147,6 +147,67 @@ template <typename real, int S> __device__ __forceinline__ void dft32(cx<real> *
   for (int k = 0; k < 32; ++k) v[k * S] = o[k];
 }
 
+// compile-time exp(-2 pi i m / 64) for the radix-64 internal twiddles (Taylor evaluation in long double, namespace ct below
+// is declared later: a small local copy of the two series keeps this table self-contained)
+namespace ct64 {
+constexpr long double PI = 3.14159265358979323846264338327950288L;
+constexpr long double sin_s(long double x) { long double t = x, s = x; for (int k = 1; k < 16; ++k) { t *= -x * x / ((2 * k) * (2 * k + 1)); s += t; } return s; }
+constexpr long double cos_s(long double x) { long double t = 1, s = 1; for (int k = 1; k < 16; ++k) { t *= -x * x / ((2 * k - 1) * (2 * k)); s += t; } return s; }
+// angles 0 .. 2 pi (49/64 at most here), reduced to |x| <= pi/4 by quadrant
+constexpr long double cosq(int m) {          // cos(2 pi m / 64), m in 0..63
+  const int mm = m % 64;
+  const int oct = mm / 8, r = mm % 8;        // angle = oct * pi/4 + r * pi/32
+  const long double a = PI * r / 32;
+  const long double c = cos_s(a), s = sin_s(a);
+  const long double h = 0.70710678118654752440084436210485L;
+  // cos(oct pi/4 + a) = cos(oct pi/4) cos a - sin(oct pi/4) sin a
+  const long double co[8] = {1, h, 0, -h, -1, -h, 0, h}, so[8] = {0, h, 1, h, 0, -h, -1, -h};
+  return co[oct] * c - so[oct] * s;
+}
+constexpr long double sinq(int m) {
+  const int mm = m % 64;
+  const int oct = mm / 8, r = mm % 8;
+  const long double a = PI * r / 32;
+  const long double c = cos_s(a), s = sin_s(a);
+  const long double h = 0.70710678118654752440084436210485L;
+  const long double co[8] = {1, h, 0, -h, -1, -h, 0, h}, so[8] = {0, h, 1, h, 0, -h, -1, -h};
+  return so[oct] * c + co[oct] * s;
+}
+}  // namespace ct64
+template <typename real> struct W64 {
+  // a * exp(-2 pi i m / 64), m a compile-time value after unrolling
+  static __device__ __forceinline__ cx<real> mul(cx<real> a, int m) {
+    constexpr struct Tab { real c[64], s[64]; constexpr Tab() : c(), s() { for (int k = 0; k < 64; ++k) { c[k] = (real)ct64::cosq(k); s[k] = (real)-ct64::sinq(k); } } } tab{};
+    const real wx = tab.c[m % 64], wy = tab.s[m % 64];
+    return {a.x * wx - a.y * wy, a.x * wy + a.y * wx};
+  }
+};
+
+template <typename real, int S> __device__ __forceinline__ void dft64(cx<real> *v) {
+  // n = i + 8a (i < 8, a < 8);  X[k1 + 8 k2] = sum_i W8^(i k2) W64^(i k1) sum_a x[i + 8a] W8^(a k1)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dft8<real, 8 * S>(v + i * S);          // Y_i[k1] at position i + 8 k1
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) {
+      const int m = i * k1;
+      if (m == 8) v[(i + 8 * k1) * S] = mul_w8_1(v[(i + 8 * k1) * S]);
+      else if (m == 16) v[(i + 8 * k1) * S] = mul_mi(v[(i + 8 * k1) * S]);
+      else if (m == 24) v[(i + 8 * k1) * S] = mul_w8_3(v[(i + 8 * k1) * S]);
+      else v[(i + 8 * k1) * S] = W64<real>::mul(v[(i + 8 * k1) * S], m);
+    }
+#pragma unroll
+  for (int k1 = 0; k1 < 8; ++k1) dft8<real, S>(v + 8 * k1 * S);      // over i: X[k1 + 8 k2] at position 8 k1 + k2
+  cx<real> o[64];
+#pragma unroll
+  for (int k1 = 0; k1 < 8; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) o[k1 + 8 * k2] = v[(8 * k1 + k2) * S];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) v[k * S] = o[k];
+}
+
 template <typename real> __device__ __forceinline__ void bf3(cx<real> &a, cx<real> &b, cx<real> &c) {
   const real h = (real)0.86602540378443864676372317075294;   // sin(pi/3)
   cx<real> t1 = b + c;
@@ -256,7 +317,7 @@ template <typename real, int S> __device__ __forceinline__ void dft20(cx<real> *
 }
 
 template <typename real, int r, int S> __device__ __forceinline__ void dft(cx<real> *v) {
-  static_assert(r == 2 || r == 3 || r == 4 || r == 5 || r == 8 || r == 10 || r == 12 || r == 16 || r == 20 || r == 32, "radix");
+  static_assert(r == 2 || r == 3 || r == 4 || r == 5 || r == 8 || r == 10 || r == 12 || r == 16 || r == 20 || r == 32 || r == 64, "radix");
   if constexpr (r == 2) dft2<real, S>(v);
   else if constexpr (r == 3) dft3<real, S>(v);
   else if constexpr (r == 4) dft4<real, S>(v);
@@ -266,6 +327,7 @@ template <typename real, int r, int S> __device__ __forceinline__ void dft(cx<re
   else if constexpr (r == 12) dft12<real, S>(v);
   else if constexpr (r == 16) dft16<real, S>(v);
   else if constexpr (r == 32) dft32<real, S>(v);
+  else if constexpr (r == 64) dft64<real, S>(v);
   else dft20<real, S>(v);
 }
 
