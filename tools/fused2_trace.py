@@ -15,7 +15,12 @@ os.environ['GFFT_FUSE2_TRACE_FILE'] = out
 import numpy as np, torch
 from mpi4py_fft_amd import PFFT, comm, _lib, fftw, zeros
 _lib.LIBPATH = os.path.join(os.path.dirname(_lib.LIBPATH), 'libgfft_trace.so')
-if 'c2' in sys.argv[1:]:
+if 'r2c' in sys.argv[1:] or 'c2r' in sys.argv[1:]:
+    fft = PFFT(comm.COMM_SELF, (1024,) * 3, dtype='d')
+    fft.forward.input_array.tensor.normal_()
+    fft.forward()
+    run = (lambda: fft.forward()) if 'r2c' in sys.argv[1:] else (lambda: fft.backward())
+elif 'c2' in sys.argv[1:]:
     a = zeros((64, 1 << 20), 'D'); torch.view_as_real(a.tensor).normal_()
     p = fftw.fftn(a, axes=(1,))
     run = lambda: p.execute_scaled(a, p.output_array, 1.0)
@@ -31,7 +36,11 @@ lo, hi = 8, 95
 # the default kernels (32 values per thread) have two butterfly stages and one exchange; GFFT_FUSE2=3 (the round-3
 # kernels, 16 values per thread) three stages and two exchanges
 three = os.environ.get('GFFT_FUSE2', '1') == '3'
-if three:
+if 'r2c' in sys.argv[1:] or 'c2r' in sys.argv[1:]:
+    # (row and strided tiles of the real pairs have different stage counts: coarse phases only)
+    names = ['wait for counter', 'loads', 'butterflies + exchanges (+ Hermitian pass)', 'issue stores', 'raise counter (A: acks; B: slowest wave)', 'to next ticket']
+    pick = lambda s, nxt: [s[0], s[1], s[2], s[5], s[3], s[4], nxt]
+elif three:
     names = ['wait for counter', 'loads', 'stage 1 butterflies', 'exchange 1', 'stage 2 (twiddles + butterflies)', 'exchange 2',
              'stage 3', 'issue stores', 'raise counter (A: acks)', 'to next ticket']
     pick = lambda s, nxt: [s[0], s[1], s[2], s[8], s[9], s[10], s[11], s[12], s[3], s[4], nxt]
@@ -39,7 +48,7 @@ else:
     names = ['wait for counter', 'loads', 'stage 1 butterflies', 'exchange', 'stage 2 (twiddles + butterflies)',
              'issue stores', 'raise counter (A: acks; B: slowest wave)', 'to next ticket']
     pick = lambda s, nxt: [s[0], s[1], s[2], s[8], s[9], s[10], s[3], s[4], nxt]
-for kind, label in ((1, 'A tiles (strided, workspace -> ring)'), (0, 'B tiles (ring -> rows of the output)')):
+for kind, label in ((1, 'A tiles (producer: -> ring)'), (0, 'B tiles (consumer: ring ->)')):
     rows = []
     for b in range(1024):
         for it in range(lo, hi):
