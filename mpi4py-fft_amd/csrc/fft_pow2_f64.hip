@@ -32,6 +32,8 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
         if (d.tr_dir && variant == 0) return P64(1024, 8, 2, false, 1, 8, 8, 8, 2);
         switch (variant) {
           default: return P64(1024, 16, 4, false, 1, 16, 16, 4);   // 4 rows / 256 threads, 2 exchanges
+          // (R4: 32 values per thread / ONE exchange inside the wave, 8 rows per 256 threads, was measured too: level --
+          // (256,512,1024) axis 2 0.745-0.776 against 0.760-0.764 ms; row passes already run at the copy rate)
 #ifdef GFFT_VARIANTS   // measured alternatives (make VARIANTS=1): not in the shipped library
           case 1: return P64(1024, 8, 1, false, 1, 8, 8, 8, 2);
           case 2: return P64(1024, 16, 1, false, 1, 16, 16, 4);
