@@ -67,6 +67,11 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
     // Up to n = 1024 they now take 16 columns per tile like the plain passes (these variants
     // used to spill at R = 16 until the row index was laundered, see fft_pow2_impl.h); the lean
     // R = 8 plans with 128-byte segments remain for n >= 2048 and as variant 9.
+    // R4: the complex pass with the fused TRUNCATING store (forward direction of a 3/2-rule transform) on 32 values per
+    // thread / one exchange: 683^3 -> 1024^3 c128 forward 12.0-12.3 -> 11.5-11.7 ms.  The zero-padding LOAD side on the same
+    // plan loses badly (backward 12.3-12.5 -> 15.9 ms) and keeps 16 values per thread (profiles/r04_variant_cols_r32.txt)
+    if (d.n == 1024 && d.tr_dir == 1 && d.mode == MODE_C2C && !d.tw_hi && !d.in_lgp && !d.out_lgp && variant != 17 && variant != 9)
+      return launch_pow2_one<double, 1024, 32, 16, true, true, 2, 16, MODE_C2C, false, 32, 32>(d, in, out, s);
     if (variant != 9) {
       switch (d.n) {
         case 64: return P64(64, 8, 16, true, 1, 8, 8);
