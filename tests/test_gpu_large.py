@@ -269,3 +269,86 @@ def test_multi_rank_baseline_configs_at_full_size_on_thread_ranks(name, P, n, gr
                 seen[s2:s2 + piece.shape[0]] = True
         assert seen.all()
         assert np.abs(got - want).max() <= 2e-10 * np.abs(want).max(), (name, k0, k1, np.abs(got - want).max() / np.abs(want).max())
+
+
+def test_c5_at_full_size_on_thread_ranks():
+    """BASELINE config C5 whole: 2048^3 real fp32 -> r2c on 8 thread-ranks, grid (4,2,1), the Hermitian axis split 513 | 512
+    (uneven exchange, pencil.py:5-9).  Staged wire (device copies between thread-ranks).  Geometry against the reference's
+    (tests/golden/geometry.npz), Parseval over the half spectrum, round trip, four lines against the long-double DFT."""
+    import torch
+    from tests import cases
+    from tests.test_gpu_c5 import _c_dft
+    from mpi4py_fft_amd import PFFT, newDistArray, _lib
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    _lib.lib().gfft_scratch_release()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 260 * 2 ** 30:
+        pytest.skip('needs ~260 GiB of HBM, %d free' % (free >> 30))
+    n, P = 2048, 8
+    shape = (n, n, n)
+    lines = [(3, 5), (n - 1, n - 1), (n // 2 + 7, n // 4 + 3), (17, 0)]
+
+    def body(comm):
+        r = comm.Get_rank()
+        fft = PFFT(comm, shape, dtype='f', wire='torch', exchange='direct')
+        pin, pout = fft.pencil
+        geo = dict(dims=[c.Get_size() for c in fft.subcomm], in_shape=tuple(pin.subshape), in_start=tuple(pin.substart),
+                   mid_shape=tuple(fft.transfer[0].subshapeB), out_shape=tuple(pout.subshape), out_start=tuple(pout.substart))
+        u = fft.forward.input_array
+        g = torch.Generator(device='cuda').manual_seed(977 + r)
+        for i in range(0, u.tensor.shape[0], 16):
+            u.tensor[i:i + 16].copy_(torch.randn(u.tensor[i:i + 16].shape, generator=g, device='cuda', dtype=torch.float32))
+        e_phys = sum(float((u.tensor[i:i + 64].double() ** 2).sum().item()) for i in range(0, u.tensor.shape[0], 64))
+        parts = []
+        for k0, k1 in lines:
+            acc = torch.zeros(n, device='cuda', dtype=torch.complex128)
+            i1 = torch.arange(pin.substart[1], pin.substart[1] + pin.subshape[1], device='cuda', dtype=torch.float64)
+            w1 = torch.polar(torch.ones_like(i1), -2 * np.pi * ((k1 * i1) % n) / n)
+            for a in range(0, pin.subshape[0], 16):
+                i0 = torch.arange(pin.substart[0] + a, pin.substart[0] + a + 16, device='cuda', dtype=torch.float64)
+                w0 = torch.polar(torch.ones_like(i0), -2 * np.pi * ((k0 * i0) % n) / n)
+                acc += torch.einsum('a,b,abc->c', w0, w1, u.tensor[a:a + 16].to(torch.complex128))
+            parts.append(acc.cpu().numpy())
+        keep = u.tensor[:8].clone()                       # a slab of the input for the round-trip check (the planned input may be clobbered)
+        uh = fft.forward().tensor
+        wgt = torch.full((pout.subshape[2],), 2.0, device='cuda', dtype=torch.float64)
+        k2 = torch.arange(pout.substart[2], pout.substart[2] + pout.subshape[2], device='cuda')
+        wgt[(k2 == 0) | (k2 == n // 2)] = 1.0
+        e_spec = sum(float(((torch.view_as_real(uh[i:i + 64]).double() ** 2).sum(-1) * wgt).sum().item()) for i in range(0, uh.shape[0], 64))
+        pieces = []
+        for k0, k1 in lines:
+            j1 = k1 - pout.substart[1]
+            pieces.append((pout.substart[2], uh[k0, j1].cpu().numpy()) if 0 <= j1 < pout.subshape[1] else None)
+        back = fft.backward().tensor
+        num = float(((back[:8].double() - keep.double()) ** 2).sum().item())
+        den = float((keep.double() ** 2).sum().item())
+        fft.destroy()
+        return geo, e_phys, e_spec, num, den, parts, pieces
+
+    res = cases.run_ranks(P, body)
+    gold = cases.load('geometry')['C5_P8']
+    for r, (geo, *_rest) in enumerate(res):
+        assert list(gold[r][8]) == geo['dims']
+        assert tuple(gold[r][0]) == geo['in_shape'] and tuple(gold[r][1]) == geo['in_start']
+        assert tuple(gold[r][4]) == geo['mid_shape']
+        assert tuple(gold[r][6]) == geo['out_shape'] and tuple(gold[r][7]) == geo['out_start']
+    N = float(n) ** 3
+    e_phys, e_spec = sum(x[1] for x in res), sum(x[2] for x in res)
+    assert abs(e_phys / N - e_spec) <= 1e-5 * e_phys / N, (e_phys / N, e_spec)
+    rt = np.sqrt(sum(x[3] for x in res) / sum(x[4] for x in res))
+    assert rt <= 1e-4 and rt < 5e-6, rt
+    dft = _c_dft()
+    for li, (k0, k1) in enumerate(lines):
+        y = sum(x[5][li] for x in res)
+        want = dft(y, -1, n, 'D')[:n // 2 + 1] / N
+        got = np.zeros(n // 2 + 1, dtype='D')
+        seen = np.zeros(n // 2 + 1, dtype=bool)
+        for x in res:
+            if x[6][li] is not None:
+                s2, piece = x[6][li]
+                got[s2:s2 + piece.shape[0]] = piece
+                seen[s2:s2 + piece.shape[0]] = True
+        assert seen.all()
+        assert np.abs(got - want).max() <= 2e-4 * np.abs(want).max(), (k0, k1, np.abs(got - want).max() / np.abs(want).max())
