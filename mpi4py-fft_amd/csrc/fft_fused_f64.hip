@@ -95,7 +95,8 @@ bool fused2_supported_f64(int kind, int variant, int n_a, int n_b) {
 #endif
   // (n = 512: measured for the 3-D schedule's pair only -- 512^3 per step 4.82 -> 4.27 ms with 24 planes of 4 MiB ahead,
   // 5.34 ms with 16: profiles/r04_ab_fuse2_n512.txt)
-  if (variant == 1 && n_a == 512) return g_fuse2_n512 != 0 && kind == FUSED_COLS_ROWS;
+  // (... and the batched 2-D kind, [rows -> strided] on contiguous planes: (256,512,512) axes (1,2) 0.78 -> 0.69 ms, (512,512,512) 1.57 -> 1.34 ms)
+  if (variant == 1 && n_a == 512) return g_fuse2_n512 != 0 && (kind == FUSED_COLS_ROWS || kind == FUSED_PLANES_2D);
   return (variant == 1 || variant == 3) && n_a == 1024;
 }
 int g_fuse2_n512 = 1;

@@ -392,3 +392,22 @@ def test_fused_pairs_of_real_fp32_transforms(shape):
         b.destroy()
     assert np.abs(res[0][0] - res[1][0]).max() <= 1e-5 * np.abs(ref).max()
     assert np.abs(res[0][1] - res[1][1]).max() <= 1e-5 * np.abs(x).max()
+
+
+def test_fused_batched_2d_transform_at_n_512():
+    """fftn over the last two axes at n1 = n2 = 512 (the leading stage of the slab-decomposed C3 with collapse=True):
+    [rows -> columns] plane by plane on the n = 512 kernels, planes of 4 MiB."""
+    from mpi4py_fft_amd import _lib
+    shape = (96, 512, 512)
+    rng = np.random.default_rng(43)
+    x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    ref = np.fft.fftn(x, axes=(1, 2))
+    a, f, b = _plans(shape, (1, 2), 1, 0, 0, 126)
+    assert 'fused pair (2-D planes: rows -> strided)' in _lib.engine().plan_describe(f._plan)
+    a[...] = x
+    got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
+    assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max()
+    back = np.asarray(b.execute_scaled(f.output_array, b.output_array, 1.0 / (512 * 512)))
+    assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
+    f.destroy()
+    b.destroy()
