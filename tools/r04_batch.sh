@@ -1,5 +1,12 @@
-mkdir -p gpurun_out/r04t
-(timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > gpurun_out/r04t/gputests.txt
-cat gpurun_out/r04t/gputests.txt
-for v in 17 0 15 17 0 15; do GFFT_VARIANT_COLS=$v timeout 300 python tools/variant_cols_probe.py 2>&1 | grep -v amdgpu; GFFT_VARIANT_COLS=$v timeout 300 python tools/survey.py 2>&1 | grep "C4@8"; done > gpurun_out/r04t/variant_cols.txt 2>&1
-cat gpurun_out/r04t/variant_cols.txt
+mkdir -p gpurun_out/r04v
+(timeout 2700 python -m pytest tests -m gpu -x -q 2>&1 | tail -6) > gpurun_out/r04v/gputests.txt
+cat gpurun_out/r04v/gputests.txt
+bash tools/prof.sh r04_bench python bench.py --steps 6 --warmup 2 --no-cpu > gpurun_out/r04v/prof.log 2>&1
+timeout 600 python bench.py > gpurun_out/r04v/bench_plain.json 2> gpurun_out/r04v/bench_plain.err
+python - <<'PY'
+import json
+d = json.load(open('gpurun_out/r04v/bench_plain.json'))
+print(d['ms_per_step'], d['value'], json.dumps(d['roofline'])[:1500])
+PY
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+timeout 900 python tools/survey.py > gpurun_out/r04v/survey.txt 2>&1
