@@ -127,6 +127,8 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
           // natural rows near 3.50 (3.53) / far 4.94 (4.15) -- ahead by 2-4 % only where both sides are
           // pitched, behind by 19 % on natural far strides: still not the default.
           case 2: return P32F(1024, 32, 16, true, true, 4, 8, 16, 16, 4);
+          // (R4: non-temporal loads and stores on either form, as the fp64 strided default has them: 1024^3 c64 per step 19.61 ->
+          // 19.57 ms on variant 2, 20.43 on the wide tile; 1024^3 r2c f32 11.65 -> 12.12 / 12.87 ms -- not adopted)
 #ifdef GFFT_VARIANTS
           // R4, measured and NOT kept: 64 values per thread, radices 64 x 16 = ONE exchange, 512 threads on 32 columns
           // (256-byte segments) -- what paid in fp64 (32 values, fft_pow2_f64.hip) does not here: 64 complex64 are 128 VGPRs of
