@@ -72,9 +72,13 @@ int gfft_device_name(int device, char *buf, size_t len);
 /* tunables consulted when a plan is created: "grid_cap", "variant_rows", "variant_cols",
  * "force_generic", "fused3", "profile" (also readable from the environment as GFFT_<UPPERCASE NAME>);
  * "fuse2" (1: pass pairs as one persistent launch through the Infinity Cache where a pair exists and pays,
- * 0: stand-alone passes), with "fuse2_ring" / "fuse2_lag" (slots of the hand-off ring / planes the producer
- * runs ahead; 0 = auto: 12 / 6, launches of fewer than 24 planes 8 / 4), "fuse2_kinds" (bit mask of pair kinds) and the A/B switches "fuse2_wlayout",
- * "fuse2_group", "fuse2_defer" (DESIGN.md section 4.7); GFFT_FUSE2_DEBUG=1 prints a fused launch's counters */
+ * 0: stand-alone passes; 3: the round-3 kernel set, for A/B), with "fuse2_ring" / "fuse2_lag" (slots of the hand-off ring /
+ * planes the producer runs ahead; 0 = auto: about 96 MiB of lead and twice that of ring -- 12 / 6 planes of 16 MiB, 24 / 12 of
+ * 8 MiB, 48 / 24 of 4 MiB --, launches with too few planes for that stay unfused), "fuse2_kinds" (bit mask of pair kinds:
+ * 2 strided->rows, 4 / 16 four-step, 8 batched 2-D, 32 r2c rows->strided, 64 strided->c2r rows), "fuse2_f32" (1: complex64
+ * pairs, 2: real fp32 pairs too), "fuse2_n512" (the n = 512 pairs), "fuse2_wait_ms" (wall-clock limit of a wait inside a fused
+ * launch before the launch voids itself, gfft_async_error below; default 2000) and the A/B switches "fuse2_wlayout",
+ * "fuse2_group", "fuse2_defer" (DESIGN.md sections 4.7, 4.8); GFFT_FUSE2_DEBUG=1 prints a fused launch's counters */
 int gfft_set_option(const char *key, int value);
 
 /* ---- serial multi-axis transform plan ------------------------------------------------
