@@ -411,3 +411,54 @@ def test_fused_batched_2d_transform_at_n_512():
     assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
     f.destroy()
     b.destroy()
+
+
+def test_recovery_of_the_real_pairs_and_the_2d_pair():
+    """The stand-alone form a voided launch falls back to exists for every pair kind: r2c planes, c2r, batched 2-D."""
+    import torch
+    from mpi4py_fft_amd import _lib, fftw, zeros
+    rng = np.random.default_rng(51)
+    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=126)
+    # r2c on (40, 1024, 1024), c2r on (1024, 40, 1024)
+    for shape, forward in (((40, 1024, 1024), True), ((1024, 40, 1024), False)):
+        x = rng.standard_normal(shape)
+        ref = np.fft.rfftn(x)
+        if forward:
+            a = zeros(shape, 'd')
+            p = fftw.rfftn(a, axes=(0, 1, 2))
+            a[...] = x
+            want, scale = ref, 1.0
+        else:
+            a = zeros(ref.shape, 'D')
+            p = fftw.irfftn(a, s=shape, axes=(0, 1, 2))
+            a[...] = ref
+            want, scale = x, 1.0 / x.size
+        assert 'fused pair' in _lib.engine().plan_describe(p._plan)
+        _opts(fuse2_wait_ms=0)
+        p.execute_scaled(a, p.output_array, scale)
+        torch.cuda.synchronize()
+        _opts(fuse2_wait_ms=2000)
+        with pytest.raises(RuntimeError, match='gave up'):
+            _lib.check_async()
+        assert 'two stand-alone passes' in _lib.engine().plan_describe(p._plan)
+        if not forward:
+            a[...] = ref                      # (multi-axis c2r preserves its input; refreshed all the same)
+        got = np.asarray(p.execute_scaled(a, p.output_array, scale))
+        assert np.abs(got - want).max() <= 2e-10 * np.abs(want).max()
+        p.destroy()
+    shape = (24, 1024, 1024)
+    x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    a, f, b = _plans(shape, (1, 2), 1, 0, 0, 126)
+    assert 'fused pair (2-D planes' in _lib.engine().plan_describe(f._plan)
+    a[...] = x
+    _opts(fuse2_wait_ms=0)
+    f.execute_scaled(a, f.output_array, 1.0)
+    torch.cuda.synchronize()
+    _opts(fuse2_wait_ms=2000)
+    with pytest.raises(RuntimeError, match='gave up'):
+        _lib.check_async()
+    got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
+    ref = np.fft.fftn(x, axes=(1, 2))
+    assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max()
+    f.destroy()
+    b.destroy()
