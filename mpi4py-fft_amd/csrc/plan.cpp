@@ -1372,6 +1372,13 @@ int plan_fused3(gfft_plan_s *pl) {
   // schedules (1024^3 c128 per step 32.85 -> 32.51 ms) and on natural-stride stage arrays, and lose 1.5-3 % here
   // (1024^3 r2c f64 per step 18.76 -> 19.03 / 19.31 ms, profiles/r04_real_pairs.txt)
   if (prec == GFFT_F64 && real && pl->variant_cols == 0) pl->variant_cols = 17;
+  // XCD-contiguous tile order for the stand-alone passes of power-of-two schedules (each XCD walks its own eighth of the
+  // tiles: neighbouring column chunks of the pitched workspace rows share an L2).  Neutral with the kernels of rounds 1-3
+  // (+-0.2 %); with the 512- / 256-thread kernels of round 4, same arrays, plans alternating (profiles/r04_ab_swizzle.txt):
+  // 1024^3 c128 per step 30.76 -> 30.52 ms and 32.23 -> 31.50 ms on two boxes (the pass 5.83 -> 5.69 ms), 1024^3 c64 19.42 ->
+  // 19.00, 512^3 c128 4.17 -> 4.07, 1024^3 r2c f64 18.65 -> 18.48; level for real fp32 and 512^3 c64, +0.8 % at 768^3
+  // (3^b 2^k kernels: left on automatic).  On natural-stride stage arrays (C4 on 8 GPUs) it LOSES 2-8 %: only here.
+  if (pl->xcd_swizzle < 0 && is_pow2(n0) && is_pow2(n1) && is_pow2(n2) && !(real && prec == GFFT_F32)) pl->xcd_swizzle = 1;
   // Workgroups per launch.  Each walks tiles block, block + grid, ...; more, shorter walks balance the
   // tail better, too many lose the overlap of one tile's stores with the next one's loads.  Clean A/B
   // on fixed caller arrays (tools/ab_option_probe.py grid_cap ...), fwd + bwd per step: 1024^3 c128
