@@ -8,6 +8,7 @@
 // Rows: 16 values per thread, a row inside one wave (exchanges without barriers); strided: 32 values per thread, one
 // exchange; 512 threads both, one workgroup per CU.
 #include "fft_fused_impl.h"
+#include <cstdlib>
 
 namespace gfft {
 
@@ -15,6 +16,9 @@ namespace gfft {
 typedef PassCfg<double, 512, 16, 16, false, true, 1 | 2048 | 8192, MODE_R2C_H, false, 16, 8, 4> R2CRows512ToRing;      // 1024 reals per row
 typedef PassCfg<double, 1024, 16, 8, false, true, 1 | 2048 | 8192, MODE_R2C_H, false, 16, 16, 4> R2CRows1024ToRing;    // 2048 reals per row
 typedef PassCfg<double, 512, 16, 16, false, true, 2 | 4096 | 8192, MODE_C2R_H, false, 16, 8, 4> C2RRows512FromRing;
+#ifdef GFFT_VARIANTS
+typedef PassCfg<double, 1024, 16, 8, false, true, 2 | 4096 | 8192, MODE_C2R_H, false, 16, 16, 4> C2RRows1024FromRing;     // (loses: see below)
+#endif
 typedef PassCfg<double, 1024, 32, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 32, 32> Cols1024ToRing;
 typedef PassCfg<double, 1024, 32, 16, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 32, 32> Cols1024FromRing;
 
@@ -22,6 +26,9 @@ bool fused2_real_supported_f64(int kind, int n_a, int n_b) {
   if (kind == FUSED_R2C_PLANES) return (n_a == 512 || n_a == 1024) && n_b == 1024;
   // (c2r rows of 2048 reals -- N = 1024 -- were built and measured: (1024,1024,2048) backward 21.4 -> 28.1 ms, the pair 21.2 ms
   // against 6.8 + 6.7 for its two passes; the r2c pair of the same shape gains, 13.4 -> 11.4 ms: profiles/r04_real_pairs.txt)
+#ifdef GFFT_VARIANTS
+  if (kind == FUSED_COLS_C2R && n_a == 1024 && n_b == 1024) return getenv("GFFT_C2R_2048") != nullptr;
+#endif
   if (kind == FUSED_COLS_C2R) return n_a == 1024 && n_b == 512;
   return false;
 }
@@ -34,6 +41,9 @@ int fused2_real_tiles_f64(int kind, const PassDesc &dA, const PassDesc &dB, int 
   }
   if (kind == FUSED_COLS_C2R) {
     *ta = (int)Cols1024ToRing::ntiles(dA);
+#ifdef GFFT_VARIANTS
+    if (dB.n == 1024) { *tb = (int)C2RRows1024FromRing::ntiles(dB); return 0; }
+#endif
     *tb = (int)C2RRows512FromRing::ntiles(dB);
     return 0;
   }
@@ -47,6 +57,9 @@ hipError_t launch_fused2_real_f64(int kind, const PassDesc &dA, const PassDesc &
     return launch_fused2<R2CRows1024ToRing, Cols1024FromRing>(dA, dB, dev, f, in, ring, out, s);
   }
   if (kind == FUSED_COLS_C2R) {
+#ifdef GFFT_VARIANTS
+    if (dB.n == 1024) return launch_fused2<Cols1024ToRing, C2RRows1024FromRing>(dA, dB, dev, f, in, ring, out, s);
+#endif
     return launch_fused2<Cols1024ToRing, C2RRows512FromRing>(dA, dB, dev, f, in, ring, out, s);
   }
   return hipErrorInvalidValue;

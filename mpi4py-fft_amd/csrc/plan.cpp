@@ -1123,7 +1123,7 @@ int plan_fused3(gfft_plan_s *pl) {
   };
   const int64_t esz = 2 * prec;
   // workspace row pitch: rows start on 128-B lines; +256 B when the pitch would be a multiple of 2 KiB
-  const int64_t seg = 128 / esz;
+  const int64_t seg = 128 / esz;      // (R4: rows in whole 256-byte pieces instead measured +1 % on the real fp64 schedule: more padding columns, nothing gained)
   int64_t P = (nc + seg - 1) / seg * seg;
   if ((P * esz) % 2048 == 0) P += 256 / esz;
   need(pl, BUF_WS, (size_t)(n0 * n1 * P * esz));

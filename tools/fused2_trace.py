@@ -16,7 +16,7 @@ import numpy as np, torch
 from mpi4py_fft_amd import PFFT, comm, _lib, fftw, zeros
 _lib.LIBPATH = os.path.join(os.path.dirname(_lib.LIBPATH), 'libgfft_trace.so')
 if 'r2c' in sys.argv[1:] or 'c2r' in sys.argv[1:]:
-    fft = PFFT(comm.COMM_SELF, (1024,) * 3, dtype='d')
+    fft = PFFT(comm.COMM_SELF, (1024, 1024, 2048) if 'wide' in sys.argv[1:] else (1024,) * 3, dtype='d')
     fft.forward.input_array.tensor.normal_()
     fft.forward()
     run = (lambda: fft.forward()) if 'r2c' in sys.argv[1:] else (lambda: fft.backward())
