@@ -1388,7 +1388,7 @@ int plan_fused3(gfft_plan_s *pl) {
   // schedules take 16384, real ones 8192 (1024^3 r2c f64 20.60 -> 20.48, f32 11.09 -> 11.04 ms; 2048 and
   // 1024 lose 1-2 % each), stand-alone strided passes keep 4096 (GFFT_GRID_CAP overrides them all).
   if (opts().grid_cap <= 0)
-    for (Pass &p : pl->passes) p.d.grid_cap = real ? 8192 : 32768;     // (R4, XCD-contiguous order, 32-value kernels: 1024^3 c128 per step 32.23 (4096) / 31.97 (16384) / 31.81 (32768) / 32.07 ms (65536))
+    for (Pass &p : pl->passes) p.d.grid_cap = real ? 8192 : ((is_pow2(n0) && is_pow2(n1) && is_pow2(n2)) ? 32768 : 16384);     // (R4, XCD-contiguous order, 32-value kernels: 1024^3 c128 per step 32.23 (4096) / 31.97 (16384) / 31.81 (32768) / 32.07 ms (65536))
   return GFFT_OK;
 }
 
