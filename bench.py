@@ -135,7 +135,22 @@ class _Fftw:
         ranks = (self.iodim * len(axes))(*[self.iodim(sizes[a], strides[a], strides[a]) for a in axes])
         rest = [i for i in range(nd) if i not in axes]
         dims = (self.iodim * max(1, len(rest)))(*[self.iodim(sizes[i], strides[i], strides[i]) for i in rest])
-        return self.lib.fftw_plan_guru_dft(len(axes), ranks, len(rest), dims, arr_in.ctypes.data,
+        p = self.lib.fftw_plan_guru_dft(len(axes), ranks, len(rest), dims, arr_in.ctypes.data,
+                                        arr_out.ctypes.data, sign, flags)
+        if p or len(rest) < 2:
+            return p
+        # a library that plans ONE batch dim (MKL's interface): adjacent batch dims that tile memory without a gap are one
+        # dim (n_i n_j, stride_j) -- the canonical form FFTW's own planner reduces them to
+        merged = [[sizes[rest[0]], strides[rest[0]]]]
+        for i in rest[1:]:
+            if merged[-1][1] == sizes[i] * strides[i]:
+                merged[-1] = [merged[-1][0] * sizes[i], strides[i]]
+            else:
+                merged.append([sizes[i], strides[i]])
+        if len(merged) == len(rest):
+            return p
+        dims = (self.iodim * len(merged))(*[self.iodim(n, st, st) for n, st in merged])
+        return self.lib.fftw_plan_guru_dft(len(axes), ranks, len(merged), dims, arr_in.ctypes.data,
                                            arr_out.ctypes.data, sign, flags)
 
 
@@ -166,15 +181,32 @@ def _cpu_fftw(cores, budget_s, F=None, clock=time.perf_counter, max_n=1024, hard
         v = np.empty(shape, dtype='D')
         t_plan = clock()
         form = 'per-axis plans (2, 1, 0)'
-        fwd = [F.plan(u, v, [2], -1, flags), F.plan(v, v, [1], -1, flags), F.plan(v, v, [0], -1, flags)]
-        bwd = [F.plan(v, v, [0], 1, flags), F.plan(v, v, [1], 1, flags), F.plan(v, u, [2], 1, flags)]
-        if not all(fwd + bwd):
-            for p in fwd + bwd:
+        slab = n * n * 16
+
+        def stage(a, b, axis, sign):
+            """[(plan, byte offset)]: one guru plan for the axis as fftw_planxfftn.c:20-76 builds it (every other axis a
+            batch dim); where the library plans ONE batch dim only (MKL's interface returns NULL for two, i.e. for the
+            middle axis of a 3-D array) the outer batch dim becomes what it is inside FFTW too -- a loop: one plan for
+            a (n, n) slab, executed on each of the n slabs through the new-array interface."""
+            p = F.plan(a, b, [axis], sign, flags)
+            if p:
+                return [(p, 0)]
+            if axis == 1:
+                p = F.plan(a[0], b[0], [0], sign, flags)
                 if p:
+                    return [(p, i * slab) for i in range(n)]
+            return None
+        fwd = [stage(u, v, 2, -1), stage(v, v, 1, -1), stage(v, v, 0, -1)]
+        bwd = [stage(v, v, 0, 1), stage(v, v, 1, 1), stage(v, u, 2, 1)]
+        if any(len(st or []) > 1 for st in fwd + bwd):
+            form += '; axis 1 as a loop over the %d slabs of one 2-D plan (this library plans one batch dimension)' % n
+        if not all(fwd + bwd):
+            for st in fwd + bwd:
+                for p, _ in (st or [])[:1]:
                     F.lib.fftw_destroy_plan(p)
             form = 'one 3-D plan (collapse=True)'
-            fwd, bwd = [F.plan(u, v, [0, 1, 2], -1, flags)], [F.plan(v, u, [0, 1, 2], 1, flags)]
-            if not all(fwd + bwd):
+            fwd, bwd = [[(F.plan(u, v, [0, 1, 2], -1, flags), 0)]], [[(F.plan(v, u, [0, 1, 2], 1, flags), 0)]]
+            if not all(st[0][0] for st in fwd + bwd):
                 raise RuntimeError('guru planner returned NULL')
         t_plan = clock() - t_plan
         # synthetic input: a random complex plane times a random complex factor per slab (filling
@@ -190,12 +222,14 @@ def _cpu_fftw(cores, budget_s, F=None, clock=time.perf_counter, max_n=1024, hard
         def fwd_bwd():
             t0 = clock()
             srcs = [u] + [v] * (len(fwd) - 1)
-            for p, a in zip(fwd, srcs):
-                ex(p, a.ctypes.data, v.ctypes.data)
+            for st, a in zip(fwd, srcs):
+                for p, off in st:
+                    ex(p, a.ctypes.data + off, v.ctypes.data + off)
             np.multiply(v, 1.0 / u.size, out=v)         # libfft.py:412-413
             dsts = [v] * (len(bwd) - 1) + [u]
-            for p, b in zip(bwd, dsts):
-                ex(p, v.ctypes.data, b.ctypes.data)
+            for st, b in zip(bwd, dsts):
+                for p, off in st:
+                    ex(p, v.ctypes.data + off, b.ctypes.data + off)
             return clock() - t0
         warm = fwd_bwd()                                # first touch of v, thread pool spin-up
         times = []
@@ -203,8 +237,8 @@ def _cpu_fftw(cores, budget_s, F=None, clock=time.perf_counter, max_n=1024, hard
             times.append(fwd_bwd())
         spent += warm + sum(times)
         err = float(np.linalg.norm(u[:4] - u0) / np.linalg.norm(u0))
-        for p in fwd + bwd:
-            F.lib.fftw_destroy_plan(p)
+        for st in fwd + bwd:
+            F.lib.fftw_destroy_plan(st[0][0])
         dt = min(times)
         best = dict(value=round(2 * flops_c2c(shape) / dt / 1e9, 2), unit='GFLOP/s', cores=F.threads, kind='port',
                     library='%s (%s)' % (F.version, os.path.basename(F.path)),
@@ -271,9 +305,23 @@ def _cpu_pocketfft(cores, budget_s):
     return best
 
 
-def cpu_baseline(cores, budget_s=25.0):
+def cpu_budget():
+    """Seconds of timed CPU executions the baseline leg may take: enough for the headline's own 1024^3 sample
+    (the reference times the array it transforms, tests/test_speed.py:15-20) when the
+    host can hold it -- two 16 GiB arrays plus slack -- else the 512^3 ladder of earlier rounds."""
+    try:
+        with open('/proc/meminfo') as f:
+            avail = int(re.search(r'MemAvailable:\s+(\d+)', f.read()).group(1)) * 1024
+    except Exception:
+        return 25.0
+    return 300.0 if avail >= (48 << 30) else 25.0
+
+
+def cpu_baseline(cores, budget_s=None):
     """FFTW with all threads when a libfftw3 can be loaded (none ships in
     this image; MKL's FFTW3 interface does), else pocketfft; the line says which."""
+    if budget_s is None:
+        budget_s = cpu_budget()
     try:
         return _cpu_fftw(cores, budget_s)
     except Exception as e:
@@ -460,6 +508,8 @@ def main():
     ap.add_argument('--no-slab', action='store_true', help='skip the slab-grid extra at N > 1')
     ap.add_argument('--no-tune', action='store_true', help='skip the measured route choice at N > 1')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--cpu-budget', type=float, default=None,
+                    help='seconds of timed CPU executions for the cpu_baseline leg (default: 300 when the host can hold the 1024^3 sample, else 25)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
@@ -499,10 +549,41 @@ def test_hook(guard, rank):
         raise RuntimeError('injected failure in phase %r' % guard.phase)
 
 
+def misroute(fft):
+    """FAULT INJECTION for the tests of the admission gates (tests/test_bench_launcher.py, tests/gloo_worker.py;
+    bench.py applies it only under GFFT_BENCH_TEST_MISROUTE=<plan label>): on this rank, swap where two relayed
+    pieces of one block land (forward schedule of a relayed Transfer) and, mirrored, where they are fetched from on
+    the way back -- the round trip still passes, every forward value and position is wrong.  True when a pair of
+    pieces was found on this rank."""
+    for t in fft.transfer:
+        if not getattr(t, '_relay', None) or t.exchange != 'relay':
+            continue
+        _, fwd, bwd = t._relay
+        cand = [(k, e) for k, e in enumerate(fwd.r2_recv) if e[0] == 'recv']
+        back = bwd.r1_send + bwd.r2_send
+        for x in range(len(cand)):
+            for y in range(x + 1, len(cand)):
+                (kx, ex), (ky, ey) = cand[x], cand[y]
+                if ex[2] != ey[2] or ex[1] == ey[1]:
+                    continue
+                sx = [k for k, e in enumerate(back) if e[0] == 'send' and e[1] == ex[1] and e[2] == ex[2]]
+                sy = [k for k, e in enumerate(back) if e[0] == 'send' and e[1] == ey[1] and e[2] == ey[2]]
+                if len(sx) != 1 or len(sy) != 1:
+                    continue
+                fwd.r2_recv[kx] = (ex[0], ey[1], ex[2], ex[3])
+                fwd.r2_recv[ky] = (ey[0], ex[1], ey[2], ey[3])
+                for k, off in ((sx[0], ey[1]), (sy[0], ex[1])):
+                    lst, kk = (bwd.r1_send, k) if k < len(bwd.r1_send) else (bwd.r2_send, k - len(bwd.r1_send))
+                    b, _, n, peer = lst[kk]
+                    lst[kk] = (b, off, n, peer)
+                return True
+    return False
+
+
 def run(args, guard, state):
     import numpy as np
     import torch
-    from mpi4py_fft_amd import PFFT, comm, _lib
+    from mpi4py_fft_amd import PFFT, comm, _lib, selftest
     world = comm.init_distributed()
     rank, size = world.Get_rank(), world.Get_size()
     assert size == args.gpus, 'launched with %d ranks but --gpus %d' % (size, args.gpus)
@@ -530,14 +611,17 @@ def run(args, guard, state):
         sl.copy_(torch.randn(sl.shape, generator=g, device=dev, dtype=torch.float64))
     u0 = u.tensor.clone()
 
-    def round_trip_error(f):
+    def round_trip_error(f, u0=u0):
         """north-star parity gate: forward -> backward on the planned arrays, relative l2 error"""
         f.forward()
         f.backward()
         sync()
         t = f.forward.input_array.tensor
-        num = float((torch.view_as_real(t) - torch.view_as_real(u0)).pow(2).sum().item())
-        den = float(torch.view_as_real(u0).pow(2).sum().item())
+        num = den = 0.0
+        for i in range(0, t.shape[0], 64):          # (slab by slab: no array-sized temporaries)
+            a, b = torch.view_as_real(t[i:i + 64]), torch.view_as_real(u0[i:i + 64])
+            num += float((a - b).pow(2).sum().item())
+            den += float(b.pow(2).sum().item())
         sums = world.allgather_obj((num, den))
         return float(np.sqrt(sum(s[0] for s in sums) / sum(s[1] for s in sums)))
 
@@ -545,8 +629,51 @@ def run(args, guard, state):
         fft.forward()
         fft.backward()
 
-    rt_err = round_trip_error(fft)
-    assert rt_err <= 1e-10, 'round-trip rel err %.3e exceeds 1e-10' % rt_err
+    def admit(f, reference_print=None, u0=u0):
+        """What admits a plan to timing (the reference's own checks are positional and
+        by value: tests/test_pencil.py:26-56, tests/test_mpifft.py:17):
+          1. every redistribution of the plan, on the wire and route about to be timed, carries global linear
+             indices to exactly the right places, forward and backward, bit for bit;
+          2. six lines of the forward equal the DFT by definition (float64 sums over the distributed input on
+             the device) within 2e-10 of the largest reference value;
+          3. for an alternative plan of the same transform: its forward output is, word for word, the one of
+             the plan already admitted (same kernels, same arithmetic);
+          4. the forward -> backward round trip returns the input within 1e-10.
+        Returns (report, reason): reason is None when the plan may be timed.  Collective."""
+        t0 = time.perf_counter()
+        rep = {}
+        x = selftest.exchange_check(f, world)
+        rep['exchange_check'] = x['result']
+        rep['exchange_hops'] = x['hops'] + x.get('pipeline_chunk_exchanges', 0)
+        if x['result'] != 'bit-exact':
+            rep['exchange_failures'] = x['failures']
+            return rep, 'exchange check failed: ' + x['failures'][0]
+        f.forward.input_array.tensor.copy_(u0)
+        out_t = f.forward().tensor
+        sync()
+        rep['forward_rel_err'] = selftest.forward_gate(f, world, u0, out_t)
+        if not rep['forward_rel_err'] <= 2e-10:
+            return rep, 'forward differs from the DFT by definition: rel err %.3e > 2e-10' % rep['forward_rel_err']
+        prints = world.allgather_obj(selftest.fingerprint(out_t))
+        if reference_print is not None:
+            rep['forward_bit_identical_to_headline'] = prints == reference_print
+            if prints != reference_print:
+                bad = [r for r in range(size) if prints[r] != reference_print[r]]
+                return rep, 'forward output differs from the admitted plan on rank(s) %s' % bad
+        rep['_print'] = prints
+        f.forward.input_array.tensor.copy_(u0)
+        rep['round_trip_rel_err'] = round_trip_error(f, u0)
+        if not rep['round_trip_rel_err'] <= 1e-10:
+            return rep, 'round-trip rel err %.3e exceeds 1e-10' % rep['round_trip_rel_err']
+        rep['gate_seconds'] = round(time.perf_counter() - t0, 3)
+        if dev == 'cuda':
+            torch.cuda.empty_cache()
+        return rep, None
+
+    gate, why_not = admit(fft)
+    assert why_not is None, why_not
+    headline_print = gate.pop('_print')
+    rt_err = gate['round_trip_rel_err']
 
     for _ in range(args.warmup):
         one_step()
@@ -668,13 +795,20 @@ def run(args, guard, state):
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'PFFT 3D c2c %d^3 complex128 forward+backward per step' % n,
                        'grid': grid, 'exchange': exchange_report(f),
-                       'round_trip_rel_err': err},
+                       'round_trip_rel_err': err['round_trip_rel_err'],
+                       'forward_rel_err': err['forward_rel_err'],
+                       'exchange_check': err['exchange_check'],
+                       'gates': dict({k: v for k, v in err.items() if not k.startswith('_')},
+                                     what='before timing: every Transfer of the plan on global linear indices, forward and '
+                                          'backward, bit-exact on the wire / route timed (tests/test_pencil.py:26-56); six lines of '
+                                          'the forward against the DFT by definition, float64 on the device, tol 2e-10 max|ref| '
+                                          '(BASELINE.md section 4); round trip tol 1e-10')},
             'whole_transform_hbm': whole,
         }
 
     out = None
     if rank == 0:
-        out = headline(fft, elapsed, rt_err)
+        out = headline(fft, elapsed, gate)
         out['roofline'] = roofline
         out['hbm_copy_ceiling'] = copy_ceiling
         if roofline and copy_ceiling and copy_ceiling.get('gbs'):
@@ -687,7 +821,7 @@ def run(args, guard, state):
         if not args.no_cpu and size == 1:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
             try:
-                out['cpu_baseline'] = cpu_baseline(cores)
+                out['cpu_baseline'] = cpu_baseline(cores, args.cpu_budget)
             except Exception as e:  # the baseline must never sink the GPU number
                 out['cpu_baseline'] = {'value': None, 'unit': 'GFLOP/s', 'cores': cores, 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
@@ -751,14 +885,24 @@ def run(args, guard, state):
                 info['pipeline'] = tuned.pipeline.describe()
             elif label.startswith('pipelined'):
                 info['skipped'] = 'transform does not qualify for the pipelined path'
-            tuned.forward.input_array.tensor.copy_(u0)
-            err2 = round_trip_error(tuned)
+            if os.environ.get('GFFT_BENCH_TEST_MISROUTE') == label:
+                info['test_misroute_applied'] = any(world.allgather_obj(misroute(tuned)))
             routes = [t.exchange for t in tuned.transfer if t.comm.Get_size() > 1]
-            info.update({'exchange': exchange_report(tuned), 'round_trip_rel_err': err2})
             differs = tuned.pipeline is not None or any(r != 'direct' for r in routes)
             if label == 'pipelined routed' and not any(e['route'] == 'relay' for e in info.get('pipeline', [])):
                 differs = False           # nothing to route on this grid: same plan as 'pipelined'
-            if differs and err2 <= 1e-10:
+            info['exchange'] = exchange_report(tuned)
+            # the same admission gates as the headline, on THIS plan's wire and route; a plan that fails one is
+            # reported with the failing rank / block and never timed
+            gate2, why_not = admit(tuned, headline_print)
+            gate2.pop('_print', None)
+            info.update(gate2)
+            if why_not is not None:
+                info['rejected'] = why_not
+            err2 = gate2.get('round_trip_rel_err', float('inf'))
+            if not differs:
+                info['not_timed'] = 'same plan as the headline on this grid'
+            if why_not is None and differs:
                 def tuned_step():
                     tuned.forward()
                     tuned.backward()
@@ -771,9 +915,9 @@ def run(args, guard, state):
                     if 'plain_route' not in out:
                         out['plain_route'] = {'ms_per_step': out['ms_per_step'], 'value': out['value'],
                                               'exchange': out['config']['exchange']}
-                    keep = {k: out[k] for k in out if k not in headline(tuned, el2, err2)}
+                    keep = {k: out[k] for k in out if k not in headline(tuned, el2, gate2)}
                     out.clear()
-                    out.update(headline(tuned, el2, err2))
+                    out.update(headline(tuned, el2, gate2))
                     out.update(keep)
                     out['config']['plan'] = label
                     if tuned.pipeline is not None:
@@ -802,18 +946,25 @@ def run(args, guard, state):
             slab = PFFT(world, shape, dtype='D', grid=(-1,), exchange='direct')
             torch.view_as_real(slab.forward.input_array.tensor).normal_()
             ksteps = max(1, min(args.steps, 5))
+            # (another grid: another input block per rank, so no bit comparison with the headline; the other gates apply)
+            su0 = slab.forward.input_array.tensor.clone()
+            sgate, why_not = admit(slab, None, su0)
+            sgate.pop('_print', None)
+            del su0
 
             def slab_step():
                 slab.forward()
                 slab.backward()
-            for _ in range(2):
-                slab_step()
-            sel = timed_steps(world, sync, slab_step, ksteps)
-            res = {'grid': [c.Get_size() for c in slab.subcomm], 'steps': ksteps,
-                   'ms_per_step': round(sel / ksteps * 1e3, 3),
-                   'gflops': round(flops / (sel / ksteps) / 1e9, 1)}
-            phase('slab grid stage breakdown')
-            res['stages_ms'] = {'forward': stages(slab.forward)}
+            res = dict(sgate, grid=[c.Get_size() for c in slab.subcomm], steps=ksteps)
+            if why_not is not None:
+                res['rejected'] = why_not            # reported, never timed
+            else:
+                for _ in range(2):
+                    slab_step()
+                sel = timed_steps(world, sync, slab_step, ksteps)
+                res.update(ms_per_step=round(sel / ksteps * 1e3, 3), gflops=round(flops / (sel / ksteps) / 1e9, 1))
+                phase('slab grid stage breakdown')
+                res['stages_ms'] = {'forward': stages(slab.forward)}
             if rank == 0:
                 out['slab_grid'] = res
             slab.destroy()

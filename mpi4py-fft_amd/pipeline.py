@@ -859,6 +859,89 @@ class Pipeline:
         return [dict(ranks=e['p'], free_axis=e.get('f'), chunks=e.get('K', 1),
                      route='relay' if e.get('relay') else 'direct', layout=getattr(self, 'layout', 'c-order')) for e in self.tplan]
 
+    def exchange_selftest(self):
+        """Every chunk of every exchange of this pipeline, both directions, on its own buffers, wire and
+        route, with the send buffers holding (sender, word index) tags: each rank must find, at the place
+        of every (chunk, peer) message, exactly the words that peer holds at ITS place for this rank --
+        and nothing anywhere else.  The positional check of the reference's exchange test
+        (tests/test_pencil.py:26-56) applied to the pipeline's chunk plan and relay schedule, which a
+        forward -> backward round trip cannot vouch for (the mirrored exchange undoes a misplaced
+        block).  Overwrites the exchange buffers.  Collective over the grid.
+        Returns {'hops': chunk exchanges run, 'failures': [text]} for THIS rank."""
+        import torch
+        compute = _streams()[0]
+        cs = self.comm_stream
+        cs_raw = cs.cuda_stream
+        L = len(self.fwd)
+        failures, hops = [], 0
+        for forward in (True, False):
+            for ti, t in enumerate(self.tplan):
+                if t['p'] == 1:
+                    continue
+                i = ti if forward else ti + 1                     # the sending stage
+                j = i + 1 if forward else i - 1
+                send_t = self.out_buf[i] if forward else self.in_buf[i]
+                recv_t = self.in_buf[j] if forward else self.out_buf[j]
+                snd, rcv = (t['A'], t['B']) if forward else (t['B'], t['A'])
+                K, p = t['K'], t['p']
+                comm = t['comm']
+                me = comm.Get_rank()
+                mytag = int(getattr(comm, '_ranks', list(range(p)))[me]) + 1
+                sb, rb = _bytes(send_t), _bytes(recv_t)
+                if send_t.data_ptr() == recv_t.data_ptr():
+                    failures.append('transfer %d: send and receive buffer are one array (not checkable)' % ti)
+                    continue
+                if sb.numel() % 8 or rb.numel() % 8 or any(n % 8 for n in list(snd['sizes']) + list(rcv['sizes'])):
+                    failures.append('transfer %d: message sizes are not whole 64-bit words (not checkable)' % ti)
+                    continue
+                sw, rw = sb.view(torch.int64), rb.view(torch.int64)
+                sw.copy_(torch.arange(sw.numel(), dtype=torch.int64, device=sw.device) + (mytag << 44))
+                rw.fill_(-1)
+                table = {c: (_places(snd, c), list(snd['sizes'])) for c in range(K)}
+                tables = comm.allgather_obj((mytag, table))
+                tag, pos = ('sf' if forward else 'sb'), 100 + ti
+                for c in range(K):
+                    self._exchange(tag, pos, c, t, send_t.data_ptr(), forward, i, compute, cs, cs_raw)
+                    hops += 1
+                for c in range(K):
+                    self._arrived(compute, tag, pos, c)
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+                want = torch.full_like(rw, -1)
+                bad = None
+                for c in range(K):
+                    rplace = _places(rcv, c)
+                    for peer in range(p):
+                        ptag, ptable = tables[peer]
+                        poff, psize = ptable[c][0][me], ptable[c][1][me]
+                        if psize != rcv['sizes'][peer] or poff % 8 or rplace[peer] % 8:
+                            bad = 'chunk %d: peer %d sends %d bytes where %d are expected' % (c, peer, psize, rcv['sizes'][peer])
+                            break
+                        n = psize // 8
+                        want[rplace[peer] // 8: rplace[peer] // 8 + n] = \
+                            torch.arange(poff // 8, poff // 8 + n, dtype=torch.int64, device=rw.device) + (ptag << 44)
+                    if bad:
+                        break
+                if bad is None:
+                    ne = rw != want
+                    cnt = int(ne.sum().item())
+                    if cnt:
+                        w = int(torch.nonzero(ne)[0].item())
+                        got, exp = int(rw[w].item()), int(want[w].item())
+                        where = next(((c, peer) for c in range(K) for peer in range(p)
+                                      if _places(rcv, c)[peer] <= 8 * w < _places(rcv, c)[peer] + rcv['sizes'][peer]), None)
+                        bad = '%d of %d words wrong, first at byte %d (%s): holds %s, expected %s' % (
+                            cnt, rw.numel(), 8 * w,
+                            'outside every message' if where is None else 'chunk %d, message from peer %d' % where,
+                            'nothing (never written)' if got == -1 else 'word %d of rank tag %d' % (got & ((1 << 44) - 1), got >> 44),
+                            'nothing' if exp == -1 else 'word %d of rank tag %d' % (exp & ((1 << 44) - 1), exp >> 44))
+                    del ne
+                del want
+                if bad:
+                    failures.append('pipeline transfer %d %s (%d ranks, %d chunks, route %s): %s' % (
+                        ti, 'forward' if forward else 'backward', p, K, 'relay' if t.get('relay') else 'direct', bad))
+        return {'hops': hops, 'failures': failures}
+
     def run(self, forward, src=None, dst=None, normalize=None):
         """One transform.  `src` / `dst`: tensors of the planned input / output layout to read /
         write instead of the planned arrays."""

@@ -1,0 +1,263 @@
+"""Self-checks of a planned PFFT on the wire and route it is about to run: what admits a plan to timing.
+
+A forward -> backward round trip cannot vouch for a redistribution: a block delivered to the wrong
+offset by a relay schedule or a chunk plan is undone by the mirrored backward exchange.  The
+reference's own exchange test is positional (tests/test_pencil.py:26-56: every rank must hold
+exactly its slice of ONE global array after each hop), and its transform tests compare forward
+values (tests/test_mpifft.py:17).  Three checks, none of which touches the oracle:
+
+  exchange_check(fft)   every Transfer of the plan, forward then backward, on global linear indices
+                        (64-bit words viewed as the element type), bit-exact after each hop; for a
+                        pipelined plan additionally every chunk of every exchange of the pipeline on
+                        its own buffers, wire and route (Pipeline.exchange_selftest).
+  forward_gate(fft, world, u0)
+                        a few (k0, k1) lines of the forward against the DFT by definition: the
+                        (i0, i1) sums over the DISTRIBUTED input in float64 on the device,
+                        all-gathered, the last axis by a dense DFT matrix (BASELINE.md section 4:
+                        max|delta| <= 2e-10 max|ref| in fp64).
+  fingerprint(t)        a position-weighted 64-bit checksum of every word of a tensor: two plans of
+                        one transform built from the same kernels must agree bit for bit.
+"""
+import numpy as np
+
+from .array import DeviceArray
+from .pencil import _blockdist
+
+
+# ---- index patterns --------------------------------------------------------------------------------------------
+def _pattern(gshape, starts, sub, itemsize, tag, device):
+    """A tensor of `sub` elements of `itemsize` bytes whose bits say WHERE in the group-global array
+    each element belongs: word 0 = C-order linear index in `gshape` of (starts + local index); the group
+    tag is folded in so that a block relayed into the wrong group cannot pass.  Returned as int64 / int32
+    words: shape sub + (itemsize // 8,) (16- and 8-byte elements) or sub (4-byte elements)."""
+    import torch
+    strides = [1] * len(gshape)
+    for d in range(len(gshape) - 2, -1, -1):
+        strides[d] = strides[d + 1] * int(gshape[d + 1])
+    idx = torch.zeros(tuple(sub), dtype=torch.int64, device=device)
+    for d, (s, n) in enumerate(zip(starts, sub)):
+        ar = (torch.arange(int(s), int(s) + int(n), dtype=torch.int64, device=device) * strides[d])
+        idx += ar.view([-1 if k == d else 1 for k in range(len(sub))])
+    if itemsize == 16:
+        out = torch.empty(tuple(sub) + (2,), dtype=torch.int64, device=device)
+        out[..., 0] = idx
+        out[..., 1] = idx ^ (int(tag) << 44)
+        return out
+    if itemsize == 8:
+        return (idx ^ (int(tag) << 44)).unsqueeze(-1)
+    assert itemsize == 4
+    return ((idx * 40503 + int(tag)) & 0x3fffffff).to(torch.int32)
+
+
+def _as_elements(words, tdtype):
+    """The pattern viewed as the array's element type (no arithmetic ever touches it)."""
+    import torch
+    if words.dtype == torch.int32:
+        return words.view(tdtype)
+    return words.view(tdtype).squeeze(-1)
+
+
+def _words(t):
+    """The inverse view: a contiguous element tensor as its 64-bit (4-byte elements: 32-bit) words."""
+    import torch
+    if t.is_complex():
+        return torch.view_as_real(t).view(torch.int64)
+    if t.dtype == torch.float64:
+        return t.unsqueeze(-1).view(torch.int64)
+    return t.view(torch.int32)
+
+
+def _to_packed(nat, axis, p):
+    """Natural local array -> the exchange-buffer layout [peer][C order of the peer's sub-box], the
+    blocks cut along `axis` by the block rule (what PFFT._fuse_packs makes the neighbouring transform
+    write / read)."""
+    import torch
+    n = nat.shape[axis]
+    parts = []
+    for r in range(p):
+        ln, st = _blockdist(n, p, r)
+        parts.append(nat.narrow(axis, st, ln).contiguous().view(-1))
+    return torch.cat(parts).view(nat.shape)
+
+
+def _first_mismatch(got, want, shape, axis_cut, p):
+    """(count, position, block): how many elements differ, the first differing local position, and the
+    peer block (along the axis the exchange cut) it lies in."""
+    import torch
+    ne = (got != want)
+    while ne.dim() > len(shape):
+        ne = ne.any(-1)
+    cnt = int(ne.sum().item())
+    if cnt == 0:
+        return 0, None, None
+    flat = int(torch.nonzero(ne.reshape(-1))[0].item())
+    pos = tuple(int(x) for x in np.unravel_index(flat, shape))
+    block = None
+    for r in range(p):
+        ln, st = _blockdist(shape[axis_cut], p, r)
+        if st <= pos[axis_cut] < st + ln:
+            block = r
+    return cnt, pos, block
+
+
+def transfer_check(tr, tag=0, device=None):
+    """One Transfer on global indices, forward then backward, honouring its packed sides and its route
+    (direct / relay / chunked).  None when every hop is bit-exact, else a description of the first
+    failure ON THIS RANK.  Collective over the transfer's communicator (and over the parent grid when the
+    route is relayed)."""
+    import torch
+    p = tr.comm.Get_size()
+    r = tr.comm.Get_rank()
+    tdt = {'F': torch.complex64, 'D': torch.complex128, 'f': torch.float32, 'd': torch.float64}[tr.dtype.char]
+    isz = tr.dtype.itemsize
+    a, b = tr.axisA, tr.axisB
+    startA = [0] * len(tr.shape)
+    startB = [0] * len(tr.shape)
+    startA[b] = _blockdist(tr.shape[b], p, r)[1]
+    startB[a] = _blockdist(tr.shape[a], p, r)[1]
+    if device is None:
+        device = 'cuda' if torch.cuda.is_available() else 'cpu'
+    wA = _pattern(tr.shape, startA, tr.subshapeA, isz, tag, device)
+    wB = _pattern(tr.shape, startB, tr.subshapeB, isz, tag, device)
+    natA, natB = _as_elements(wA, tdt), _as_elements(wB, tdt)
+    msg = None
+    # forward hop: A (aligned on axisA, cut along axisB over the group) -> B
+    A = _to_packed(natA, a, p) if tr.packedA else natA.clone()
+    B = torch.zeros(tr.subshapeB, dtype=tdt, device=device)
+    tr.forward(DeviceArray(tr.subshapeA, tr.dtype, tensor=A), DeviceArray(tr.subshapeB, tr.dtype, tensor=B))
+    wantB = _to_packed(natB, b, p) if tr.packedB else natB
+    cnt, pos, blk = _first_mismatch(_words(B), _words(wantB), tr.subshapeB, b, p)
+    if cnt:
+        msg = 'forward hop (axis %d -> %d, %d ranks, route %s): %d of %d elements misplaced on sub-rank %d, first at local %s (block from peer %s)' % (
+            a, b, p, tr.exchange, cnt, int(np.prod(tr.subshapeB)), r, pos, blk)
+    del A
+    # backward hop from the EXPECTED B (so that one failure does not mask the other direction)
+    Bsrc = wantB.clone() if wantB is natB else wantB
+    A2 = torch.zeros(tr.subshapeA, dtype=tdt, device=device)
+    tr.backward(DeviceArray(tr.subshapeB, tr.dtype, tensor=Bsrc), DeviceArray(tr.subshapeA, tr.dtype, tensor=A2))
+    wantA = _to_packed(natA, a, p) if tr.packedA else natA
+    cnt, pos, blk = _first_mismatch(_words(A2), _words(wantA), tr.subshapeA, a, p)
+    if cnt and msg is None:
+        msg = 'backward hop (axis %d -> %d, %d ranks, route %s): %d of %d elements misplaced on sub-rank %d, first at local %s (block from peer %s)' % (
+            b, a, p, tr.exchange, cnt, int(np.prod(tr.subshapeA)), r, pos, blk)
+    return msg
+
+
+def exchange_check(fft, world=None):
+    """Every redistribution of the plan on the wire / route it will run, positions checked bit for bit.
+    Returns {'result': 'bit-exact' | 'FAILED', 'hops': n, 'failures': [...]}; collective over the grid.
+    The planned stage arrays are left untouched by the staged check (it works on arrays of its own);
+    the pipeline's check overwrites the pipeline's exchange buffers -- contents the next transform
+    rewrites anyway."""
+    import torch
+    failures = []
+    hops = 0
+    dims = [c.Get_size() for c in fft.subcomm]
+    coords = [c.Get_rank() for c in fft.subcomm]
+    for i, tr in enumerate(fft.transfer):
+        # group tag: this rank's coordinates in the grid dimensions the exchange does NOT span
+        members = tuple(getattr(tr.comm, '_ranks', (0,)))
+        tag = (min(members) if members else 0) + 1 + 64 * i
+        m = transfer_check(tr, tag, fft.forward.input_array.tensor.device)
+        hops += 2
+        if m is not None:
+            failures.append('transfer %d: %s' % (i, m))
+        torch.cuda.empty_cache() if torch.cuda.is_available() else None
+    pipe_hops = 0
+    if getattr(fft, 'pipeline', None) is not None:
+        pf = fft.pipeline.exchange_selftest()
+        pipe_hops = pf['hops']
+        failures += pf['failures']
+    everyone = world.allgather_obj(failures) if world is not None and world.Get_size() > 1 else [failures]
+    flat = ['rank %d: %s' % (rk, f) for rk, fl in enumerate(everyone) for f in fl]
+    out = {'result': 'bit-exact' if not flat else 'FAILED', 'hops': hops, 'grid': dims}
+    if pipe_hops:
+        out['pipeline_chunk_exchanges'] = pipe_hops
+    if all(d == 1 for d in dims):
+        out['note'] = 'one rank: every Transfer of the plan is a local copy (elided inside the fused plan); checked as built'
+    if flat:
+        out['failures'] = flat[:8]
+    return out
+
+
+# ---- forward values against the DFT by definition ---------------------------------------------------------------
+def default_lines(shape):
+    n0, n1 = int(shape[0]), int(shape[1])
+    lines = [(3 % n0, 5 % n1), (n0 - 1, n1 - 1), (n0 // 2, 1 % n1), ((n0 // 2 + 7) % n0, (n1 // 4 + 3) % n1),
+             (0, n1 // 2), (17 % n0, 0)]
+    return lines
+
+
+def forward_gate(fft, world, u0, uh=None, lines=None):
+    """max over `lines` of |forward - DFT| / max|DFT| for a 3-D complex transform over all axes whose
+    input pencil keeps axis 2 whole (the default plan): `u0` = this rank's block of the input (natural
+    layout, left untouched), `uh` = this rank's block of the forward output (default: the planned output
+    array, which must hold forward(u0)).  Collective over `world`."""
+    import torch
+    pin, pout = fft.pencil
+    shape = tuple(int(s) for s in pin.shape)
+    assert len(shape) == 3 and pin.subshape[2] == shape[2], 'forward_gate: 3-D plans with the last axis whole in the input'
+    assert tuple(pout.shape) == shape and u0.is_complex(), 'forward_gate: complex-to-complex transforms'
+    if uh is None:
+        uh = fft.forward.output_array.tensor
+    assert tuple(u0.shape) == tuple(pin.subshape) and tuple(uh.shape) == tuple(pout.subshape)
+    if lines is None:
+        lines = default_lines(shape)
+    dev = u0.device
+    n0, n1, n2 = shape
+    l0, l1 = u0.shape[0], u0.shape[1]
+    k0 = torch.tensor([k for k, _ in lines], dtype=torch.float64, device=dev)
+    k1 = torch.tensor([k for _, k in lines], dtype=torch.float64, device=dev)
+    i0 = torch.arange(pin.substart[0], pin.substart[0] + l0, device=dev, dtype=torch.float64)
+    i1 = torch.arange(pin.substart[1], pin.substart[1] + l1, device=dev, dtype=torch.float64)
+    w0 = torch.polar(torch.ones(len(lines), l0, dtype=torch.float64, device=dev),
+                     -2 * np.pi * torch.remainder(k0[:, None] * i0[None, :], n0) / n0)
+    w1 = torch.polar(torch.ones(len(lines), l1, dtype=torch.float64, device=dev),
+                     -2 * np.pi * torch.remainder(k1[:, None] * i1[None, :], n1) / n1)
+    x = u0 if u0.dtype == torch.complex128 else None
+    acc = torch.zeros(len(lines), n2, dtype=torch.complex128, device=dev)
+    step = max(1, min(l0, (1 << 22) // max(1, l1 * n2) * 8 or 1))
+    for a in range(0, l0, step):
+        blk = u0[a:a + step] if x is not None else u0[a:a + step].to(torch.complex128)
+        part = torch.matmul(w1.unsqueeze(0), blk)                       # (a, L, n2): the i1 sums
+        acc += torch.einsum('la,alc->lc', w0[:, a:a + step], part)      # the i0 sums
+    parts = world.allgather_obj(acc.cpu().numpy()) if world.Get_size() > 1 else [acc.cpu().numpy()]
+    line_in = torch.from_numpy(np.sum(parts, axis=0)).to(dev)           # (L, n2): every line before its last transform
+    # axis 2 by a dense DFT matrix, float64, exact phase reduction
+    k2 = torch.arange(n2, device=dev, dtype=torch.float64)
+    err = 0.0
+    ref_max = 0.0
+    s1, s2 = pout.substart[1], pout.substart[2]
+    m1, m2 = uh.shape[1], uh.shape[2]
+    assert uh.shape[0] == n0
+    kk = torch.arange(s2, s2 + m2, device=dev, dtype=torch.float64)
+    W2 = None
+    for li, (a0, a1) in enumerate(lines):
+        if W2 is None:
+            W2 = torch.polar(torch.ones(m2, n2, dtype=torch.float64, device=dev),
+                             -2 * np.pi * torch.remainder(kk[:, None] * k2[None, :], n2) / n2)
+        if not (s1 <= a1 < s1 + m1):
+            continue
+        ref = torch.mv(W2, line_in[li]) / float(n0 * n1 * n2)
+        got = uh[a0, a1 - s1, :].to(torch.complex128)
+        err = max(err, float((got - ref).abs().max().item()))
+        ref_max = max(ref_max, float(ref.abs().max().item()))
+    both = world.allgather_obj((err, ref_max)) if world.Get_size() > 1 else [(err, ref_max)]
+    e, m = max(b[0] for b in both), max(b[1] for b in both)
+    return e / m if m > 0 else float('inf')
+
+
+# ---- every word of a tensor, position weighted -----------------------------------------------------------------
+def fingerprint(t, chunk=1 << 26):
+    """sum_k word_k * (2 k + 1) mod 2^64 over the 64-bit (32-bit for odd sizes) words of a contiguous
+    tensor: equal tensors agree, a moved or altered word almost surely does not."""
+    import torch
+    v = torch.view_as_real(t) if t.is_complex() else t
+    v = v.contiguous().view(-1)
+    v = v.view(torch.int64) if (v.numel() * v.element_size()) % 8 == 0 else v.view(torch.int32).to(torch.int64)
+    acc = 0
+    for a in range(0, v.numel(), chunk):
+        w = v[a:a + chunk]
+        k = torch.arange(a, a + w.numel(), dtype=torch.int64, device=w.device) * 2 + 1
+        acc = (acc + int((w * k).sum().item())) & 0xffffffffffffffff
+    return acc

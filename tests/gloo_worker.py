@@ -13,7 +13,8 @@ import numpy as np
 
 
 def main():
-    from mpi4py_fft_amd import comm, _lib, PFFT, newDistArray, DistArray, Subcomm
+    from mpi4py_fft_amd import comm, _lib, PFFT, newDistArray, DistArray, Subcomm, selftest
+    import bench
     from tests.host_engine import HostEngine
     from oracle import pfft_oracle as O
     _lib.set_engine(HostEngine())
@@ -28,6 +29,7 @@ def main():
              ((12, 10, 8), 'D', dict(grid=(-1,))), ((12, 9, 8, 6), 'd', dict(axes=((0,), (1,), (2, 3))))]
     from mpi4py_fft_amd import relay
     relayed, run = [], relay.Schedule.run
+    misrouted = []
     relay.Schedule.run = lambda self, *a: (relayed.append(1), run(self, *a))[1]
     # second sweep: the two-round multi-path exchange (relay.py) over point-to-point messages
     sweeps = [(c, '0') for c in cases] + ([(c, '1') for c in cases] if P > 2 else [])
@@ -38,22 +40,45 @@ def main():
         want = ref.forward(ref.scatter(G))[r]
         fft = PFFT(world, shape, dtype=dt, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
         assert [c.Get_size() for c in fft.subcomm] == list(ref.dims), (shape, kw)
+        # what bench.py admits a plan on: every hop of every Transfer positional and bit-exact on this route
+        chk = selftest.exchange_check(fft, world)
+        assert chk['result'] == 'bit-exact' and chk['hops'] == 2 * len(fft.transfer), (shape, dt, kw, mode, chk)
         u = newDistArray(fft, False)
         assert tuple(u.shape) == ref.pencil_in[r].subshape
         u[...] = G[fft.local_slice(False)]
         uh = np.asarray(fft.forward(u))
         assert uh.shape == want.shape, (uh.shape, want.shape)
         assert np.abs(uh - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (shape, dt, kw)
+        if dt == 'D' and len(shape) == 3 and not kw.get('padding'):
+            import torch
+            u0 = torch.from_numpy(np.ascontiguousarray(G[fft.local_slice(False)]))
+            assert selftest.forward_gate(fft, world, u0) <= 1e-13, (shape, kw, mode)
+            if P > 1:
+                # ... and the gate notices a block in the wrong place where a round trip does not
+                bad = fft.forward.output_array.tensor.clone()
+                bad.copy_(torch.roll(bad, 1, 0))
+                assert selftest.forward_gate(fft, world, u0, uh=bad) > 1e-3
         if not kw.get('padding'):
             back = np.asarray(fft.backward())
             assert np.abs(back - G[fft.local_slice(False)]).max() < 1e-12
+        if mode == '1' and any(t._relay for t in fft.transfer) and not kw.get('padding'):
+            # a relay piece delivered to the wrong offset, mirrored in the backward schedule: the round trip
+            # still passes, the positional check names it
+            if any(world.allgather_obj(bench.misroute(fft))):
+                fft.forward(u)
+                back = np.asarray(fft.backward())
+                assert np.abs(back - G[fft.local_slice(False)]).max() < 1e-12
+                chk = selftest.exchange_check(fft, world)
+                assert chk['result'] == 'FAILED' and 'misplaced' in chk['failures'][0], chk
+                misrouted.append(1)
         fft.destroy()
-    assert bool(relayed) == (P > 2)
+    assert bool(relayed) == (P > 2) and bool(misrouted) == (P > 2)
     # the chunked pipeline (pipeline.py) on torch.distributed's asynchronous all-to-all: layouts,
     # chunk offsets, guru-plan geometry and exchange order, against the staged path and the oracle
     from mpi4py_fft_amd import pipeline
     pipeline.Pipeline.MIN_CHUNK_BYTES = 0
     pipeline.Pipeline.MIN_WIDTH = 2
+    misplaced_chunks = []
     os.environ['GFFT_RELAY'] = '0'
     # (the last three take the line-aligned exchange buffers of pipeline._Aligned: tile-major T0, pitched T1)
     for shape, dt, kw, layout in (((32, 16, 64), 'D', {}, None), ((16, 32, 32), 'F', {}, None),
@@ -68,6 +93,8 @@ def main():
         piped = PFFT(world, shape, dtype=dt, wire='overlap', **kw)
         assert piped.pipeline is not None, (shape, kw)
         assert layout is None or piped.pipeline.layout == layout, (shape, dt, kw, piped.pipeline.describe())
+        chk = selftest.exchange_check(piped, world)
+        assert chk['result'] == 'bit-exact' and chk['pipeline_chunk_exchanges'] > 0, (shape, dt, kw, chk)
         u = newDistArray(piped, False)
         u[...] = G[piped.local_slice(False)]
         uh = np.asarray(piped.forward(u))
@@ -75,7 +102,22 @@ def main():
         assert np.abs(uh - want).max() <= tol * max(1.0, np.abs(want).max()), (shape, dt, kw, np.abs(uh - want).max())
         back = np.asarray(piped.backward())
         assert np.abs(back - G[piped.local_slice(False)]).max() <= 10 * tol
+        # a wire that delivers the messages of chunk c to the places of chunk K-1-c: the pipeline's positional
+        # check names the chunk and the peer
+        e = next(t for t in piped.pipeline.tplan if t['p'] > 1)
+        if e['K'] > 1 and 'peer_stride' not in e['B'] and 'peer_stride' not in e['A']:
+            w, K = e['wire'], e['K']
+            good = w.exchange_chunk
+            w.exchange_chunk = lambda send, so, ss, recv, ro, rs: good(send, so, ss, recv, (K - 1) * sum(rs) - ro, rs)
+            try:
+                chk = selftest.exchange_check(piped, world)
+                assert chk['result'] == 'FAILED' and 'words wrong' in chk['failures'][0], chk
+                misplaced_chunks.append(1)
+            finally:
+                w.exchange_chunk = good
+            assert selftest.exchange_check(piped, world)['result'] == 'bit-exact'
         piped.destroy()
+    assert misplaced_chunks
     # DistArray.redistribute over the real communicator (tests/test_darray.py:50-57)
     N = (8, 10, 12)
     sub = Subcomm(world, [0, 0, 1])

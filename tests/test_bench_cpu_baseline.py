@@ -82,3 +82,35 @@ def test_cpu_baseline_falls_back_to_the_oracle_when_no_fftw_loads(monkeypatch):
     monkeypatch.setattr(bench, '_cpu_pocketfft', fake_pocket)
     out = bench.cpu_baseline(4, 5.0)
     assert seen['args'] == (4, 5.0) and 'FFTW probe' in out['sample']
+
+
+def test_per_axis_plans_on_a_one_batch_dim_library_equal_fftn():
+    """What the cpu_baseline leg executes when the FFTW3 implementation at hand is MKL's interface (one batch dim per
+    guru plan): merged contiguous batch dims for axes 2 and 0, a loop over the slabs of one 2-D plan for axis 1 --
+    the reference's default per-axis stage order (mpifft.py:313-331), checked by value, not by a round trip."""
+    import numpy as np
+    import pytest
+    try:
+        F = bench._Fftw(2)
+    except OSError:
+        pytest.skip('no FFTW3 implementation loadable here')
+    n = 24
+    rng = np.random.default_rng(0)
+    u = rng.standard_normal((n, n, n)) + 1j * rng.standard_normal((n, n, n))
+    v = np.empty_like(u)
+    ex = F.lib.fftw_execute_dft
+    p2 = F.plan(u, v, [2], -1, F.ESTIMATE)
+    assert p2
+    ex(p2, u.ctypes.data, v.ctypes.data)
+    p1 = F.plan(v, v, [1], -1, F.ESTIMATE)
+    if p1:
+        ex(p1, v.ctypes.data, v.ctypes.data)
+    else:
+        p1 = F.plan(v[0], v[0], [0], -1, F.ESTIMATE)
+        assert p1
+        for i in range(n):
+            ex(p1, v.ctypes.data + i * n * n * 16, v.ctypes.data + i * n * n * 16)
+    p0 = F.plan(v, v, [0], -1, F.ESTIMATE)
+    assert p0
+    ex(p0, v.ctypes.data, v.ctypes.data)
+    assert np.abs(v - np.fft.fftn(u)).max() < 1e-11

@@ -40,6 +40,9 @@ def _check_line(out, nranks, size):
     assert out['scaling'] == 'strong' and out['higher_is_better'] is True and out['dtype'] == 'f64'
     assert out['value'] > 0 and out['ms_per_step'] > 0
     assert out['config']['round_trip_rel_err'] <= 1e-10
+    # the admission gates of the plan that was timed (tests/test_pencil.py:26-56 of the reference)
+    assert out['config']['exchange_check'] == 'bit-exact' and out['config']['forward_rel_err'] <= 2e-10
+    assert out['config']['gates']['exchange_hops'] > 0
     assert 'extras_error' not in out, out['extras_error']
 
 
@@ -63,6 +66,27 @@ def test_bench_self_launch_four_ranks_measures_routes_and_slab():
     assert rm["round_trip_rel_err"] <= 1e-10
     assert all(len(e['measured_s']) == 2 and e['route'] in ('direct', 'relay') for e in rm['exchange'])
     assert out['slab_grid']['grid'] == [4, 1, 1] and out['slab_grid']['gflops'] > 0
+
+
+def test_bench_drops_a_route_that_misplaces_a_relay_piece():
+    """The relayed route with one piece per rank delivered to a neighbouring piece's offset and fetched back from
+    there (bench.misroute): forward -> backward still returns the input, so the round trip of rounds 1-4 would have
+    admitted the route to timing.  The positional check rejects it, names rank and block, and it is never timed."""
+    out = _run(os.path.join(ROOT, 'tests', 'bench_host_runner.py'), 4, 32,
+               extra_env={'GFFT_RELAY': 'relay', 'GFFT_RELAY_MIN_BYTES': '0', 'GFFT_BENCH_TEST_MISROUTE': 'measured routes'},
+               extra_args=('--no-slab',))
+    _check_line(out, 4, 32)
+    rm = [a for a in out['alternatives'] if a['plan'] == 'measured routes'][0]
+    assert rm['test_misroute_applied'] is True and all(e['route'] == 'relay' for e in rm['exchange'])
+    assert rm['exchange_check'] == 'FAILED' and 'misplaced' in rm['rejected'] and 'rank' in rm['exchange_failures'][0]
+    assert 'ms_per_step' not in rm and 'value' not in rm
+    assert out['config'].get('plan') != 'measured routes' and out['config']['exchange_check'] == 'bit-exact'
+    # the same route, intact, is admitted and timed
+    ok = _run(os.path.join(ROOT, 'tests', 'bench_host_runner.py'), 4, 32,
+              extra_env={'GFFT_RELAY': 'relay', 'GFFT_RELAY_MIN_BYTES': '0'}, extra_args=('--no-slab',))
+    rm = [a for a in ok['alternatives'] if a['plan'] == 'measured routes'][0]
+    assert rm['exchange_check'] == 'bit-exact' and rm['forward_rel_err'] <= 2e-10 and rm['forward_bit_identical_to_headline']
+    assert rm['ms_per_step'] > 0
 
 
 def test_bench_keeps_the_headline_when_an_extra_hangs():
