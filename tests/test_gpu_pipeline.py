@@ -417,3 +417,66 @@ def test_late_messages_are_waited_for():
     neg = subprocess.run([sys.executable, worker, 'broken'], env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.STDOUT, timeout=600, text=True)
     assert neg.returncode == 0 and 'results WRONG' in neg.stdout, neg.stdout[-2000:]
+
+
+@pytest.mark.parametrize('P,shape,kw', [
+    (2, (64, 64, 64), {}),
+    (4, (64, 64, 64), {}),
+    (8, (64, 64, 128), {}),
+    (8, (32, 32, 1024), {}),                       # line-aligned exchange buffers (pipeline._Aligned)
+    (4, (64, 128, 64), dict(grid=(-1,))),          # slab
+])
+def test_admission_gates_on_every_wire_and_route(P, shape, kw, monkeypatch):
+    """bench.py's admission gates (mpi4py-fft_amd/selftest.py) on the HIP engine: the positional exchange check of
+    every Transfer -- packed sides written / read by the neighbouring kernels included -- and of every chunk exchange
+    of the pipeline, the forward against the DFT by definition, and word-for-word identity of the plans, on the staged
+    and the pipelined wire, direct and relayed; then a relayed route with two pieces swapped (and swapped back on the
+    way home, so that the round trip holds) must be named by the check."""
+    import torch
+    import bench
+    from mpi4py_fft_amd import PFFT, newDistArray, pipeline, selftest
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_CHUNK_BYTES', 0)
+    monkeypatch.setattr(pipeline.Pipeline, 'MIN_WIDTH', 4)
+    G = O.rng_array(shape, 'D', 5)
+
+    def body(comm):
+        k = {a: (list(b) if isinstance(b, list) else b) for a, b in kw.items()}
+        out = []
+        prints = None
+        for wire, exchange in (('torch', 'direct'), ('torch', 'relay'), ('native', 'direct'), ('native', 'relay')):
+            f = PFFT(comm, shape, dtype='D', wire=wire, exchange=exchange, **k)
+            chk = selftest.exchange_check(f, comm)
+            u = newDistArray(f, False)
+            u[...] = G[f.local_slice(False)]
+            u0 = u.tensor.clone()
+            uh = f.forward(u).tensor
+            torch.cuda.synchronize()
+            err = selftest.forward_gate(f, comm, u0, uh)
+            fp = comm.allgather_obj(selftest.fingerprint(uh))
+            same = prints is None or fp == prints
+            prints = fp
+            packed = [(t.packedA, t.packedB) for t in f.transfer if t.comm.Get_size() > 1]
+            routes = [t.exchange for t in f.transfer if t.comm.Get_size() > 1]
+            bad = None
+            if wire == 'torch' and exchange == 'relay' and any(comm.allgather_obj(bench.misroute(f))):
+                back = np.asarray(f.backward(f.forward(u))).copy()
+                rt = float(np.abs(back - G[f.local_slice(False)]).max())
+                bad = (rt, selftest.exchange_check(f, comm), selftest.forward_gate(f, comm, u0, f.forward(u).tensor))
+            out.append((wire, exchange, chk, err, same, packed, routes, f.pipeline is not None, bad))
+            f.destroy()
+        return out
+    res = cases.run_ranks(P, body)
+    for r, rows in enumerate(res):
+        for wire, exchange, chk, err, same, packed, routes, piped, bad in rows:
+            assert chk['result'] == 'bit-exact', (r, wire, exchange, chk)
+            assert (chk.get('pipeline_chunk_exchanges', 0) > 0) == piped
+            assert err <= 2e-10 and same, (r, wire, exchange, err, same)
+            if wire == 'torch':
+                assert any(a or b for a, b in packed), packed        # the kernels' own exchange-buffer layouts were checked
+            if bad is not None:
+                rt, chk2, err2 = bad
+                assert rt < 1e-12                                    # the round trip cannot see it
+                assert chk2['result'] == 'FAILED' and 'misplaced' in chk2['failures'][0], chk2
+                assert err2 > 1e-3                                   # ... the forward gate can
+    if P > 2 and not kw:
+        assert any(row[8] is not None for row in res[0])
