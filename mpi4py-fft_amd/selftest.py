@@ -25,91 +25,101 @@ from .pencil import _blockdist
 
 
 # ---- index patterns --------------------------------------------------------------------------------------------
-def _pattern(gshape, starts, sub, itemsize, tag, device):
-    """A tensor of `sub` elements of `itemsize` bytes whose bits say WHERE in the group-global array
-    each element belongs: word 0 = C-order linear index in `gshape` of (starts + local index); the group
-    tag is folded in so that a block relayed into the wrong group cannot pass.  Returned as int64 / int32
-    words: shape sub + (itemsize // 8,) (16- and 8-byte elements) or sub (4-byte elements)."""
+# Every element carries WHERE in the group-global array it belongs: word 0 = C-order linear index in the
+# group-global shape, the group tag folded into the spare bits (16-byte elements: a second word) so that a block
+# relayed into the wrong group cannot pass.  Patterns are written and compared in place, slab by slab: no
+# array-sized temporaries (at 1024^3 an allocation of 16 GiB costs more than the exchange being checked).
+_SLAB = 1 << 24                      # elements per slab of pattern generated at a time
+
+
+def _regions(shape, axis, p, packed):
+    """Contiguous regions of a local array as (element offset, sub-box shape, start along `axis`): the natural
+    array is one; a packed side (PFFT._fuse_packs: the neighbouring transform writes / reads the exchange buffer) is
+    [peer][C order of the peer's sub-box], the blocks cut along `axis` by the block rule."""
+    if not packed:
+        return [(0, tuple(shape), 0)]
+    out, off = [], 0
+    for r in range(p):
+        ln, st = _blockdist(shape[axis], p, r)
+        sub = tuple(ln if d == axis else n for d, n in enumerate(shape))
+        out.append((off, sub, st))
+        off += int(np.prod(sub, dtype=np.int64))
+    return out
+
+
+def _slab_words(gshape, starts, sub, lo, hi, itemsize, tag, device):
+    """Pattern words of rows lo:hi (along dim 0) of the sub-box `sub` placed at `starts` in `gshape`."""
     import torch
     strides = [1] * len(gshape)
     for d in range(len(gshape) - 2, -1, -1):
         strides[d] = strides[d + 1] * int(gshape[d + 1])
-    idx = torch.zeros(tuple(sub), dtype=torch.int64, device=device)
-    for d, (s, n) in enumerate(zip(starts, sub)):
-        ar = (torch.arange(int(s), int(s) + int(n), dtype=torch.int64, device=device) * strides[d])
-        idx += ar.view([-1 if k == d else 1 for k in range(len(sub))])
+    shp = (hi - lo,) + tuple(sub[1:])
+    idx = torch.zeros(shp, dtype=torch.int64, device=device)
+    for d, n in enumerate(shp):
+        s0 = int(starts[d]) + (lo if d == 0 else 0)
+        ar = torch.arange(s0, s0 + int(n), dtype=torch.int64, device=device) * strides[d]
+        idx += ar.view([-1 if k == d else 1 for k in range(len(shp))])
     if itemsize == 16:
-        out = torch.empty(tuple(sub) + (2,), dtype=torch.int64, device=device)
-        out[..., 0] = idx
-        out[..., 1] = idx ^ (int(tag) << 44)
-        return out
+        return torch.stack((idx, idx ^ (int(tag) << 44)), dim=-1)
     if itemsize == 8:
         return (idx ^ (int(tag) << 44)).unsqueeze(-1)
     assert itemsize == 4
     return ((idx * 40503 + int(tag)) & 0x3fffffff).to(torch.int32)
 
 
-def _as_elements(words, tdtype):
-    """The pattern viewed as the array's element type (no arithmetic ever touches it)."""
+def _walk(t, gshape, starts, shape, axis, p, packed, tag, write):
+    """Write the pattern into the contiguous tensor `t` (a local array of `shape`, natural or packed along `axis`)
+    or compare `t` with it.  Comparing returns (mismatching elements, first mismatching (region, local position))."""
     import torch
-    if words.dtype == torch.int32:
-        return words.view(tdtype)
-    return words.view(tdtype).squeeze(-1)
+    isz = t.element_size()
+    words = (torch.view_as_real(t) if t.is_complex() else t).reshape(-1)
+    words = words.view(torch.int32) if isz == 4 else words.view(torch.int64)
+    wpe = max(1, isz // 8)
+    bad, first = 0, None
+    for ri, (off, sub, st_axis) in enumerate(_regions(shape, axis, p, packed)):
+        st = list(starts)
+        st[axis] = starts[axis] + st_axis
+        row = int(np.prod(sub[1:], dtype=np.int64))
+        rows = max(1, _SLAB // max(1, row))
+        for lo in range(0, sub[0], rows):
+            hi = min(sub[0], lo + rows)
+            want = _slab_words(gshape, st, sub, lo, hi, isz, tag, t.device)
+            view = words[(off + lo * row) * wpe: (off + hi * row) * wpe].view(want.shape)
+            if write:
+                view.copy_(want)
+                continue
+            ne = view != want
+            if ne.dim() > len(sub):
+                ne = ne.any(-1)
+            cnt = int(ne.sum().item())
+            if cnt and first is None:
+                flat = int(torch.nonzero(ne.reshape(-1))[0].item())
+                pos = list(np.unravel_index(flat, (hi - lo,) + tuple(sub[1:])))
+                pos[0] += lo
+                first = (ri if packed else None, tuple(int(x) for x in pos))
+            bad += cnt
+    return bad, first
 
 
-def _words(t):
-    """The inverse view: a contiguous element tensor as its 64-bit (4-byte elements: 32-bit) words."""
+def _scratch(buf, shape, tdt):
+    """A contiguous tensor of `shape` / `tdt` carved out of the byte buffer `buf` (None: allocate)."""
     import torch
-    if t.is_complex():
-        return torch.view_as_real(t).view(torch.int64)
-    if t.dtype == torch.float64:
-        return t.unsqueeze(-1).view(torch.int64)
-    return t.view(torch.int32)
+    n = int(np.prod(shape, dtype=np.int64))
+    if buf is not None and buf.numel() >= n * tdt.itemsize:
+        return buf[:n * tdt.itemsize].view(tdt).view(tuple(shape))
+    return torch.empty(tuple(shape), dtype=tdt, device=buf.device if buf is not None else None)
 
 
-def _to_packed(nat, axis, p):
-    """Natural local array -> the exchange-buffer layout [peer][C order of the peer's sub-box], the
-    blocks cut along `axis` by the block rule (what PFFT._fuse_packs makes the neighbouring transform
-    write / read)."""
-    import torch
-    n = nat.shape[axis]
-    parts = []
-    for r in range(p):
-        ln, st = _blockdist(n, p, r)
-        parts.append(nat.narrow(axis, st, ln).contiguous().view(-1))
-    return torch.cat(parts).view(nat.shape)
-
-
-def _first_mismatch(got, want, shape, axis_cut, p):
-    """(count, position, block): how many elements differ, the first differing local position, and the
-    peer block (along the axis the exchange cut) it lies in."""
-    import torch
-    ne = (got != want)
-    while ne.dim() > len(shape):
-        ne = ne.any(-1)
-    cnt = int(ne.sum().item())
-    if cnt == 0:
-        return 0, None, None
-    flat = int(torch.nonzero(ne.reshape(-1))[0].item())
-    pos = tuple(int(x) for x in np.unravel_index(flat, shape))
-    block = None
-    for r in range(p):
-        ln, st = _blockdist(shape[axis_cut], p, r)
-        if st <= pos[axis_cut] < st + ln:
-            block = r
-    return cnt, pos, block
-
-
-def transfer_check(tr, tag=0, device=None):
+def transfer_check(tr, tag=0, device=None, scratch=(None, None)):
     """One Transfer on global indices, forward then backward, honouring its packed sides and its route
     (direct / relay / chunked).  None when every hop is bit-exact, else a description of the first
-    failure ON THIS RANK.  Collective over the transfer's communicator (and over the parent grid when the
-    route is relayed)."""
+    failure ON THIS RANK.  `scratch`: two uint8 device buffers the arrays may be carved from (their contents
+    are destroyed).  Collective over the transfer's communicator (and over the parent grid when the route is
+    relayed)."""
     import torch
     p = tr.comm.Get_size()
     r = tr.comm.Get_rank()
     tdt = {'F': torch.complex64, 'D': torch.complex128, 'f': torch.float32, 'd': torch.float64}[tr.dtype.char]
-    isz = tr.dtype.itemsize
     a, b = tr.axisA, tr.axisB
     startA = [0] * len(tr.shape)
     startB = [0] * len(tr.shape)
@@ -117,52 +127,60 @@ def transfer_check(tr, tag=0, device=None):
     startB[a] = _blockdist(tr.shape[a], p, r)[1]
     if device is None:
         device = 'cuda' if torch.cuda.is_available() else 'cpu'
-    wA = _pattern(tr.shape, startA, tr.subshapeA, isz, tag, device)
-    wB = _pattern(tr.shape, startB, tr.subshapeB, isz, tag, device)
-    natA, natB = _as_elements(wA, tdt), _as_elements(wB, tdt)
+    with torch.device(device):
+        A = _scratch(scratch[0], tr.subshapeA, tdt)
+        B = _scratch(scratch[1], tr.subshapeB, tdt)
+    dA = DeviceArray(tr.subshapeA, tr.dtype, tensor=A)
+    dB = DeviceArray(tr.subshapeB, tr.dtype, tensor=B)
     msg = None
+
+    def report(direction, cnt, first, total, src, dst, packed):
+        region, pos = first
+        return '%s hop (axis %d -> %d, %d ranks, route %s): %d of %d elements misplaced on sub-rank %d, first at %s%s' % (
+            direction, src, dst, p, tr.exchange, cnt, total, r,
+            'local %s' % (pos,) if not packed else 'position %s of the block from peer %d' % (pos, region),
+            '' if packed else ' (block from peer %d)' % next(
+                q for q in range(p) if _blockdist(tr.shape[dst], p, q)[1] <= pos[dst] < sum(_blockdist(tr.shape[dst], p, q))))
     # forward hop: A (aligned on axisA, cut along axisB over the group) -> B
-    A = _to_packed(natA, a, p) if tr.packedA else natA.clone()
-    B = torch.zeros(tr.subshapeB, dtype=tdt, device=device)
-    tr.forward(DeviceArray(tr.subshapeA, tr.dtype, tensor=A), DeviceArray(tr.subshapeB, tr.dtype, tensor=B))
-    wantB = _to_packed(natB, b, p) if tr.packedB else natB
-    cnt, pos, blk = _first_mismatch(_words(B), _words(wantB), tr.subshapeB, b, p)
+    _walk(A, tr.shape, startA, tr.subshapeA, a, p, tr.packedA, tag, True)
+    B.view(-1)[:].zero_()
+    tr.forward(dA, dB)
+    cnt, first = _walk(B, tr.shape, startB, tr.subshapeB, b, p, tr.packedB, tag, False)
     if cnt:
-        msg = 'forward hop (axis %d -> %d, %d ranks, route %s): %d of %d elements misplaced on sub-rank %d, first at local %s (block from peer %s)' % (
-            a, b, p, tr.exchange, cnt, int(np.prod(tr.subshapeB)), r, pos, blk)
-    del A
+        msg = report('forward', cnt, first, B.numel(), a, b, tr.packedB)
     # backward hop from the EXPECTED B (so that one failure does not mask the other direction)
-    Bsrc = wantB.clone() if wantB is natB else wantB
-    A2 = torch.zeros(tr.subshapeA, dtype=tdt, device=device)
-    tr.backward(DeviceArray(tr.subshapeB, tr.dtype, tensor=Bsrc), DeviceArray(tr.subshapeA, tr.dtype, tensor=A2))
-    wantA = _to_packed(natA, a, p) if tr.packedA else natA
-    cnt, pos, blk = _first_mismatch(_words(A2), _words(wantA), tr.subshapeA, a, p)
+    _walk(B, tr.shape, startB, tr.subshapeB, b, p, tr.packedB, tag, True)
+    A.view(-1)[:].zero_()
+    tr.backward(dB, dA)
+    cnt, first = _walk(A, tr.shape, startA, tr.subshapeA, a, p, tr.packedA, tag, False)
     if cnt and msg is None:
-        msg = 'backward hop (axis %d -> %d, %d ranks, route %s): %d of %d elements misplaced on sub-rank %d, first at local %s (block from peer %s)' % (
-            b, a, p, tr.exchange, cnt, int(np.prod(tr.subshapeA)), r, pos, blk)
+        msg = report('backward', cnt, first, A.numel(), b, a, tr.packedA)
     return msg
 
 
-def exchange_check(fft, world=None):
+def exchange_check(fft, world=None, use_planned_arrays=True):
     """Every redistribution of the plan on the wire / route it will run, positions checked bit for bit.
     Returns {'result': 'bit-exact' | 'FAILED', 'hops': n, 'failures': [...]}; collective over the grid.
-    The planned stage arrays are left untouched by the staged check (it works on arrays of its own);
-    the pipeline's check overwrites the pipeline's exchange buffers -- contents the next transform
-    rewrites anyway."""
+    DESTROYS the contents of the planned input / output arrays (the index arrays are carved out of them where they
+    fit: nothing array-sized is allocated) and of the pipeline's exchange buffers."""
     import torch
     failures = []
     hops = 0
     dims = [c.Get_size() for c in fft.subcomm]
     coords = [c.Get_rank() for c in fft.subcomm]
+    scratch = (None, None)
+    tin, tout = fft.forward.input_array.tensor, fft.forward.output_array.tensor
+    if use_planned_arrays and tin.data_ptr() != tout.data_ptr() and tin.is_contiguous() and tout.is_contiguous():
+        as_bytes = lambda t: (torch.view_as_real(t) if t.is_complex() else t).reshape(-1).view(torch.uint8)
+        scratch = (as_bytes(tout), as_bytes(tin))
     for i, tr in enumerate(fft.transfer):
-        # group tag: this rank's coordinates in the grid dimensions the exchange does NOT span
+        # group tag: which group of the grid this exchange runs in (its smallest member), and which transfer
         members = tuple(getattr(tr.comm, '_ranks', (0,)))
         tag = (min(members) if members else 0) + 1 + 64 * i
-        m = transfer_check(tr, tag, fft.forward.input_array.tensor.device)
+        m = transfer_check(tr, tag, tin.device, scratch)
         hops += 2
         if m is not None:
             failures.append('transfer %d: %s' % (i, m))
-        torch.cuda.empty_cache() if torch.cuda.is_available() else None
     pipe_hops = 0
     if getattr(fft, 'pipeline', None) is not None:
         pf = fft.pipeline.exchange_selftest()
