@@ -53,7 +53,8 @@ typedef enum {
   GFFT_ERR_UNSUPPORTED = -2, /* valid request the engine cannot plan (e.g. huge prime) */
   GFFT_ERR_NO_DEVICE = -3,   /* no HIP device / HIP runtime failure at init            */
   GFFT_ERR_HIP = -4,         /* a HIP call failed; see gfft_last_error()               */
-  GFFT_ERR_NOMEM = -5
+  GFFT_ERR_NOMEM = -5,
+  GFFT_ERR_VOIDED = -6       /* a launch that had already returned GFFT_OK failed on the device: gfft_async_error() */
 } gfft_status;
 
 /* transform kinds: same integers as the reference (fftw_planxfftn.c:3-8, utilities.pyx:7-26) */
@@ -104,14 +105,18 @@ int gfft_plan_destroy(gfft_plan plan);
 int gfft_scratch_release(void);           /* frees the shared per-stream workspaces, pinned ones included */
 /* Errors of launches that have already returned GFFT_OK (execution is asynchronous): a fused pass-pair launch
  * whose workgroups waited longer than option "fuse2_wait_ms" (default 2000) for one another -- a device shared
- * with a long foreign kernel, a debugger -- voids itself instead of hanging or trapping.  GFFT_OK, or
- * GFFT_ERR_HIP once per event with the plan named in gfft_last_error(): the results of that plan's last execution
- * are invalid, and the plan runs the pair as stand-alone launches from then on.  Does not synchronise -- call it
- * after synchronising the stream to learn whether what was waited for is valid; gfft_execute() reports a pending
- * event the same way, before enqueueing anything.  (The reference raises RuntimeError where FFTW fails to plan,
- * mpi4py_fft/fftw/fftw_xfftn.pyx:152-153, and cannot fail afterwards; this is the analogue for a failure mode only
- * a persistent launch has.) */
+ * with a long foreign kernel, a debugger -- voids itself instead of hanging or trapping.  The results of that plan's
+ * last execution are invalid and the plan runs the pair as stand-alone launches from then on.  The event stays with
+ * ITS plan until it is reported once, as GFFT_ERR_VOIDED with the plan named in gfft_last_error(), by whichever of
+ * these looks first:
+ *   gfft_plan_status(plan)  this plan's pending event;
+ *   gfft_execute(plan, ..)  the same, before enqueueing anything (other plans' events do not refuse the call);
+ *   gfft_async_error()      any plan's pending event (call until GFFT_OK to drain several).
+ * None of them synchronises -- call after synchronising the stream to learn whether what was waited for is valid.
+ * (The reference raises RuntimeError where FFTW fails to plan, mpi4py_fft/fftw/fftw_xfftn.pyx:152-153, and cannot
+ * fail afterwards; this is the analogue for a failure mode only a persistent launch has.) */
 int gfft_async_error(void);
+int gfft_plan_status(gfft_plan plan);
 /* Fuse FFTBase._truncation_forward / _padding_backward (libfft.py:263-311) into a single-axis plan:
  * afterwards gfft_execute writes (forward kinds) / reads (backward kinds) the TRUNCATED array,
  * n_keep entries along the axis (N on a complex axis, N/2+1 on the real half-axis), with the

@@ -39,6 +39,15 @@ def _check_async():
     _lib.check_async()
 
 
+def _item(t):
+    """A 0-d tensor as a Python scalar: the read synchronises, so this is where a launch that voided itself on the
+    device (gfft_async_error) must surface instead of a garbage number."""
+    v = t.item()
+    if t.is_cuda:
+        _check_async()
+    return v
+
+
 def _bounce(device):
     key = str(device)
     b = _pinned.get(key)
@@ -244,7 +253,7 @@ class DeviceArray:
 
     def _view(self, sub):
         if sub.ndim == 0:
-            return sub.item()
+            return _item(sub)
         out = DeviceArray.__new__(DeviceArray)
         out._shape = tuple(sub.shape)
         out._dtype = self._dtype
@@ -310,7 +319,7 @@ class DeviceArray:
         # signature numpy's np.sum(a) dispatches to for non-ndarray objects
         assert out is None
         r = self._t.sum() if axis is None else self._t.sum(dim=axis)
-        return r.item() if r.ndim == 0 else self._new(r)
+        return _item(r) if r.ndim == 0 else self._new(r)
 
     def __neg__(self):
         return self._new(-self._t)

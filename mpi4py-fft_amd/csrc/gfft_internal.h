@@ -186,7 +186,7 @@ int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &
 // dev_descs: {dA, dB} in device memory (uploaded when the plan was made; the scale factors travel as arguments)
 hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs,
                              const FusedDesc &f, const void *in, void *ring, void *out, hipStream_t s);
-// ... complex64 (fft_fused_f32.hip; off unless option fuse2_f32 is set: measured, see there)
+// ... complex64 (fft_fused_f32.hip; on by default: option fuse2_f32 = 1, 0 switches them off; measured, see there)
 bool fused2_supported_f32(int kind, int n_a, int n_b);
 int fused2_tiles_f32(int kind, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b);
 hipError_t launch_fused2_f32(int kind, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev_descs, const FusedDesc &f,

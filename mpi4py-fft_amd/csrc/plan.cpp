@@ -277,7 +277,8 @@ constexpr int GENERIC_MAX_PRIME = 61;
 size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // ---- scratch shared by all plans ---------------------------------------------------------------
-// One buffer per (host thread, stream), grown to the largest request seen there: the passes of one
+// One buffer per (device, host thread, stream) -- torch's default stream is handle 0 on EVERY device --, grown to the
+// largest request seen there: the passes of one
 // gfft_execute are enqueued back to back by one thread and a stream runs them in order, so every
 // plan that thread executes on that stream can share the buffer (the forward and the backward plan
 // of a 1024^3 PFFT each need a 16 GiB padded workspace; owning one each doubled that).  Other
@@ -286,12 +287,17 @@ size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // using the old buffer).
 struct ScratchPool {
   struct Slot { void *p = nullptr; size_t n = 0; bool pinned = false; };
+  struct Key {
+    int dev; std::thread::id th; hipStream_t st;
+    bool operator<(const Key &o) const { return std::tie(dev, th, st) < std::tie(o.dev, o.th, o.st); }
+  };
   std::mutex m;
-  std::map<std::pair<std::thread::id, hipStream_t>, Slot> bufs;
+  std::map<Key, Slot> bufs;
   std::vector<void *> retired;      // buffers a captured graph may still use, replaced by larger ones
   int get(hipStream_t s, size_t bytes, void **out) {
     std::lock_guard<std::mutex> lock(m);
     const auto me = std::this_thread::get_id();
+    const int dev = current_device();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
     if (cap != hipStreamCaptureStatusNone) {
@@ -301,10 +307,10 @@ struct ScratchPool {
       // into the graph: it is PINNED -- never freed by growth or by the last plan going away, only
       // by an explicit gfft_scratch_release().
       for (auto &kv : bufs)
-        if (kv.first.first == me && kv.second.n >= bytes) { kv.second.pinned = true; *out = kv.second.p; return GFFT_OK; }
+        if (kv.first.dev == dev && kv.first.th == me && kv.second.n >= bytes) { kv.second.pinned = true; *out = kv.second.p; return GFFT_OK; }
       return fail(GFFT_ERR_INVALID, "stream capture: execute the plan once before capturing it (its workspace is allocated at the first execution)");
     }
-    Slot &b = bufs[{me, s}];
+    Slot &b = bufs[Key{dev, me, s}];
     if (bytes > b.n) {
       if (b.p && b.pinned) {
         retired.push_back(b.p);      // a captured graph holds this address: keep it alive
@@ -327,17 +333,25 @@ struct ScratchPool {
   // freed; true: gfft_scratch_release(), the caller vouches that no captured graph will be replayed
   int release(bool everything) {
     std::lock_guard<std::mutex> lock(m);
-    // (one device-wide synchronisation: the stream handles in the keys may have been destroyed since)
-    if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+    // (one device-wide synchronisation per device that holds a buffer: the stream handles in the keys may have been
+    // destroyed since)
+    const int here = current_device();
+    int synced = -1;
     for (auto it = bufs.begin(); it != bufs.end();) {
       if (it->second.p && (everything || !it->second.pinned)) {
+        if (it->first.dev != synced) {          // (keys are ordered by device)
+          if (hipSetDevice(it->first.dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+          synced = it->first.dev;
+        }
         (void)hipFree(it->second.p);
         it = bufs.erase(it);
       } else {
         ++it;
       }
     }
+    if (synced >= 0 && synced != here && hipSetDevice(here) != hipSuccess) (void)hipGetLastError();
     if (everything) {
+      if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
       for (void *p : retired) (void)hipFree(p);
       retired.clear();
     }
@@ -369,26 +383,32 @@ struct gfft_plan_s {
   unsigned id = 0;                              // what a voided fused launch reports (async_errors)
   int device = 0;                               // the device the plan's tables and descriptors live on
   std::atomic<bool> fused_off{false};           // a fused launch gave up a wait: the pairs run as stand-alone passes from now on
+  std::atomic<bool> voided{false};              // ... and nobody has been told yet (poll_async_error)
   gfft_plan_s();
   ~gfft_plan_s();
 };
 
 // ---- fused launches that gave up a wait (fft_pow2_impl.h fused_give_up) --------------------------------
-// The kernel writes the plan's id into one pinned host word; the library looks at it on entry to gfft_execute and
-// in gfft_async_error(): the plan named there switches its pairs to stand-alone passes, and the call reports
-// GFFT_ERR_HIP once -- the results of that plan's last execution are invalid, everything else is untouched.
+// The kernel writes the plan's id into a slot of a small table of pinned host words (slot = id mod 64, so that two plans
+// voiding before anybody looks are both recorded); the library scans the table on entry to gfft_execute, in
+// gfft_plan_status() and in gfft_async_error().  A plan named there switches its pairs to stand-alone passes and carries
+// the error until it is reported ONCE: by that plan's own next gfft_execute (which enqueues nothing), by
+// gfft_plan_status(plan), or by gfft_async_error() -- whichever looks first.  Other plans are not refused: the results of
+// the voided plan's last execution are invalid, everything else is untouched.
 namespace {
 struct AsyncErrors {
+  static constexpr int SLOTS = 64;
   std::mutex m;
-  unsigned *flag = nullptr;                    // pinned, device-visible
+  unsigned *flag = nullptr;                    // SLOTS pinned, device-visible words
   std::map<unsigned, gfft_plan_s *> live;
+  std::vector<unsigned> orphans;               // ids of voided plans destroyed before anybody looked
   unsigned next_id = 1;
   unsigned *word() {
     if (!flag) {
       void *p = nullptr;
-      if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      if (hipHostMalloc(&p, SLOTS * sizeof(unsigned), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
       flag = static_cast<unsigned *>(p);
-      *flag = 0;
+      for (int i = 0; i < SLOTS; ++i) flag[i] = 0;
     }
     return flag;
   }
@@ -397,25 +417,47 @@ AsyncErrors &async_errors() {
   static AsyncErrors a;
   return a;
 }
-int poll_async_error() {
-  AsyncErrors &a = async_errors();
-  if (!a.flag) return GFFT_OK;
-  const unsigned id = __atomic_load_n(a.flag, __ATOMIC_ACQUIRE);
-  if (!id) return GFFT_OK;
-  std::lock_guard<std::mutex> lock(a.m);
-  __atomic_store_n(a.flag, 0u, __ATOMIC_RELEASE);
-  auto it = a.live.find(id);
-  if (it != a.live.end()) {
+// move what the kernels wrote since the last look into the plans (a.m held by the caller)
+void collect_async_errors(AsyncErrors &a) {
+  if (!a.flag) return;
+  for (int i = 0; i < AsyncErrors::SLOTS; ++i) {
+    const unsigned id = __atomic_load_n(a.flag + i, __ATOMIC_ACQUIRE);
+    if (!id) continue;
+    __atomic_store_n(a.flag + i, 0u, __ATOMIC_RELEASE);
+    auto it = a.live.find(id);
+    if (it == a.live.end()) { a.orphans.push_back(id); continue; }
     gfft_plan_s *pl = it->second;
     pl->fused_off = true;
+    pl->voided = true;
     for (const Pass &p : pl->passes)
       if (p.kind == PK_FUSED2 && p.alt_buf >= 0 && p.alt_bytes > pl->region_bytes[p.alt_buf]) pl->region_bytes[p.alt_buf] = p.alt_bytes;
   }
-  char msg[256];
+}
+int report_voided(unsigned id) {
+  char msg[320];
   snprintf(msg, sizeof msg, "a fused launch of plan #%u waited longer than %d ms for another workgroup and gave up (device shared or stalled?): "
            "the results of that plan's last execution are INVALID; the plan runs its pass pairs as stand-alone launches from now on", id,
            opts().fuse2_wait_ms);
-  return fail(GFFT_ERR_HIP, msg);
+  return fail(GFFT_ERR_VOIDED, msg);
+}
+// `only`: report this plan's pending event (if any); nullptr: report any pending event
+int poll_async_error(gfft_plan_s *only) {
+  AsyncErrors &a = async_errors();
+  if (!a.flag) return GFFT_OK;
+  std::lock_guard<std::mutex> lock(a.m);
+  collect_async_errors(a);
+  if (only) {
+    if (!only->voided.exchange(false)) return GFFT_OK;
+    return report_voided(only->id);
+  }
+  for (auto &kv : a.live)
+    if (kv.second->voided.exchange(false)) return report_voided(kv.first);
+  if (!a.orphans.empty()) {
+    const unsigned id = a.orphans.back();
+    a.orphans.pop_back();
+    return report_voided(id);
+  }
+  return GFFT_OK;
 }
 }  // namespace
 gfft_plan_s::gfft_plan_s() {
@@ -430,6 +472,7 @@ gfft_plan_s::~gfft_plan_s() {
   {
     AsyncErrors &a = async_errors();
     std::lock_guard<std::mutex> lock(a.m);
+    if (voided.exchange(false)) a.orphans.push_back(id);      // destroyed before anybody looked: still reported, by gfft_async_error
     a.live.erase(id);
   }
   for (void *q : device_allocs) (void)hipFree(q);
@@ -496,7 +539,8 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   if (!fused2_ring(pl->precision, dA.n, dB.n, slot_bytes, planes, &ring, &lag)) return false;
   if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1)) return false;
   const int variant = (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1;
-  // (fp64 only: the fp32 pairs measured slower than their stand-alone passes, fft_fused_f64.hip)
+  // (complex64 pairs are on by default since round 4 -- option fuse2_f32 = 1, profiles/r04_ab_fuse2_f32.txt; the real fp32
+  // pairs measured level with their stand-alone passes and need fuse2_f32 = 2)
   const bool real_kind = kind == FUSED_R2C_PLANES || kind == FUSED_COLS_C2R;
   const bool f32 = pl->precision == GFFT_F32;
   if (f32 && (!opts().fuse2_f32 || (real_kind && opts().fuse2_f32 < 2))) return false;
@@ -1450,6 +1494,7 @@ const char *gfft_strerror(int status) {
     case GFFT_ERR_NO_DEVICE: return "no HIP device";
     case GFFT_ERR_HIP: return "HIP runtime error";
     case GFFT_ERR_NOMEM: return "out of memory";
+    case GFFT_ERR_VOIDED: return "asynchronous launch failure";
   }
   return "unknown gfft status";
 }
@@ -1716,9 +1761,10 @@ int gfft_plan_create_r2r(gfft_plan *plan, int ndims, const int64_t *sizes, int n
 int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void *stream) {
   if (!pl || !d_in || !d_out) return fail(GFFT_ERR_INVALID, "null argument");
   {
-    // a fused launch of an earlier execution gave up a wait: report it now, once (the plan named in the message
-    // has been switched to stand-alone passes; calling again runs it that way)
-    int rc = poll_async_error();
+    // a fused launch of an earlier execution of THIS plan gave up a wait: report it now, once, and enqueue nothing (the
+    // plan has been switched to stand-alone passes; calling again runs it that way).  Another plan's pending event stays
+    // with that plan (gfft_plan_status / gfft_async_error / its own next execute) and does not refuse this call.
+    int rc = poll_async_error(pl);
     if (rc) return rc;
   }
   if (current_device() != pl->device) return fail(GFFT_ERR_INVALID, "the plan was made on another device than the calling thread's current one");
@@ -1780,7 +1826,7 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
       {
         AsyncErrors &ae = async_errors();
         if (!ae.flag) { std::lock_guard<std::mutex> lock(ae.m); (void)ae.word(); }
-        f.host_flag = ae.flag;
+        f.host_flag = ae.flag ? ae.flag + (pl->id % AsyncErrors::SLOTS) : nullptr;
         const int ms = opts().fuse2_wait_ms;
         f.wait_ticks = ms <= 0 ? 0u : (ms > 40000 ? 4000000000u : (unsigned)ms * 100000u);      // 100 MHz ticks
       }
@@ -2211,7 +2257,11 @@ int gfft_scratch_release(void) { return scratch_pool().release(true); }
 /* Did a fused launch give up a wait since the last look?  GFFT_OK, or GFFT_ERR_HIP once per event with the plan
  * named in gfft_last_error().  Does not synchronise: call it after the stream (or device) has been synchronised to
  * learn whether the results that synchronisation waited for are valid. */
-int gfft_async_error(void) { return poll_async_error(); }
+int gfft_async_error(void) { return poll_async_error(nullptr); }
+int gfft_plan_status(gfft_plan pl) {
+  if (!pl) return fail(GFFT_ERR_INVALID, "null plan");
+  return poll_async_error(pl);
+}
 
 int gfft_plan_destroy(gfft_plan pl) {
   if (!pl) return GFFT_OK;

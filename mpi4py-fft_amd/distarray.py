@@ -13,7 +13,7 @@ from numbers import Number
 
 import numpy as np
 
-from .array import DeviceArray
+from .array import DeviceArray, _item
 from .pencil import Pencil, Subcomm
 from . import comm as _comm
 
@@ -79,7 +79,7 @@ class DistArray(DeviceArray):
             key = key.tensor
         sub = self._t[key]
         if sub.ndim == 0:
-            return sub.item()
+            return _item(sub)
         lead = None
         if self._p0 is not None and self.ndim > 1:
             if isinstance(key, (int, np.integer, slice)):

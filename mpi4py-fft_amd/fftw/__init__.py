@@ -187,6 +187,13 @@ class FFT:
             return copy_out
         return tout
 
+    def status(self):
+        """After synchronising: raise RuntimeError if a launch of this plan voided itself on the device (a fused pass
+        pair that waited too long for another workgroup, include/gfft.h gfft_plan_status); the plan's last results are
+        then invalid and it runs stand-alone passes from now on."""
+        if hasattr(self._eng, 'plan_status'):
+            self._eng.plan_status(self._plan)
+
     def execute_scaled(self, tin, tout, scale):
         """Internal: run on explicit arrays with an arbitrary fused scale factor."""
         self._eng.plan_execute(self._plan, tin.tensor, tout.tensor, scale)

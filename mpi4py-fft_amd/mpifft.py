@@ -35,6 +35,7 @@ class Transform:
         self._fused = fused
         # (pipeline.Pipeline, is_forward): chunked execution overlapped with the exchanges
         self._pipe = pipe
+        self._check = None            # PFFT.check when GFFT_CHECK=1 (set by PFFT)
 
     @property
     def input_array(self):
@@ -53,6 +54,12 @@ class Transform:
         return self._pencil[1]
 
     def __call__(self, input_array=None, output_array=None, **kw):
+        out = self._run(input_array, output_array, **kw)
+        if self._check is not None:
+            self._check()
+        return out
+
+    def _run(self, input_array=None, output_array=None, **kw):
         """Compute the transform.  Without arguments it works on the planned arrays and returns
         the planned output array (aliasing is part of the contract, mpifft.py:75-79).
         ``normalize=True/False`` overrides the default (forward normalised, backward not).
@@ -255,6 +262,8 @@ class PFFT:
             [o.backward for o in self.xfftn[::-1]],
             [o.backward for o in self.transfer[::-1]],
             self.pencil[::-1], fused_bck, None if self.pipeline is None else (self.pipeline, False))
+        if os.environ.get('GFFT_CHECK', '0') not in ('0', ''):
+            self.forward._check = self.backward._check = self.check
 
     def _plan_pipeline(self, wire, exchange=None):
         """The chunked, stream-overlapped form of this transform (pipeline.py), or None.  `wire`:
@@ -529,6 +538,29 @@ class PFFT:
             bck.execute_scaled(V if src is None else src, U if dst is None else dst, M if normalize else 1.0)
 
         return forward, backward
+
+    def check(self):
+        """Synchronise the device and learn whether every launch of this process since the last look was valid
+        (include/gfft.h gfft_async_error: a fused pass-pair launch voids itself instead of hanging when its workgroups
+        wait too long for one another).  COLLECTIVE over the grid: every rank raises RuntimeError if ANY rank saw a
+        failure -- a rank that raised alone would leave its peers waiting in the next exchange.  Not called by
+        forward / backward (it synchronises); GFFT_CHECK=1 makes every transform end with it."""
+        import torch
+        from . import _lib
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        mine = []
+        while len(mine) < 64:
+            try:
+                _lib.check_async()
+                break
+            except _lib.GfftError as e:
+                mine.append(str(e))
+        parent = next((c.relay_parent for c in self.subcomm if getattr(c, 'relay_parent', None) is not None), None)
+        everyone = [mine] if parent is None else parent.allgather_obj(mine)
+        bad = ['rank %d: %s' % (r, m) for r, ms in enumerate(everyone) for m in ms]
+        if bad:
+            raise _lib.GfftError('; '.join(bad[:4]))
 
     def destroy(self):
         if isinstance(self.subcomm, Subcomm):

@@ -241,6 +241,37 @@ def test_a_pending_failure_is_reported_by_the_next_execute():
     b.destroy()
 
 
+def test_a_voided_launch_stays_with_its_plan_and_two_of_them_are_both_reported():
+    """The event belongs to the plan that voided (include/gfft.h gfft_plan_status): another plan's execute is not
+    refused by it, scalar reads surface it, and two plans voiding before anybody looks are both named."""
+    import torch
+    from mpi4py_fft_amd import _lib, PFFT, comm
+    shape = (1024, 16, 1024)
+    a, f, b = _plans(shape, (0, 1, 2), 1, 8, 4, 21)
+    a2, f2, b2 = _plans(shape, (0, 1, 2), 1, 8, 4, 22)
+    _opts(fuse2_wait_ms=0)
+    f.execute_scaled(a, f.output_array, 1.0)
+    f2.execute_scaled(a2, f2.output_array, 1.0)
+    torch.cuda.synchronize()
+    _opts(fuse2_wait_ms=2000)
+    b.execute_scaled(f.output_array, b.output_array, 1.0)        # an unrelated plan: runs, the events stay pending
+    torch.cuda.synchronize()
+    b.status()
+    with pytest.raises(RuntimeError, match='gave up'):
+        f.status()
+    f.status()                                                   # reported once
+    with pytest.raises(RuntimeError, match='gave up'):
+        f2.output_array[0, 0, 0]                                 # a scalar read synchronises: the other event surfaces here
+    _lib.check_async()
+    # PFFT.check(): synchronise and drain (collective on a grid)
+    p = PFFT(comm.COMM_SELF, (256, 256, 256), dtype='D')
+    p.forward()
+    p.check()
+    p.destroy()
+    for x in (f, b, f2, b2):
+        x.destroy()
+
+
 def test_the_round3_kernel_set_is_still_selectable_and_agrees():
     """fuse2 = 3: the pairs on 16 values per thread / two LDS exchanges (the default, 1, runs 32 values per thread and
     one exchange): same results to rounding, both against numpy."""
