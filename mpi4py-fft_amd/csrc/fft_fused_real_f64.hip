@@ -12,23 +12,24 @@
 
 namespace gfft {
 
+// option c2r_2048: the c2r pair on rows of 2048 reals.  Round 4 measured it losing -- (1024,1024,2048) backward 21.4 -> 28.1 ms,
+// every memory phase of its tiles 2-3 x slower than at 1024 reals -- and left it off, unexplained.  Round 5: the workspace
+// pitch of that shape was 1032 = 8 x 129 entries, the one multiplier the channel hash folds onto itself (plan.cpp
+// plan_fused3, pitch129); on 1040 entries the pair runs 11.8 ms against 5.8 + 6.7 for its two passes, the step 37.85 ->
+// 36.33 ms (profiles/r05_ab_pitch129.txt).
+int g_c2r_2048 = 1;
+
 //                            real    N    R   T  COLS   SPLIT FLAGS                 MODE        BIGTW  radices
 typedef PassCfg<double, 512, 16, 16, false, true, 1 | 2048 | 8192, MODE_R2C_H, false, 16, 8, 4> R2CRows512ToRing;      // 1024 reals per row
 typedef PassCfg<double, 1024, 16, 8, false, true, 1 | 2048 | 8192, MODE_R2C_H, false, 16, 16, 4> R2CRows1024ToRing;    // 2048 reals per row
 typedef PassCfg<double, 512, 16, 16, false, true, 2 | 4096 | 8192, MODE_C2R_H, false, 16, 8, 4> C2RRows512FromRing;
-#ifdef GFFT_VARIANTS
-typedef PassCfg<double, 1024, 16, 8, false, true, 2 | 4096 | 8192, MODE_C2R_H, false, 16, 16, 4> C2RRows1024FromRing;     // (loses: see below)
-#endif
+typedef PassCfg<double, 1024, 16, 8, false, true, 2 | 4096 | 8192, MODE_C2R_H, false, 16, 16, 4> C2RRows1024FromRing;     // 2048 reals per row (option c2r_2048)
 typedef PassCfg<double, 1024, 32, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 32, 32> Cols1024ToRing;
 typedef PassCfg<double, 1024, 32, 16, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 32, 32> Cols1024FromRing;
 
 bool fused2_real_supported_f64(int kind, int n_a, int n_b) {
   if (kind == FUSED_R2C_PLANES) return (n_a == 512 || n_a == 1024) && n_b == 1024;
-  // (c2r rows of 2048 reals -- N = 1024 -- were built and measured: (1024,1024,2048) backward 21.4 -> 28.1 ms, the pair 21.2 ms
-  // against 6.8 + 6.7 for its two passes; the r2c pair of the same shape gains, 13.4 -> 11.4 ms: profiles/r04_real_pairs.txt)
-#ifdef GFFT_VARIANTS
-  if (kind == FUSED_COLS_C2R && n_a == 1024 && n_b == 1024) return getenv("GFFT_C2R_2048") != nullptr;
-#endif
+  if (kind == FUSED_COLS_C2R && n_a == 1024 && n_b == 1024) return g_c2r_2048 != 0;
   if (kind == FUSED_COLS_C2R) return n_a == 1024 && n_b == 512;
   return false;
 }
@@ -41,9 +42,7 @@ int fused2_real_tiles_f64(int kind, const PassDesc &dA, const PassDesc &dB, int 
   }
   if (kind == FUSED_COLS_C2R) {
     *ta = (int)Cols1024ToRing::ntiles(dA);
-#ifdef GFFT_VARIANTS
     if (dB.n == 1024) { *tb = (int)C2RRows1024FromRing::ntiles(dB); return 0; }
-#endif
     *tb = (int)C2RRows512FromRing::ntiles(dB);
     return 0;
   }
@@ -57,9 +56,7 @@ hipError_t launch_fused2_real_f64(int kind, const PassDesc &dA, const PassDesc &
     return launch_fused2<R2CRows1024ToRing, Cols1024FromRing>(dA, dB, dev, f, in, ring, out, s);
   }
   if (kind == FUSED_COLS_C2R) {
-#ifdef GFFT_VARIANTS
     if (dB.n == 1024) return launch_fused2<Cols1024ToRing, C2RRows1024FromRing>(dA, dB, dev, f, in, ring, out, s);
-#endif
     return launch_fused2<Cols1024ToRing, C2RRows512FromRing>(dA, dB, dev, f, in, ring, out, s);
   }
   return hipErrorInvalidValue;

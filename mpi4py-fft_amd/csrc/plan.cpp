@@ -72,6 +72,8 @@ struct Options {
   int real_half = 1;         // contiguous real lines as half-length complex transforms (fft_real_*.hip)
   int debug_flat = 0;        // gfft_debug_pass: tiles over the flattened (mid, inner) index
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
+  int pitch129 = 1;          // 3-D schedules: avoid workspace pitches of 129 x 2^k entries (plan_fused3)
+  int ws_plane_skew = 0;     // 3-D schedules: elements added to the FAR stride of the workspace (planes a little more than n * pitch apart)
   int fuse2 = 1;             // pass pairs in one persistent launch, handed over through the Infinity Cache (fft_fused_f64.hip)
   int fuse2_ring = 0, fuse2_lag = 0;   // slots of the hand-off ring / planes the producer runs ahead; 0 = auto (make_fused2)
   int fuse2_group = 1;       // tiles per ticket
@@ -1170,6 +1172,17 @@ int plan_fused3(gfft_plan_s *pl) {
   const int64_t seg = 128 / esz;      // (R4: rows in whole 256-byte pieces instead measured +1 % on the real fp64 schedule: more padding columns, nothing gained)
   int64_t P = (nc + seg - 1) / seg * seg;
   if ((P * esz) % 2048 == 0) P += 256 / esz;
+  // ... and never 129 x 2^k entries: the far stride of the workspace is a power of two times P, and with P = 129 x 2^k
+  // the rows a far-axis tile walks lie k (2^7 + 1) 2^j bytes apart -- the one multiplier found so far that the address
+  // hash of the memory channels folds onto itself (row k and row k + 2^7 j share their channel).  Measured (round 5,
+  // tools/ab_combo_probe.py ws_plane_skew, profiles/r05_ab_pitch129.txt), far-axis pass alone, same arrays:
+  // (1024,1024,2048) r2c f64 [1025-wide rows, P = 1032] 11.6 -> 7.2 ms; (512,1024,2048) c128 [P = 2064] 14.0 -> 6.4 ms;
+  // (2048,512,2048) r2c f64 18.0 -> 7.8 ms; (1024,1024,4096) r2c f32 [2049-wide, P = 2064] 14.0 -> 8.5 ms; pitches of
+  // 17 / 33 / 65 / 257 x 2^k entries (every other BASELINE-sized shape) are level with or without a skew.
+  if (opts().pitch129) {
+    auto odd = [](int64_t x) { while (x && !(x & 1)) x >>= 1; return x; };
+    while (odd(P) == 129 || (P * esz) % 2048 == 0) P += seg;
+  }
   need(pl, BUF_WS, (size_t)(n0 * n1 * P * esz));
   // columns the in-workspace passes run over: nc rounded up to whole 128-byte lines (the padding
   // columns hold zeros written by the pass that fills W), see PassDesc::inner_ld / inner_st
@@ -1313,6 +1326,13 @@ int plan_fused3(gfft_plan_s *pl) {
   // ... and the workspace then is W[i0][k1][c]: the stand-alone axis-1 pass stores on NEAR strides (stores are
   // what far strides hurt), the fused pair's axis-0 tiles read the far (pitched) ones
   if (pair_cols_rows && opts().fuse2_wlayout) { w_i0 = n1 * P; w_i1 = P; }
+  if (opts().ws_plane_skew > 0) {
+    // (A/B, tools/skew_sweep.py: consecutive planes of the workspace a few lines further apart than rows * pitch, so that
+    // the rows a far-axis tile walks differ in their LOW address bits too)
+    const int64_t sk = opts().ws_plane_skew;
+    (w_i0 > w_i1 ? w_i0 : w_i1) += sk;
+    need(pl, BUF_WS, (size_t)((n0 * n1 * P + (n0 > n1 ? n0 : n1) * sk) * esz));
+  }
   std::vector<Pass> seq;
   if (flat_out) {
     seq.push_back(rows(MODE_R2C, false, true, BUF_IN, BUF_WS));
@@ -1541,8 +1561,11 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "fuse2_wait_ms")) opts().fuse2_wait_ms = value;
   else if (!strcmp(key, "fuse2_f32")) opts().fuse2_f32 = value;
   else if (!strcmp(key, "fuse2_n512")) gfft::g_fuse2_n512 = value;
+  else if (!strcmp(key, "c2r_2048")) gfft::g_c2r_2048 = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
+  else if (!strcmp(key, "ws_plane_skew")) opts().ws_plane_skew = value;
+  else if (!strcmp(key, "pitch129")) opts().pitch129 = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
   else if (!strcmp(key, "debug_tile_side")) opts().debug_tile_side = value;
   else if (!strcmp(key, "debug_tile_stride")) opts().debug_tile_stride = value;

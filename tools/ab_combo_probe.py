@@ -2,7 +2,7 @@
 """Developer probe: clean A/B of COMBINATIONS of libgfft planning options inside a cubic complex128 PFFT -- one plan
 set per combination, all run alternately on the SAME caller arrays (placement moves the step time by several per
 cent), 5 rounds x 10 steps; then the per-pass times of each.
-usage: ab_combo_probe.py [-n 1024] [-d D] "fuse2=1" "fuse2=3,fuse2_defer=2" ...   (the first one is the baseline)"""
+usage: ab_combo_probe.py [-n 1024 | -n 1024x1024x2048] [-d D] "fuse2=1" "fuse2=3,fuse2_defer=2" ...   (the first one is the baseline)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ from mpi4py_fft_amd import PFFT, comm, _lib
 args = sys.argv[1:]
 n, dt = 1024, 'D'
 while args and args[0].startswith('-'):
-    if args[0] == '-n': n = int(args[1])
+    if args[0] == '-n': n = tuple(int(x) for x in args[1].split('x')) if 'x' in args[1] else int(args[1])
     if args[0] == '-d': dt = args[1]
     args = args[2:]
 combos = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in a.split(',') if kv) for a in args]
@@ -22,12 +22,25 @@ ffts = []
 for c in combos:
     for k in keys:
         _lib.set_option(k, c.get(k, base[k]))
-    ffts.append(PFFT(comm.COMM_SELF, (n,) * 3, dtype=dt))
+    ffts.append(PFFT(comm.COMM_SELF, n if isinstance(n, tuple) else (n,) * 3, dtype=dt))
 for k in keys:
     _lib.set_option(k, base[k])
 u, w = ffts[0].forward.input_array, ffts[0].forward.output_array
 (torch.view_as_real(u.tensor) if u.tensor.is_complex() else u.tensor).normal_()
 tot = [[] for _ in combos]
+# every combination computes the same transform: forward outputs against the baseline's
+ref = None
+for i, f in enumerate(ffts):
+    f.forward(u, w)
+    torch.cuda.synchronize()
+    if ref is None:
+        ref = w.tensor.clone()
+    else:
+        d = float((torch.view_as_real(w.tensor) - torch.view_as_real(ref)).abs().max().item())
+        m = float(torch.view_as_real(ref).abs().max().item())
+        print('%-40s forward max|diff| vs baseline %.2e (max|ref| %.2e)' % (args[i], d, m), flush=True)
+    f.backward(w, u)
+del ref
 for rnd in range(5):
     for i, f in enumerate(ffts):
         f.forward(u, w); f.backward(w, u)
@@ -48,4 +61,9 @@ for i, f in enumerate(ffts):
     torch.cuda.synchronize()
     if f._fused_plans:
         print('%-40s forward passes:' % args[i], ', '.join('%s %.3f ms' % (name, ms / max(k, 1)) for name, nb, ms, k in f._fused_plans[0].profile()), flush=True)
+    for _ in range(5):
+        f.backward(w, u)
+    torch.cuda.synchronize()
+    if f._fused_plans:
+        print('%-40s backward passes:' % args[i], ', '.join('%s %.3f ms' % (name, ms / max(k, 1)) for name, nb, ms, k in f._fused_plans[1].profile()), flush=True)
 _lib.set_option('profile', 0)
