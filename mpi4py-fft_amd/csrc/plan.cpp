@@ -73,6 +73,7 @@ struct Options {
   int debug_flat = 0;        // gfft_debug_pass: tiles over the flattened (mid, inner) index
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
   int pitch129 = 1;          // 3-D schedules: avoid workspace pitches of 129 x 2^k entries (plan_fused3)
+  int pitch_extra = 0;       // A/B: lines (128 B) added to the workspace pitch
   int ws_plane_skew = 0;     // 3-D schedules: elements added to the FAR stride of the workspace (planes a little more than n * pitch apart)
   int fuse2 = 1;             // pass pairs in one persistent launch, handed over through the Infinity Cache (fft_fused_f64.hip)
   int fuse2_ring = 0, fuse2_lag = 0;   // slots of the hand-off ring / planes the producer runs ahead; 0 = auto (make_fused2)
@@ -378,6 +379,7 @@ struct gfft_plan_s {
   double flops = 0, bytes = 0;
   int variant_rows = 0, variant_cols = 0, xcd_swizzle = 0;
   bool fused3 = false;
+  int64_t ws_pitch = 0;                        // plan_fused3: entries between consecutive rows of the workspace
   std::vector<int64_t> trunc;                  // gfft_plan_create_padded: kept entries per axis (else empty)
   std::vector<std::vector<hipEvent_t>> prof;   // per execute: events before pass 0 and after each pass
   std::vector<void *> device_allocs;            // small device buffers the plan owns (descriptors of fused launches)
@@ -1183,7 +1185,9 @@ int plan_fused3(gfft_plan_s *pl) {
     auto odd = [](int64_t x) { while (x && !(x & 1)) x >>= 1; return x; };
     while (odd(P) == 129 || (P * esz) % 2048 == 0) P += seg;
   }
+  if (opts().pitch_extra > 0) P += (int64_t)opts().pitch_extra * seg;        // (A/B: tools/ab_combo_probe.py pitch_extra=...)
   need(pl, BUF_WS, (size_t)(n0 * n1 * P * esz));
+  pl->ws_pitch = P;
   // columns the in-workspace passes run over: nc rounded up to whole 128-byte lines (the padding
   // columns hold zeros written by the pass that fills W), see PassDesc::inner_ld / inner_st
   const int64_t Pu = (nc + seg - 1) / seg * seg;
@@ -1566,6 +1570,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "ws_plane_skew")) opts().ws_plane_skew = value;
   else if (!strcmp(key, "pitch129")) opts().pitch129 = value;
+  else if (!strcmp(key, "pitch_extra")) opts().pitch_extra = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
   else if (!strcmp(key, "debug_tile_side")) opts().debug_tile_side = value;
   else if (!strcmp(key, "debug_tile_stride")) opts().debug_tile_stride = value;
@@ -2299,8 +2304,10 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
   char line[256];
   const char *kn = pl->kind == GFFT_C2C_FORWARD ? "c2c-forward" : pl->kind == GFFT_C2C_BACKWARD ? "c2c-backward"
                    : pl->kind == GFFT_R2C ? "r2c" : "c2r";
+  char sched[96] = "";
+  if (pl->fused3) snprintf(sched, sizeof sched, " [3-D schedule: padded-pitch workspace, rows %lld entries apart]", (long long)pl->ws_pitch);
   snprintf(line, sizeof line, "gfft plan: %s %s, %d dims, %zu passes%s\n", kn, pl->precision == 8 ? "f64" : "f32",
-           pl->ndims, pl->passes.size(), pl->fused3 ? " [3-D schedule: padded-pitch workspace]" : "");
+           pl->ndims, pl->passes.size(), sched);
   s += line;
   static const char *bufn[] = {"IN", "OUT", "WS", "FS", "AUX", "RING"};
   for (const Pass &p : pl->passes) {

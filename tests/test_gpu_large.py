@@ -111,7 +111,10 @@ def test_1024cubed_roundtrip_c128():
     fft.destroy()
 
 
-@pytest.mark.parametrize('shape', [(128, 128, 128), (64, 128, 256), (256, 64, 128), (128, 256, 64), (32, 512, 1024)])
+# ((64, 128, 2048) / (32, 64, 4096): 1025- and 2049-wide half spectra and 2048-long complex rows, whose line-rounded
+# workspace pitches used to be 129 x 2^k entries -- the pitch rule of plan_fused3)
+@pytest.mark.parametrize('shape', [(128, 128, 128), (64, 128, 256), (256, 64, 128), (128, 256, 64), (32, 512, 1024), (64, 128, 2048),
+                                   (32, 64, 4096)])
 @pytest.mark.parametrize('dt', list('DdFf'))
 def test_single_rank_3d_schedule_vs_oracle(shape, dt):
     """The fused single-GPU schedule (reordered passes + padded workspace, plan.cpp:plan_fused3)
@@ -122,7 +125,16 @@ def test_single_rank_3d_schedule_vs_oracle(shape, dt):
     _lib.set_option('fused3_min_mib', 0)
     try:
         fft = PFFT(comm.COMM_SELF, shape, dtype=dt)
-        assert 'padded-pitch workspace' in fft._fused_plans[0]._eng.plan_describe(fft._fused_plans[0]._plan)
+        desc = fft._fused_plans[0]._eng.plan_describe(fft._fused_plans[0]._plan)
+        assert 'padded-pitch workspace' in desc
+        # the workspace pitch: whole 128-byte lines, never a multiple of 2 KiB, never 129 x 2^k entries (channel aliasing)
+        import re
+        pitch = int(re.search(r'rows (\d+) entries apart', desc).group(1))
+        isz = {'D': 16, 'd': 16, 'F': 8, 'f': 8}[dt]
+        odd = pitch
+        while odd % 2 == 0:
+            odd //= 2
+        assert pitch >= fft.forward.output_array.shape[2] and (pitch * isz) % 128 == 0 and (pitch * isz) % 2048 and odd != 129, desc
         G = O.rng_array(shape, dt, 99)
         u = newDistArray(fft, False)
         u[...] = G
