@@ -376,7 +376,9 @@ class _Aligned:
         CS0 = p0 * BS0                          # one chunk region on the strided stage's side
         # ---- geometry of T1
         bw1, tw1 = Wq - Wq % TW, Wq % TW            # (the same split as T0's: a stage between the two sees one body)
-        E = _pitch(N1b * Wq, isz)
+        # body rows of a T1 slab lie RP entries apart: bw1 (whole lines already), plus GFFT_T1_ROWPAD entries (A/B, tools/stage_probe.py)
+        RP = bw1 + (int(os.environ.get('GFFT_T1_ROWPAD', 0)) if bw1 else 0)
+        E = _pitch(N1b * (RP + tw1), isz)
         BS1 = N0 * E
         CS1 = p1 * BS1
         self.E = E
@@ -432,10 +434,10 @@ class _Aligned:
                         off=0 if body else N1 * bw0, g=N1 * W)
 
         def t1_side1(body):         # stage 1's view of T1: axis 1 cut into p1 blocks, slabs i0 E apart
-            return dict(es=bw1 if body else tw1, blocks=p1, bstride=BS1, tile=None, off=0 if body else N1b * bw1, g=E)
+            return dict(es=RP if body else tw1, blocks=p1, bstride=BS1, tile=None, off=0 if body else N1b * RP, g=E)
 
         def t1_side2(body):         # stage 2's view of T1: axis 0 = (peer, slab), rows i1 inside a slab
-            return dict(es=E, blocks=p1, bstride=BS1, tile=None, off=0 if body else N1b * bw1, g=bw1 if body else tw1)
+            return dict(es=E, blocks=p1, bstride=BS1, tile=None, off=0 if body else N1b * RP, g=RP if body else tw1)
 
         def nat_side(shape, ax, g, col0):
             st = _cstrides(shape)
@@ -514,7 +516,7 @@ class _Aligned:
                 a, c = t1_side2(bw1 > 0), nat_side(sh2, 0, 1, 0)       # (no body at all: the leftover rows are the rows)
                 hf = s2f.own(eng.plan_create_guru(prec, -1, (M0, a['es'], c['es']), [(1, 0, 0), (N1b, a['g'], c['g']), (W, 1, 1)],
                                                   p1, BS1, 1, 0))
-                if not (hf and eng.plan_set_flat(hf, bw1, N1b * bw1, tw1)):
+                if not (hf and eng.plan_set_flat(hf, bw1, N1b * RP, tw1)):
                     s2f.plan = None
                 s2f.steps[0].append((hf, 0, 0))
             col = 0
@@ -550,7 +552,7 @@ class _Aligned:
             e1['A'] = dict(chunk=CS1 * isz, sizes=[BS1 * isz] * p1)
             e1['B'] = dict(chunk=CS1 * isz, sizes=[BS1 * isz] * p1)
             # what a rank whose local width is `w` sends per peer (routed exchanges need every rank's sizes)
-            e1['block_bytes'] = lambda w, N0=N0, N1b=N1b, K1=K1: N0 * _pitch(N1b * (w // K1), isz) * isz
+            e1['block_bytes'] = lambda w, N0=N0, N1b=N1b, K1=K1, pad=RP - bw1: N0 * _pitch(N1b * (w // K1 + (pad if (w // K1) >= TW else 0)), isz) * isz
             self.t1_elems = K1 * CS1
         self.ok = True
 

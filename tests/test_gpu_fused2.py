@@ -71,7 +71,7 @@ def test_fused_3d_schedule_matches_the_unfused_one(shape, dt):
         b1.destroy()
 
 
-@pytest.mark.parametrize('shape,dt', [((32, 1 << 20), 'D')])
+@pytest.mark.parametrize('shape,dt', [((32, 1 << 20), 'D'), ((64, 1 << 20), 'F')])      # (complex64: round 5, csrc/fft_fused_f32.hip)
 def test_fused_four_step_matches_the_two_launch_form(shape, dt):
     from mpi4py_fft_amd import _lib
     rng = np.random.default_rng(6)
@@ -108,31 +108,33 @@ def test_shapes_without_a_paying_pair_keep_the_unfused_plans():
         b.destroy()
 
 
-def test_fused_batched_2d_transform():
+@pytest.mark.parametrize('dt', ['D', 'F'])
+def test_fused_batched_2d_transform(dt):
     """fftn over the last two axes of a 3-D array (the leading stage of a slab-decomposed PFFT with
     collapse=True): [rows] -> [columns] plane by plane in one launch."""
     from mpi4py_fft_amd import _lib
     shape = (24, 1024, 1024)
     rng = np.random.default_rng(8)
-    x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
-    a0, f0, b0 = _plans(shape, (1, 2), 0)
+    x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dt)
+    eps = 1e-13 if dt == 'D' else 1e-5
+    a0, f0, b0 = _plans(shape, (1, 2), 0, dt=dt)
     a0[...] = x
     want = np.asarray(f0.execute_scaled(a0, f0.output_array, 1.0)).copy()
-    ref = np.fft.fftn(x[:3], axes=(1, 2))
-    assert np.abs(want[:3] - ref).max() <= 2e-10 * np.abs(ref).max()
+    ref = np.fft.fftn(x[:3].astype('D'), axes=(1, 2))
+    assert np.abs(want[:3] - ref).max() <= (2e-10 if dt == 'D' else 2e-4) * np.abs(ref).max()
     f0.destroy()
     b0.destroy()
     for ring, lag in ((8, 4), (4, 2), (12, 6)):
         if shape[0] < 2 * ring:
             continue
-        a1, f1, b1 = _plans(shape, (1, 2), 1, ring, lag)
+        a1, f1, b1 = _plans(shape, (1, 2), 1, ring, lag, dt=dt)
         assert 'fused pair (2-D planes' in _lib.engine().plan_describe(f1._plan)
         a1[...] = x
         for rep in range(3):
             got = np.asarray(f1.execute_scaled(a1, f1.output_array, 1.0))
-            assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), (ring, lag, rep)
+            assert np.abs(got - want).max() <= eps * np.abs(want).max(), (ring, lag, rep)
             back = np.asarray(b1.execute_scaled(f1.output_array, b1.output_array, 1.0 / (1024 * 1024)))
-            assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
+            assert np.abs(back - x).max() <= 10 * eps * np.abs(x).max()
         f1.destroy()
         b1.destroy()
 
@@ -315,7 +317,8 @@ def test_fused_pairs_of_real_transforms(shape):
         df, db = _lib.engine().plan_describe(f._plan), _lib.engine().plan_describe(b._plan)
         if fuse:
             assert ('fused pair (r2c rows -> strided)' in df) == (shape[1] == 1024), df
-            assert ('fused pair (strided -> c2r rows)' in db) == (shape[0] == 1024 and shape[2] == 1024), db
+            # (rows of 2048 reals too since round 5: option c2r_2048, on once the workspace pitch stopped aliasing)
+            assert ('fused pair (strided -> c2r rows)' in db) == (shape[0] == 1024), db
         else:
             assert 'fused pair' not in df + db
         a[...] = x

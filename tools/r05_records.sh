@@ -1,0 +1,22 @@
+# round 5 records: A/B of the workspace-pitch rule and the c2r pair of 2048-real rows (same arrays, plans alternating)
+mkdir -p gpurun_out/r05r
+{
+echo "# tools/ab_combo_probe.py, one box, same caller arrays per shape, plan sets alternating (5 rounds x 10 steps), then per-pass times"
+echo "# pitch129=0: workspace pitch = width rounded up to 128-byte lines (+256 B off multiples of 2 KiB) -- 1032 / 2064 entries = 129 x 2^k for these shapes"
+echo "# pitch129=1 (default since round 5): the next pitch whose odd part is not 129 (1040 / 2080 = 65 x 2^k)"
+echo "# ws_plane_skew=16: the old pitch with consecutive workspace planes 256 bytes further apart (what located the effect)"
+for spec in "1024x1024x2048 d" "2048x512x2048 d" "512x1024x2048 D" "1024x1024x4096 f"; do
+  set -- $spec
+  echo "== shape $1 dtype $2"
+  python tools/ab_combo_probe.py -n $1 -d $2 "pitch129=0,ws_plane_skew=0" "pitch129=1" "pitch129=0,ws_plane_skew=16" 2>&1 | grep -v "^/opt\|AMD Radeon"
+done
+echo "== the c2r pair on rows of 2048 reals (option c2r_2048), under both pitches: shape 1024x1024x2048 dtype d"
+python tools/ab_combo_probe.py -n 1024x1024x2048 -d d "c2r_2048=0,pitch129=1" "c2r_2048=1" "c2r_2048=1,pitch129=0" "c2r_2048=0,pitch129=0" 2>&1 | grep -v "^/opt\|AMD Radeon"
+echo "== shapes whose pitches are 17 / 33 / 65 / 257 x 2^k entries: a plane skew changes nothing (or loses)"
+for spec in "1024x1024x1024 D" "1024x1024x1024 d" "1024x1024x512 d" "512x512x4096 D"; do
+  set -- $spec
+  echo "== shape $1 dtype $2"
+  python tools/ab_combo_probe.py -n $1 -d $2 "ws_plane_skew=0" "ws_plane_skew=16" 2>&1 | grep -v "^/opt\|AMD Radeon"
+done
+} > gpurun_out/r05r/ab_pitch129.txt 2>&1
+tail -5 gpurun_out/r05r/ab_pitch129.txt
