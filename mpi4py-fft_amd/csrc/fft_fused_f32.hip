@@ -13,41 +13,42 @@ typedef PassCfg<float, 1024, 32, 32, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, 
 typedef PassCfg<float, 1024, 16, 16, false, false, 2 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> RowsFromRingF32;    // a row per wave
 
 // Round 5: the other kinds on the same two tile shapes -- 32 adjacent columns on 32 values per thread (256-byte hand-off
-// segments), 16 rows with a row inside one wave --: the four-step pairs of a length-2^20 transform (config C2 in
-// complex64: 128 x 2^20 ran as two launches at 0.245 of the 2 S roofline) and the batched 2-D pair on contiguous planes.
+// segments), 16 rows with a row inside one wave --: the four-step pair of a length-2^20 transform and the batched 2-D pair
+// on contiguous planes.  Same arrays, plans alternating (tools/serial_ab_probe.py, profiles/r05_c2_c64_pairs.txt):
+//   128 x 2^20 complex64 (config C2's shape in fp32): two launches 1.097 ms -> [strided -> strided] pair 0.979 ms (-10.8 %);
+//     the [strided -> rows, transposed on store] form that complex128 prefers: 1.009 ms (its first pass spills 128 bytes
+//     at 32 values per thread + four-step twiddle in 128 VGPRs) -- not built into the product;
+//   (256,1024,1024) complex64 over axes (1, 2): 1.817 -> 1.567 ms (-13.7 %).
+// Half the bytes per butterfly of complex128: the LDS exchanges (4-byte planes, twice the DS instructions per byte) and the
+// butterflies weigh twice as much in a tile, and one resident workgroup per CU cannot overlap them with its memory phases.
 struct Fused1024F32 {
   typedef PassCfg<float, 1024, 16, 16, false, false, 1 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> RowsToRing;
-  typedef RowsFromRingF32 RowsFromRing;
-  typedef ColsToRingF32 ColsToRing;
   typedef PassCfg<float, 1024, 32, 32, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> ColsFromRing;
   typedef PassCfg<float, 1024, 32, 32, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirst;
-  typedef PassCfg<float, 1024, 32, 32, true, true, 1 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirstNat;
-  typedef PassCfg<float, 1024, 16, 16, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> RowsFromRingT;      // (the transposing store works on split planes)
 };
-
-// the four-step first passes on the stand-alone table's shape instead -- 16 columns on 16 values per thread, 128-byte
-// hand-off segments, no spills -- (option fuse2_f32 = 3; A/B)
-struct Fused1024F32Lean : Fused1024F32 {
-  typedef PassCfg<float, 1024, 16, 16, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirst;
-  typedef PassCfg<float, 1024, 16, 16, true, true, 1 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirstNat;
-};
-int g_fuse2_f32_lean = 0;
 
 bool fused2_supported_f32(int kind, int n_a, int n_b) {
   if (n_a != 1024 || n_b != 1024) return false;
-  return kind == FUSED_COLS_ROWS || kind == FUSED_FOURSTEP || kind == FUSED_FOURSTEP_ROWS || kind == FUSED_PLANES_2D;
+  return kind == FUSED_COLS_ROWS || kind == FUSED_FOURSTEP || kind == FUSED_PLANES_2D;
 }
 
 int fused2_tiles_f32(int kind, const PassDesc &dA, const PassDesc &dB, int *ta, int *tb) {
-  if (g_fuse2_f32_lean) return fused2_tiles_kind<Fused1024F32Lean>(kind, dA, dB, ta, tb);
-  return fused2_tiles_kind<Fused1024F32>(kind, dA, dB, ta, tb);
+  switch (kind) {
+    case FUSED_COLS_ROWS: *ta = (int)ColsToRingF32::ntiles(dA); *tb = (int)RowsFromRingF32::ntiles(dB); return 0;
+    case FUSED_FOURSTEP: *ta = (int)Fused1024F32::FourStepFirst::ntiles(dA); *tb = (int)Fused1024F32::ColsFromRing::ntiles(dB); return 0;
+    case FUSED_PLANES_2D: *ta = (int)Fused1024F32::RowsToRing::ntiles(dA); *tb = (int)Fused1024F32::ColsFromRing::ntiles(dB); return 0;
+  }
+  return -1;
 }
 
 hipError_t launch_fused2_f32(int kind, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev, const FusedDesc &f,
                              const void *in, void *ring, void *out, hipStream_t s) {
-  if (kind == FUSED_ROWS_COLS) return hipErrorInvalidValue;          // (not built: the forward order the 3-D schedule does not take)
-  if (g_fuse2_f32_lean && (kind == FUSED_FOURSTEP || kind == FUSED_FOURSTEP_ROWS)) return launch_fused2_kind<Fused1024F32Lean>(kind, dA, dB, dev, f, in, ring, out, s);
-  return launch_fused2_kind<Fused1024F32>(kind, dA, dB, dev, f, in, ring, out, s);
+  switch (kind) {
+    case FUSED_COLS_ROWS: return launch_fused2<ColsToRingF32, RowsFromRingF32>(dA, dB, dev, f, in, ring, out, s);
+    case FUSED_FOURSTEP: return launch_fused2<Fused1024F32::FourStepFirst, Fused1024F32::ColsFromRing>(dA, dB, dev, f, in, ring, out, s);
+    case FUSED_PLANES_2D: return launch_fused2<Fused1024F32::RowsToRing, Fused1024F32::ColsFromRing>(dA, dB, dev, f, in, ring, out, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace gfft

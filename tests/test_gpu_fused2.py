@@ -87,7 +87,8 @@ def test_fused_four_step_matches_the_two_launch_form(shape, dt):
     # kinds 15: [strided + transposing store] -> [strided]; 31: [strided] -> [rows + transposing store] (the default)
     for ring, lag, kinds in ((8, 4, 15), (4, 1, 15), (16, 8, 15), (8, 4, 31), (4, 1, 31), (12, 6, 31), (0, 0, 31)):
         a1, f1, b1 = _plans(shape, (1,), 1, ring, lag, kinds, dt=dt)
-        assert ('fused pair (four-step)' if kinds == 15 else 'fused pair (four-step: strided -> rows') in _lib.engine().plan_describe(f1._plan)
+        # (complex64 has the [strided -> strided] form only: measured ahead of the other one, csrc/fft_fused_f32.hip)
+        assert ('fused pair (four-step)' if (kinds == 15 or dt == 'F') else 'fused pair (four-step: strided -> rows') in _lib.engine().plan_describe(f1._plan)
         a1[...] = x
         for rep in range(3):
             got = np.asarray(f1.execute_scaled(a1, f1.output_array, 1.0))

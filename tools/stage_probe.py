@@ -34,7 +34,7 @@ def run_case(name, prec, real0, sh0, nh, sh1, sh2, p0, K0, widths, p1, K1):
     isz = 2 * prec
     stages = [fake_stage(2, sh0, sh0[:2] + (nh,)), fake_stage(1, sh1), fake_stage(0, sh2)]
     eng = _lib.engine()
-    nbuf = int(max(np.prod(sh1), np.prod(sh2), np.prod(sh0[:2]) * nh) * 1.02) + (1 << 20)
+    nbuf = int(max(np.prod(sh1), np.prod(sh2), np.prod(sh0[:2]) * nh) * 1.25) + (1 << 20)
     cdt = torch.complex64 if prec == 4 else torch.complex128
     a = torch.randn(nbuf, dtype=cdt, device='cuda')
     b = torch.empty_like(a)
