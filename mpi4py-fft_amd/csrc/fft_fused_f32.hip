@@ -14,7 +14,7 @@ typedef PassCfg<float, 1024, 16, 16, false, false, 2 | 4096 | 8192, MODE_C2C, fa
 
 // Round 5: the other kinds on the same two tile shapes -- 32 adjacent columns on 32 values per thread (256-byte hand-off
 // segments), 16 rows with a row inside one wave --: the four-step pair of a length-2^20 transform and the batched 2-D pair
-// on contiguous planes.  Same arrays, plans alternating (tools/serial_ab_probe.py, profiles/r05_c2_c64_pairs.txt):
+// on contiguous planes.  Same arrays, plans alternating (tools/serial_ab_probe.py, profiles/r05_c2_pairs.txt):
 //   128 x 2^20 complex64 (config C2's shape in fp32): two launches 1.097 ms -> [strided -> strided] pair 0.979 ms (-10.8 %);
 //     the [strided -> rows, transposed on store] form that complex128 prefers: 1.009 ms (its first pass spills 128 bytes
 //     at 32 values per thread + four-step twiddle in 128 VGPRs) -- not built into the product;

@@ -1,0 +1,43 @@
+// fp32 (complex64) one-pass kernels for lengths 3 x 5 x 2^k, 3^2 x 5 x 2^k, 3 x 5^2 x 2^k (240 ... 3840): see
+// fft_mix15_f64.hip.  A complex64 is 8 bytes, so the strided kernels take up to 32 values per thread (the radix-15 stage
+// keeps 30 of them) and 32 adjacent columns where the length divides by both 30 and 32.
+#include "fft_pow2_impl.h"
+
+namespace gfft {
+
+#define X32(N, R, T, COLS, MINW, ...) \
+  launch_pow2_inst<float, N, R, T, COLS, true, MINW, 8, __VA_ARGS__>(d, in, out, s)
+
+hipError_t launch_mix15_f32(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s) {
+  if (d.mode != MODE_C2C) return hipErrorInvalidValue;
+  if (!cols) {
+    switch (d.n) {
+      case 240: return X32(240, 16, 16, false, 1, 15, 16);
+      case 480: return X32(480, 16, 8, false, 1, 15, 16, 2);
+      case 960: return X32(960, 16, 4, false, 1, 15, 16, 4);
+      case 1920: return X32(1920, 16, 2, false, 1, 15, 16, 8);
+      case 3840: return X32(3840, 16, 1, false, 1, 15, 16, 16);
+      case 720: return X32(720, 16, 8, false, 1, 15, 3, 16);
+      case 1440: return X32(1440, 16, 4, false, 1, 15, 3, 16, 2);
+      case 2880: return X32(2880, 16, 2, false, 1, 15, 3, 16, 4);
+      case 1200: return X32(1200, 16, 4, false, 1, 15, 5, 16);
+      case 2400: return X32(2400, 16, 2, false, 1, 15, 5, 16, 2);
+    }
+  } else {
+    switch (d.n) {
+      case 240: return X32(240, 16, 32, true, 1, 15, 16);
+      case 480: return X32(480, 32, 32, true, 1, 15, 16, 2);
+      case 960: return X32(960, 32, 32, true, 4, 15, 16, 4);
+      case 1920: return X32(1920, 32, 16, true, 4, 15, 16, 8);
+      case 3840: return X32(3840, 32, 8, true, 4, 15, 16, 16);
+      case 720: return X32(720, 16, 16, true, 4, 15, 3, 16);
+      case 1440: return X32(1440, 32, 16, true, 4, 15, 3, 16, 2);
+      case 2880: return X32(2880, 32, 8, true, 4, 15, 3, 16, 4);
+      case 1200: return X32(1200, 16, 8, true, 4, 15, 5, 16);
+      case 2400: return X32(2400, 32, 8, true, 4, 15, 5, 16, 2);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace gfft

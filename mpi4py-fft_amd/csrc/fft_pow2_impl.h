@@ -316,8 +316,27 @@ template <typename real, int S> __device__ __forceinline__ void dft20(cx<real> *
   for (int k = 0; k < 20; ++k) v[k * S] = o[k];
 }
 
+// radix 15 = 3 x 5 by the prime-factor map (3 and 5 coprime: no twiddles inside): input n = (5 n1 + 3 n2) mod 15, output
+// k = (10 k1 + 6 k2) mod 15, W15^(n k) = W3^(n1 k1) W5^(n2 k2); the index maps are compile-time register renamings
+template <typename real, int S> __device__ __forceinline__ void dft15(cx<real> *v) {
+  cx<real> a[15];
+#pragma unroll
+  for (int n1 = 0; n1 < 3; ++n1)
+#pragma unroll
+    for (int n2 = 0; n2 < 5; ++n2) a[n1 * 5 + n2] = v[((5 * n1 + 3 * n2) % 15) * S];
+#pragma unroll
+  for (int n1 = 0; n1 < 3; ++n1) dft5<real, 1>(a + n1 * 5);
+#pragma unroll
+  for (int k2 = 0; k2 < 5; ++k2) dft3<real, 5>(a + k2);
+#pragma unroll
+  for (int k1 = 0; k1 < 3; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < 5; ++k2) v[((10 * k1 + 6 * k2) % 15) * S] = a[k1 * 5 + k2];
+}
+
 template <typename real, int r, int S> __device__ __forceinline__ void dft(cx<real> *v) {
-  static_assert(r == 2 || r == 3 || r == 4 || r == 5 || r == 8 || r == 10 || r == 12 || r == 16 || r == 20 || r == 32 || r == 64, "radix");
+  static_assert(r == 2 || r == 3 || r == 4 || r == 5 || r == 8 || r == 10 || r == 12 || r == 15 || r == 16 || r == 20 || r == 32 || r == 64, "radix");
+  if constexpr (r == 15) { dft15<real, S>(v); return; }
   if constexpr (r == 2) dft2<real, S>(v);
   else if constexpr (r == 3) dft3<real, S>(v);
   else if constexpr (r == 4) dft4<real, S>(v);
@@ -376,6 +395,22 @@ __device__ __forceinline__ void twiddle(cx<real> *v, int k, const cx<real> *__re
   v[1 * S] = cmul(v[1 * S], w1);
   if constexpr (r == 3) {
     v[2 * S] = cmul(v[2 * S], tw[2 * k * step]);
+  } else if constexpr (r == 15) {
+    const cx<real> w2 = tw[2 * k * step], w4 = tw[4 * k * step], w8 = tw[8 * k * step];
+    const cx<real> w3 = cmul(w1, w2), w12 = cmul(w4, w8);
+    v[2 * S] = cmul(v[2 * S], w2);
+    v[3 * S] = cmul(v[3 * S], w3);
+    v[4 * S] = cmul(v[4 * S], w4);
+    v[5 * S] = cmul(v[5 * S], cmul(w1, w4));
+    v[6 * S] = cmul(v[6 * S], cmul(w2, w4));
+    v[7 * S] = cmul(v[7 * S], cmul(w3, w4));
+    v[8 * S] = cmul(v[8 * S], w8);
+    v[9 * S] = cmul(v[9 * S], cmul(w1, w8));
+    v[10 * S] = cmul(v[10 * S], cmul(w2, w8));
+    v[11 * S] = cmul(v[11 * S], cmul(w3, w8));
+    v[12 * S] = cmul(v[12 * S], w12);
+    v[13 * S] = cmul(v[13 * S], cmul(w1, w12));
+    v[14 * S] = cmul(v[14 * S], cmul(w2, w12));
   } else if constexpr (r == 5 || r == 10 || r == 20) {
     // binary bases from the table, the rest composed: w^m = prod over set bits of m
     const cx<real> w2 = tw[2 * k * step], w4 = tw[4 * k * step];
@@ -573,6 +608,120 @@ struct Stage<real, N, R, SPLIT, WL, PADSH, Ns, r, REST...> {
       }
       GFFT_PHASE(PH + 1)
       Stage<real, N, R, SPLIT, WL, PADSH, Ns * r, REST...>::run(v, t, col, tw);
+    }
+  }
+};
+
+// ---- stages that do not all keep the same number of values per thread ----------------------------------------
+// A stage of radix r works on R_s = (R / r) * r values per thread: R itself when r divides R (every plan of rounds 1-4),
+// fewer otherwise -- n = 960 = 15 x 16 x 4 on R = 16: the radix-15 stage keeps 15 values in each of 64 threads per
+// column, the radix-16 and radix-4 stages 16 values in 60.  A column then takes TPC = max_s n / R_s threads, of which
+// stage s uses the first n / R_s; the LDS exchange between two stages is written in the geometry of the one and read in
+// the geometry of the other, and the pass loads in the first stage's geometry and stores in the last one's.
+// (What makes 3 x 5 x 2^k lengths one-pass lengths: a single R would have to be a multiple of 15 AND of 16.)
+template <int N, int R, int... RADS> struct Geo {
+  static constexpr int cnt = (int)sizeof...(RADS);
+  static constexpr int rad(int i) {
+    constexpr int r[] = {RADS..., 1};
+    return r[i];
+  }
+  static constexpr int Rs(int i) { return (R / rad(i)) * rad(i); }
+  static constexpr int RL = cnt ? Rs(0) : R;                      // values per thread on the load side
+  static constexpr int RS = cnt ? Rs(cnt ? cnt - 1 : 0) : R;      // ... on the store side
+  static constexpr int tpc() {
+    int m = N / R;
+    for (int i = 0; i < cnt; ++i)
+      if (N / Rs(i) > m) m = N / Rs(i);
+    return m;
+  }
+  static constexpr int TPC = tpc();                               // threads per column
+  static constexpr bool uniform() {
+    for (int i = 0; i < cnt; ++i)
+      if (Rs(i) != R) return false;
+    return true;
+  }
+  static constexpr bool UNIFORM = uniform();
+};
+
+template <typename real, int N, int R, bool SPLIT, int Ns, int... RADS> struct StageV;
+template <typename real, int N, int R, bool SPLIT, int Ns> struct StageV<real, N, R, SPLIT, Ns> {
+  static __device__ __forceinline__ void run(cx<real> *, int, void *, const cx<real> *) {}
+};
+template <typename real, int N, int R, bool SPLIT, int Ns, int r, int... REST>
+struct StageV<real, N, R, SPLIT, Ns, r, REST...> {
+  static constexpr int RC = (R / r) * r;      // values per thread in this stage
+  static constexpr int NT = N / RC;           // threads per column at work in it
+  static constexpr int NB = RC / r;           // butterflies per thread
+  static constexpr int RNX = FirstRadix<REST...>::value;
+  static constexpr int RN = RNX ? (R / RNX) * RNX : RC;       // the next stage's values per thread ...
+  static constexpr int NTN = N / RN;                          // ... and threads
+  static __device__ __forceinline__ void run(cx<real> *v, int t, void *col, const cx<real> *__restrict__ tw) {
+    static_assert(RC >= r && N % RC == 0 && N % (Ns * r) == 0, "bad radix plan");
+    const bool mine = t < NT;
+    if (mine) {
+      if constexpr (Ns > 1) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) twiddle<real, N, r, Ns, NB>(v + i, (t + i * NT) % Ns, tw);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) dft<real, r, NB>(v + i);
+    }
+    if constexpr (sizeof...(REST) > 0) {
+      // butterfly j = t + i NT, output m -> slot (j / Ns) Ns r + j % Ns + m Ns (the Stockham autosort scatter); the next
+      // stage's thread t reads its slots t + q NTN.  No slot padding: these lengths scatter with odd multiples.
+      int wbase[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int j = t + i * NT;
+        wbase[i] = (j / Ns) * (Ns * r) + (j % Ns);
+      }
+      const bool next = t < NTN;
+      if constexpr (SPLIT) {
+        real *w = reinterpret_cast<real *>(col);
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+          for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int m = 0; m < r; ++m) w[wbase[i] + m * Ns] = v[i + m * NB].x;
+        }
+        __syncthreads();
+        if (next) {
+#pragma unroll
+          for (int q = 0; q < RN; ++q) v[q].x = w[t + q * NTN];
+        }
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+          for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int m = 0; m < r; ++m) w[wbase[i] + m * Ns] = v[i + m * NB].y;
+        }
+        __syncthreads();
+        if (next) {
+#pragma unroll
+          for (int q = 0; q < RN; ++q) v[q].y = w[t + q * NTN];
+        }
+      } else {
+        float2 *w = reinterpret_cast<float2 *>(col);
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+          for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int m = 0; m < r; ++m) w[wbase[i] + m * Ns] = make_float2(v[i + m * NB].x, v[i + m * NB].y);
+        }
+        __syncthreads();
+        if (next) {
+#pragma unroll
+          for (int q = 0; q < RN; ++q) {
+            const float2 f = w[t + q * NTN];
+            v[q].x = f.x;
+            v[q].y = f.y;
+          }
+        }
+      }
+      StageV<real, N, R, SPLIT, Ns * r, REST...>::run(v, t, col, tw);
     }
   }
 };
@@ -907,7 +1056,7 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
 }
 
 template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int MODE, bool BIGTW, int... RADS>
-__global__ void __launch_bounds__(T *(N / R), MINW)
+__global__ void __launch_bounds__((T * Geo<N, R, RADS...>::TPC), MINW)
 fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // Tile order.  Plain: tile = block + k*grid (adjacent tiles run at the same time on different
@@ -951,7 +1100,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 template <typename real_, int N, int R, int T, bool COLS, bool SPLIT, int FLAGS, int MODE, bool BIGTW, int... RADS>
 struct PassCfg {
   typedef real_ real;
-  static constexpr int threads = T * (N / R);
+  static constexpr int threads = T * Geo<N, R, RADS...>::TPC;
   static constexpr int regs_per_thread = R * 2 * (int)(sizeof(real_) / 4);     // the column's values alone, in VGPRs
   static constexpr size_t lds = (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real_) == 4), FirstRadix<RADS...>::value>::CS * (SPLIT ? sizeof(real_) : 2 * sizeof(real_));
   template <typename HOOK>
@@ -1207,8 +1356,10 @@ hipError_t launch_fused2(const PassDesc &dA, const PassDesc &dB, const PassDesc 
 
 template <typename real, int N, int R, int T, bool COLS, bool SPLIT, int MINW, int FLAGS, int MODE, bool BIGTW, int... RADS>
 hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStream_t s) {
-  constexpr int NT = N / R;
+  constexpr int NT = Geo<N, R, RADS...>::TPC;
   constexpr int threads = T * NT;
+  // (plans whose stages keep different numbers of values per thread: plain natural-layout complex passes only)
+  if (!Geo<N, R, RADS...>::UNIFORM && (d.in_lgp || d.out_lgp || d.in_tlg || d.out_tlg || d.tr_dir || d.tw_hi)) return hipErrorInvalidValue;
   static_assert(threads >= 64 && threads <= 1024, "workgroup size");
   constexpr size_t lds_x = (sizeof...(RADS) > 1 || (FLAGS & 32) || MODE == MODE_R2C_H || MODE == MODE_C2R_H) ? (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real) == 4), FirstRadix<RADS...>::value>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
   constexpr size_t lds_f = (FLAGS & 16) ? (size_t)T * 2 * sizeof(real) : 0;

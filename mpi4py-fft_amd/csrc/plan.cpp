@@ -72,6 +72,7 @@ struct Options {
   int real_half = 1;         // contiguous real lines as half-length complex transforms (fft_real_*.hip)
   int debug_flat = 0;        // gfft_debug_pass: tiles over the flattened (mid, inner) index
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
+  int mix15 = 1;             // one-pass kernels for 3 x 5 x 2^k lengths (fft_mix15_*.hip); 0: the two-pass plans of rounds 1-4 (A/B)
   int pitch129 = 1;          // 3-D schedules: avoid workspace pitches of 129 x 2^k entries (plan_fused3)
   int pitch_extra = 0;       // A/B: lines (128 B) added to the workspace pitch
   int ws_plane_skew = 0;     // 3-D schedules: elements added to the FAR stride of the workspace (planes a little more than n * pitch apart)
@@ -243,6 +244,14 @@ bool regk_ok(int64_t n, int precision) {
   if (n > 4096) return false;
   if (mix3_supported((int)n) || mix5_supported((int)n)) return true;
   return precision == 8 ? pow2_supported_f64((int)n) : pow2_supported_f32((int)n);
+}
+
+// ... plus the lengths that have plain COMPLEX one-pass kernels only (3 x 5 x 2^k and neighbours, fft_mix15_*.hip: no real
+// modes, no fused truncation, no four-step twiddle, no exchange-buffer layouts): natural-layout c2c lines and the complex
+// passes of the one-rank 3-D schedule take them; everything else keeps the paths it had
+bool regk_c2c_ok(int64_t n, int precision, int mode) {
+  (void)precision;
+  return !opts().force_generic && opts().mix15 && mode == MODE_C2C && n <= 4096 && mix15_supported((int)n);
 }
 
 // lengths whose kernels carry the fused 3/2-rule truncation / zero-padding adapters: every register-kernel
@@ -1090,7 +1099,7 @@ int plan_line(gfft_plan_s *pl, const Line &L, bool top) {
     pl->passes.push_back(p);
     return GFFT_OK;
   }
-  if (regk_ok(n, prec)) {
+  if (regk_ok(n, prec) || regk_c2c_ok(n, prec, L.mode)) {
     p.regk = true;
     p.cols = L.inner > 1;
     int rc = get_twiddles(n, prec, &p.d.tw);
@@ -1146,7 +1155,7 @@ bool fused3_applicable(const gfft_plan_s *pl) {
   if (real && pl->axes.back() != 2) return false;
   const std::vector<int64_t> &full = (pl->kind == GFFT_C2R) ? pl->sizes_out : pl->sizes_in;
   for (int i = 0; i < 3; ++i)
-    if (!regk_ok(full[i], pl->precision)) return false;
+    if (!regk_ok(full[i], pl->precision) && !(regk_c2c_ok(full[i], pl->precision, MODE_C2C) && (!real || i < 2) && pl->trunc.empty())) return false;
   const int64_t bytes = full[0] * full[1] * full[2] * (real ? 1 : 2) * pl->precision;
   return bytes >= opts().fused3_min_bytes;
 }
@@ -1494,6 +1503,9 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   if (p.regk && mix5_supported(d.n)) {
     return pl->precision == 8 ? launch_mix5_f64(d, p.cols, in, out, s) : launch_mix5_f32(d, p.cols, in, out, s);
   }
+  if (p.regk && mix15_supported(d.n)) {
+    return pl->precision == 8 ? launch_mix15_f64(d, p.cols, in, out, s) : launch_mix15_f32(d, p.cols, in, out, s);
+  }
   if (p.regk) {
     const int variant = p.cols ? pl->variant_cols : pl->variant_rows;
     return pl->precision == 8 ? launch_pow2_f64(d, p.cols, variant, in, out, s)
@@ -1570,6 +1582,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "ws_plane_skew")) opts().ws_plane_skew = value;
   else if (!strcmp(key, "pitch129")) opts().pitch129 = value;
+  else if (!strcmp(key, "mix15")) opts().mix15 = value;
   else if (!strcmp(key, "pitch_extra")) opts().pitch_extra = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
   else if (!strcmp(key, "debug_tile_side")) opts().debug_tile_side = value;

@@ -20,3 +20,10 @@ for spec in "1024x1024x1024 D" "1024x1024x1024 d" "1024x1024x512 d" "512x512x409
 done
 } > gpurun_out/r05r/ab_pitch129.txt 2>&1
 tail -5 gpurun_out/r05r/ab_pitch129.txt
+{
+echo "# tools/serial_ab_probe.py: one serial plan per option set, same arrays, alternating (5 rounds x 20 executions)"
+python tools/serial_ab_probe.py 128x1048576 F 1 "fuse2_f32=0,fuse2_kinds=126" "fuse2_f32=1,fuse2_kinds=126"
+python tools/serial_ab_probe.py 256x1024x1024 F 1,2 "fuse2_f32=0,fuse2_kinds=126" "fuse2_f32=1,fuse2_kinds=126"
+python tools/serial_ab_probe.py 64x1048576 D 1 "fuse2=0,fuse2_kinds=126" "fuse2=1,fuse2_kinds=126"
+} 2>&1 | grep -v "^/opt" > gpurun_out/r05r/c2_pairs.txt
+cat gpurun_out/r05r/c2_pairs.txt
