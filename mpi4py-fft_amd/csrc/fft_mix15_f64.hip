@@ -56,4 +56,30 @@ hipError_t launch_mix15_f64(const PassDesc &d, bool cols, const void *in, void *
   return hipErrorInvalidValue;
 }
 
+// packed-real rows of 2 n reals (MODE_R2C_H / MODE_C2R_H, fft_real_f64.hip) on the same row plans: the Hermitian pass runs in
+// the geometry of the side it sits on (after the last stage for r2c, before the first for c2r).  Plain rows only.
+template <int MODE>
+static hipError_t half15_f64(const PassDesc &d, const void *in, void *out, hipStream_t s) {
+  if (d.tr_dir || d.ub_p > 1) return hipErrorInvalidValue;
+  switch (d.n) {
+    case 240: return launch_pow2_one<double, 240, 16, 16, false, true, 1, 0, MODE, false, 15, 16>(d, in, out, s);
+    case 480: return launch_pow2_one<double, 480, 16, 8, false, true, 1, 0, MODE, false, 15, 16, 2>(d, in, out, s);
+    case 960: return launch_pow2_one<double, 960, 16, 4, false, true, 1, 0, MODE, false, 15, 16, 4>(d, in, out, s);
+    case 1920: return launch_pow2_one<double, 1920, 16, 2, false, true, 1, 0, MODE, false, 15, 16, 8>(d, in, out, s);
+    case 3840: return launch_pow2_one<double, 3840, 16, 1, false, true, 1, 0, MODE, false, 15, 16, 16>(d, in, out, s);
+    case 720: return launch_pow2_one<double, 720, 16, 8, false, true, 1, 0, MODE, false, 15, 3, 16>(d, in, out, s);
+    case 1440: return launch_pow2_one<double, 1440, 16, 4, false, true, 1, 0, MODE, false, 15, 3, 16, 2>(d, in, out, s);
+    case 2880: return launch_pow2_one<double, 2880, 16, 2, false, true, 1, 0, MODE, false, 15, 3, 16, 4>(d, in, out, s);
+    case 1200: return launch_pow2_one<double, 1200, 16, 4, false, true, 1, 0, MODE, false, 15, 5, 16>(d, in, out, s);
+    case 2400: return launch_pow2_one<double, 2400, 16, 2, false, true, 1, 0, MODE, false, 15, 5, 16, 2>(d, in, out, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_real_half_mix15_f64(const PassDesc &d, const void *in, void *out, hipStream_t s) {
+  if (d.mode == MODE_R2C_H) return half15_f64<MODE_R2C_H>(d, in, out, s);
+  if (d.mode == MODE_C2R_H) return half15_f64<MODE_C2R_H>(d, in, out, s);
+  return hipErrorInvalidValue;
+}
+
 }  // namespace gfft

@@ -932,41 +932,55 @@ template <typename real, int R> __device__ __forceinline__ cx<real> mirror_twidd
   return {wt.x * c - wt.y * s, wt.x * s + wt.y * c};
 }
 
+// (`active`: false for the thread rows of a column that hold no values in this geometry -- plans whose stages keep different
+// numbers of values per thread, Geo -- : they take part in the barriers only)
 template <typename real, int N, int R, bool SPLIT, bool WL, int PADSH, typename F>
-__device__ __forceinline__ void mirror_pass(cx<real> *v, int t, void *col, cx<real> top, F &&combine) {
+__device__ __forceinline__ void mirror_pass(cx<real> *v, int t, void *col, cx<real> top, F &&combine, bool active = true) {
   constexpr int NT = N / R;
   constexpr int PAD = PADSH;
   if constexpr (SPLIT) {
     real *w = reinterpret_cast<real *>(col);
     real px[R];
     tile_sync<WL>();
+    if (active) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = v[q].x;
-    if (t == 0) w[pad_slot<PAD>(N)] = top.x;
+      for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = v[q].x;
+      if (t == 0) w[pad_slot<PAD>(N)] = top.x;
+    }
     tile_sync<WL>();
+    if (active) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) px[q] = w[pad_slot<PAD>(N - (t + q * NT))];
+      for (int q = 0; q < R; ++q) px[q] = w[pad_slot<PAD>(N - (t + q * NT))];
+    }
     tile_sync<WL>();
+    if (active) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = v[q].y;
-    if (t == 0) w[pad_slot<PAD>(N)] = top.y;
+      for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = v[q].y;
+      if (t == 0) w[pad_slot<PAD>(N)] = top.y;
+    }
     tile_sync<WL>();
+    if (active) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const real py = w[pad_slot<PAD>(N - (t + q * NT))];
-      combine(q, cx<real>{px[q], py});
+      for (int q = 0; q < R; ++q) {
+        const real py = w[pad_slot<PAD>(N - (t + q * NT))];
+        combine(q, cx<real>{px[q], py});
+      }
     }
   } else {
     float2 *w = reinterpret_cast<float2 *>(col);
     tile_sync<WL>();
+    if (active) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = make_float2(v[q].x, v[q].y);
-    if (t == 0) w[pad_slot<PAD>(N)] = make_float2(top.x, top.y);
+      for (int q = 0; q < R; ++q) w[pad_slot<PAD>(t + q * NT)] = make_float2(v[q].x, v[q].y);
+      if (t == 0) w[pad_slot<PAD>(N)] = make_float2(top.x, top.y);
+    }
     tile_sync<WL>();
+    if (active) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
-      const float2 p = w[pad_slot<PAD>(N - (t + q * NT))];
-      combine(q, cx<real>{(real)p.x, (real)p.y});
+      for (int q = 0; q < R; ++q) {
+        const float2 p = w[pad_slot<PAD>(N - (t + q * NT))];
+        combine(q, cx<real>{(real)p.x, (real)p.y});
+      }
     }
   }
 }

@@ -296,6 +296,14 @@ def test_one_pass_kernels_for_3x5x2k_lengths(n, dt):
         assert desc.count('kernel=regs') == 1 and '1 passes' in desc, desc
         fft.destroy()
         _check(shape, axes, dt, seed=n)
+    # real lines of 2 n entries: packed-real rows on the same row plan (Hermitian pass in the geometry of its side)
+    rdt = dt.lower()
+    for shape in ((3, 2 * n), (37, 2 * n)):
+        fft = FFT(shape, (1,), dtype=rdt)
+        desc = _lib.engine().plan_describe(fft.fwd._plan) + _lib.engine().plan_describe(fft.bck._plan)
+        assert desc.count('kernel=regs') == 2 and desc.count('1 passes') == 2, desc
+        fft.destroy()
+        _check(shape, (1,), rdt, seed=n + 1)
     A = O.rng_array((5, n), dt, 3)
     got = {}
     for opt in (1, 0):
@@ -309,7 +317,8 @@ def test_one_pass_kernels_for_3x5x2k_lengths(n, dt):
     assert np.abs(got[0] - got[1]).max() <= (1e-13 if dt == 'D' else 1e-5) * np.abs(got[0]).max()
 
 
-@pytest.mark.parametrize('shape,dt', [((240, 480, 240), 'D'), ((480, 240, 720), 'F'), ((240, 240, 960), 'd'), ((960, 240, 64), 'D')])
+@pytest.mark.parametrize('shape,dt', [((240, 480, 240), 'D'), ((480, 240, 720), 'F'), ((240, 240, 960), 'd'), ((960, 240, 64), 'D'),
+                                      ((240, 720, 480), 'f'), ((128, 240, 1920), 'd')])
 def test_3x5x2k_lengths_in_the_one_rank_3d_schedule(shape, dt):
     """... and inside the single-GPU 3-D schedule (plan.cpp plan_fused3: pitched workspace, reordered passes); a real
     transform takes them on its two complex axes."""

@@ -41,7 +41,9 @@ CASES = {
     'r2c_d': lambda: pfft((1024,) * 3, 'd'),
     'r2c_f': lambda: pfft((1024,) * 3, 'f'),
     'r2c_d2048': lambda: pfft((1024, 1024, 2048), 'd'),
-    'r2c_d1026': lambda: pfft((1024, 1024, 1026), 'd'),
+    'c960': lambda: pfft((960, 960, 960), 'D'),
+    'c960f': lambda: pfft((960, 960, 960), 'F'),
+    'r960': lambda: pfft((960, 960, 960), 'd'),
     'c5rows': lambda: serial((512, 1024, 2048), 'f', (2,)),
     'c5ax1': lambda: serial((512, 2048, 513), 'F', (1,)),
     'c5ax0': lambda: serial((2048, 512, 513), 'F', (0,)),

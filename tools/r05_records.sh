@@ -27,3 +27,14 @@ python tools/serial_ab_probe.py 256x1024x1024 F 1,2 "fuse2_f32=0,fuse2_kinds=126
 python tools/serial_ab_probe.py 64x1048576 D 1 "fuse2=0,fuse2_kinds=126" "fuse2=1,fuse2_kinds=126"
 } 2>&1 | grep -v "^/opt" > gpurun_out/r05r/c2_pairs.txt
 cat gpurun_out/r05r/c2_pairs.txt
+
+# 960^3: the two-pass plans of rounds 1-4 against the one-pass kernels, then the rocprofv3 passes of the new kernels
+{
+python tools/ab_combo_probe.py -n 960 -d D "mix15=0" "mix15=1"
+python tools/ab_combo_probe.py -n 960 -d F "mix15=0" "mix15=1"
+python tools/ab_combo_probe.py -n 960 -d d "mix15=0" "mix15=1"
+python tools/ab_combo_probe.py -n 720x1200x480 -d D "mix15=0" "mix15=1"
+} 2>&1 | grep -v "^/opt\|AMD Radeon" > gpurun_out/r05r/ab_mix15.txt
+cat gpurun_out/r05r/ab_mix15.txt
+bash tools/prof.sh r05_c960 python tools/prof_cases.py c960 c960f > gpurun_out/r05r/prof_c960.log 2>&1
+bash tools/prof.sh r05_r2c_d2048 python tools/prof_cases.py r2c_d2048 > gpurun_out/r05r/prof_r2c.log 2>&1
