@@ -316,6 +316,33 @@ template <typename real, int S> __device__ __forceinline__ void dft20(cx<real> *
   for (int k = 0; k < 20; ++k) v[k * S] = o[k];
 }
 
+// radix 7, symmetric form: X[k] = a_k - i b_k, X[7-k] = a_k + i b_k with a_k = x0 + sum_j cos(2 pi j k / 7) (x_j + x_{7-j}),
+// b_k = sum_j sin(2 pi j k / 7) (x_j - x_{7-j}), j, k = 1..3
+template <typename real, int S> __device__ __forceinline__ void dft7(cx<real> *v) {
+  constexpr real C1 = (real)0.62348980185873353052500488400424, C2 = (real)-0.22252093395631440428890256449679,
+                 C3 = (real)-0.90096886790241912623610231950745;      // cos(2 pi k / 7)
+  constexpr real S1 = (real)0.78183148246802980870844452667406, S2 = (real)0.97492791218182360701813168299393,
+                 S3 = (real)0.43388373911755812047576833284836;       // sin(2 pi k / 7)
+  const cx<real> x0 = v[0];
+  const cx<real> p1 = v[1 * S] + v[6 * S], p2 = v[2 * S] + v[5 * S], p3 = v[3 * S] + v[4 * S];
+  const cx<real> m1 = v[1 * S] - v[6 * S], m2 = v[2 * S] - v[5 * S], m3 = v[3 * S] - v[4 * S];
+  v[0] = x0 + p1 + p2 + p3;
+  // (cos / sin of 2 pi j k / 7 for k = 1, 2, 3: rows of the index table j k mod 7 -> +-{1, 2, 3})
+  const cx<real> a1 = {x0.x + C1 * p1.x + C2 * p2.x + C3 * p3.x, x0.y + C1 * p1.y + C2 * p2.y + C3 * p3.y};
+  const cx<real> a2 = {x0.x + C2 * p1.x + C3 * p2.x + C1 * p3.x, x0.y + C2 * p1.y + C3 * p2.y + C1 * p3.y};
+  const cx<real> a3 = {x0.x + C3 * p1.x + C1 * p2.x + C2 * p3.x, x0.y + C3 * p1.y + C1 * p2.y + C2 * p3.y};
+  const cx<real> b1 = {S1 * m1.x + S2 * m2.x + S3 * m3.x, S1 * m1.y + S2 * m2.y + S3 * m3.y};
+  const cx<real> b2 = {S2 * m1.x - S3 * m2.x - S1 * m3.x, S2 * m1.y - S3 * m2.y - S1 * m3.y};
+  const cx<real> b3 = {S3 * m1.x - S1 * m2.x + S2 * m3.x, S3 * m1.y - S1 * m2.y + S2 * m3.y};
+  // a - i b = (a.x + b.y, a.y - b.x);  a + i b = (a.x - b.y, a.y + b.x)
+  v[1 * S] = {a1.x + b1.y, a1.y - b1.x};
+  v[6 * S] = {a1.x - b1.y, a1.y + b1.x};
+  v[2 * S] = {a2.x + b2.y, a2.y - b2.x};
+  v[5 * S] = {a2.x - b2.y, a2.y + b2.x};
+  v[3 * S] = {a3.x + b3.y, a3.y - b3.x};
+  v[4 * S] = {a3.x - b3.y, a3.y + b3.x};
+}
+
 // radix 15 = 3 x 5 by the prime-factor map (3 and 5 coprime: no twiddles inside): input n = (5 n1 + 3 n2) mod 15, output
 // k = (10 k1 + 6 k2) mod 15, W15^(n k) = W3^(n1 k1) W5^(n2 k2); the index maps are compile-time register renamings
 template <typename real, int S> __device__ __forceinline__ void dft15(cx<real> *v) {
@@ -335,8 +362,9 @@ template <typename real, int S> __device__ __forceinline__ void dft15(cx<real> *
 }
 
 template <typename real, int r, int S> __device__ __forceinline__ void dft(cx<real> *v) {
-  static_assert(r == 2 || r == 3 || r == 4 || r == 5 || r == 8 || r == 10 || r == 12 || r == 15 || r == 16 || r == 20 || r == 32 || r == 64, "radix");
+  static_assert(r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8 || r == 10 || r == 12 || r == 15 || r == 16 || r == 20 || r == 32 || r == 64, "radix");
   if constexpr (r == 15) { dft15<real, S>(v); return; }
+  if constexpr (r == 7) { dft7<real, S>(v); return; }
   if constexpr (r == 2) dft2<real, S>(v);
   else if constexpr (r == 3) dft3<real, S>(v);
   else if constexpr (r == 4) dft4<real, S>(v);
@@ -395,6 +423,13 @@ __device__ __forceinline__ void twiddle(cx<real> *v, int k, const cx<real> *__re
   v[1 * S] = cmul(v[1 * S], w1);
   if constexpr (r == 3) {
     v[2 * S] = cmul(v[2 * S], tw[2 * k * step]);
+  } else if constexpr (r == 7) {
+    const cx<real> w2 = tw[2 * k * step], w4 = tw[4 * k * step];
+    v[2 * S] = cmul(v[2 * S], w2);
+    v[3 * S] = cmul(v[3 * S], cmul(w1, w2));
+    v[4 * S] = cmul(v[4 * S], w4);
+    v[5 * S] = cmul(v[5 * S], cmul(w1, w4));
+    v[6 * S] = cmul(v[6 * S], cmul(w2, w4));
   } else if constexpr (r == 15) {
     const cx<real> w2 = tw[2 * k * step], w4 = tw[4 * k * step], w8 = tw[8 * k * step];
     const cx<real> w3 = cmul(w1, w2), w12 = cmul(w4, w8);

@@ -72,7 +72,7 @@ struct Options {
   int real_half = 1;         // contiguous real lines as half-length complex transforms (fft_real_*.hip)
   int debug_flat = 0;        // gfft_debug_pass: tiles over the flattened (mid, inner) index
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
-  int mix15 = 1;             // one-pass kernels for 3 x 5 x 2^k lengths (fft_mix15_*.hip); 0: the two-pass plans of rounds 1-4 (A/B)
+  int mixv = 1;              // one-pass kernels for 3 x 5 x 2^k lengths (fft_mixv_*.hip); 0: the two-pass plans of rounds 1-4 (A/B)
   int pitch129 = 1;          // 3-D schedules: avoid workspace pitches of 129 x 2^k entries (plan_fused3)
   int pitch_extra = 0;       // A/B: lines (128 B) added to the workspace pitch
   int ws_plane_skew = 0;     // 3-D schedules: elements added to the FAR stride of the workspace (planes a little more than n * pitch apart)
@@ -246,16 +246,16 @@ bool regk_ok(int64_t n, int precision) {
   return precision == 8 ? pow2_supported_f64((int)n) : pow2_supported_f32((int)n);
 }
 
-// ... plus the lengths that have plain COMPLEX one-pass kernels only (3 x 5 x 2^k and neighbours, fft_mix15_*.hip: no real
+// ... plus the lengths that have plain COMPLEX one-pass kernels only (3 x 5 x 2^k and neighbours, fft_mixv_*.hip: no real
 // modes, no fused truncation, no four-step twiddle, no exchange-buffer layouts): natural-layout c2c lines and the complex
 // passes of the one-rank 3-D schedule take them; everything else keeps the paths it had
 bool regk_c2c_ok(int64_t n, int precision, int mode) {
   (void)precision;
-  return !opts().force_generic && opts().mix15 && mode == MODE_C2C && n <= 4096 && mix15_supported((int)n);
+  return !opts().force_generic && opts().mixv && mode == MODE_C2C && n <= 4096 && mixv_supported((int)n);
 }
 
 // ... and packed-real rows of twice such a length (complex length m = n / 2): plain rows only
-bool real_half_mix15_ok(int64_t m) { return !opts().force_generic && opts().mix15 && m <= 4096 && mix15_supported((int)m); }
+bool real_half_mixv_ok(int64_t m) { return !opts().force_generic && opts().mixv && m <= 4096 && mixv_supported((int)m); }
 
 // lengths whose kernels carry the fused 3/2-rule truncation / zero-padding adapters: every register-kernel
 // length except 5^c 2^k, whose adapters only a `make VARIANTS=1` library instantiates (fft_pow2_impl.h
@@ -266,7 +266,7 @@ bool fused_pad_ok(int64_t n_axis) {
   (void)n_axis;
   return true;
 #else
-  return !(n_axis <= 4096 && (mix5_supported((int)n_axis) || mix15_supported((int)n_axis)));
+  return !(n_axis <= 4096 && (mix5_supported((int)n_axis) || mixv_supported((int)n_axis)));
 #endif
 }
 
@@ -648,7 +648,7 @@ bool real_half_ok(const Line &L, int prec) {
   (void)prec;
   return opts().real_half && !opts().force_generic && (L.mode == MODE_R2C || L.mode == MODE_C2R) &&
          L.inner == 1 && L.n % 2 == 0 && L.n / 2 <= 4096 &&
-         (real_half_supported((int)(L.n / 2)) || real_half_mix_supported((int)(L.n / 2)) || real_half_mix15_ok(L.n / 2)) && L.outer < ((int64_t)1 << 31);
+         (real_half_supported((int)(L.n / 2)) || real_half_mix_supported((int)(L.n / 2)) || real_half_mixv_ok(L.n / 2)) && L.outer < ((int64_t)1 << 31);
 }
 
 // natural_desc(L) restated for the packed-real form: d.n = complex length, real side in pairs
@@ -1159,7 +1159,7 @@ bool fused3_applicable(const gfft_plan_s *pl) {
   const std::vector<int64_t> &full = (pl->kind == GFFT_C2R) ? pl->sizes_out : pl->sizes_in;
   for (int i = 0; i < 3; ++i)
     if (!regk_ok(full[i], pl->precision) && !(pl->trunc.empty() && ((!real || i < 2) ? regk_c2c_ok(full[i], pl->precision, MODE_C2C)
-                                                                                       : (opts().real_half && full[i] % 2 == 0 && real_half_mix15_ok(full[i] / 2))))) return false;
+                                                                                       : (opts().real_half && full[i] % 2 == 0 && real_half_mixv_ok(full[i] / 2))))) return false;
   const int64_t bytes = full[0] * full[1] * full[2] * (real ? 1 : 2) * pl->precision;
   return bytes >= opts().fused3_min_bytes;
 }
@@ -1258,7 +1258,7 @@ int plan_fused3(gfft_plan_s *pl) {
     p.d.out_es = 1;
     p.src = src; p.dst = dst;
     if (mode != MODE_C2C && opts().real_half && n2 % 2 == 0 &&
-        (real_half_supported((int)(n2 / 2)) || real_half_mix_supported((int)(n2 / 2)) || (!tr && real_half_mix15_ok(n2 / 2)))) {
+        (real_half_supported((int)(n2 / 2)) || real_half_mix_supported((int)(n2 / 2)) || (!tr && real_half_mixv_ok(n2 / 2)))) {
       // packed-real form: complex length n2/2, the real side (the user's natural array) in pairs
       p.d.n = (int)(n2 / 2);
       p.d.mode = mode == MODE_R2C ? MODE_R2C_H : MODE_C2R_H;
@@ -1497,8 +1497,8 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   if ((d.mode == MODE_R2C_H || d.mode == MODE_C2R_H) && real_half_supported(d.n))
     return pl->precision == 8 ? launch_real_half_f64(d, pl->variant_rows, in, out, s)
                               : launch_real_half_f32(d, pl->variant_rows, in, out, s);
-  if ((d.mode == MODE_R2C_H || d.mode == MODE_C2R_H) && mix15_supported(d.n))
-    return pl->precision == 8 ? launch_real_half_mix15_f64(d, in, out, s) : launch_real_half_mix15_f32(d, in, out, s);
+  if ((d.mode == MODE_R2C_H || d.mode == MODE_C2R_H) && mixv_supported(d.n))
+    return pl->precision == 8 ? launch_real_half_mixv_f64(d, in, out, s) : launch_real_half_mixv_f32(d, in, out, s);
   if (d.mode == MODE_R2C_H || d.mode == MODE_C2R_H)
     return pl->precision == 8 ? launch_real_half_mix_f64(d, in, out, s) : launch_real_half_mix_f32(d, in, out, s);
   if (p.regk && d.mode == MODE_R2R && pow2_r2r_supported(d.n))
@@ -1509,8 +1509,8 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   if (p.regk && mix5_supported(d.n)) {
     return pl->precision == 8 ? launch_mix5_f64(d, p.cols, in, out, s) : launch_mix5_f32(d, p.cols, in, out, s);
   }
-  if (p.regk && mix15_supported(d.n)) {
-    return pl->precision == 8 ? launch_mix15_f64(d, p.cols, in, out, s) : launch_mix15_f32(d, p.cols, in, out, s);
+  if (p.regk && mixv_supported(d.n)) {
+    return pl->precision == 8 ? launch_mixv_f64(d, p.cols, in, out, s) : launch_mixv_f32(d, p.cols, in, out, s);
   }
   if (p.regk) {
     const int variant = p.cols ? pl->variant_cols : pl->variant_rows;
@@ -1588,7 +1588,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "ws_plane_skew")) opts().ws_plane_skew = value;
   else if (!strcmp(key, "pitch129")) opts().pitch129 = value;
-  else if (!strcmp(key, "mix15")) opts().mix15 = value;
+  else if (!strcmp(key, "mixv")) opts().mixv = value;
   else if (!strcmp(key, "pitch_extra")) opts().pitch_extra = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
   else if (!strcmp(key, "debug_tile_side")) opts().debug_tile_side = value;
@@ -2040,8 +2040,8 @@ int gfft_plan_set_split(gfft_plan pl, int side, int nblocks) {
     return fail(GFFT_ERR_UNSUPPORTED, "split layouts fuse into single-pass plans only");
   Pass &p = pl->passes[0];
   // (3 x 5 x 2^k lengths: their stages keep different numbers of values per thread, and a block boundary would have to
-  // fall between the same thread slots on the load AND the store geometry -- natural layouts only, fft_mix15_*.hip)
-  if (p.regk && mix15_supported(p.d.n)) return fail(GFFT_ERR_UNSUPPORTED, "split layouts: not for 3 x 5 x 2^k lengths");
+  // fall between the same thread slots on the load AND the store geometry -- natural layouts only, fft_mixv_*.hip)
+  if (p.regk && mixv_supported(p.d.n)) return fail(GFFT_ERR_UNSUPPORTED, "split layouts: not for 3 x 5 x 2^k lengths");
   if ((p.d.mode == MODE_R2C_H && side == 1) || (p.d.mode == MODE_C2R_H && side == 0)) {
     // packed-real rows: the half-spectrum side as an all-to-all buffer of UNEVEN blocks (the
     // n/2 + 1 entries never divide evenly; pencil.py:5-9 deals the remainder to the first ranks)
@@ -2217,7 +2217,7 @@ int gfft_plan_set_tiles(gfft_plan pl, int side, int tile, int64_t tile_stride) {
   if (side != 0 && side != 1) return fail(GFFT_ERR_INVALID, "side must be 0 (input) or 1 (output)");
   if (pl->passes.size() != 1 || pl->fused3) return fail(GFFT_ERR_UNSUPPORTED, "tile-major layouts: single-pass plans only");
   Pass &p = pl->passes[0];
-  if (p.kind != PK_FFT || !p.regk || p.d.mode != MODE_C2C || p.d.tw_hi || p.d.tr_dir || mix15_supported(p.d.n))
+  if (p.kind != PK_FFT || !p.regk || p.d.mode != MODE_C2C || p.d.tw_hi || p.d.tr_dir || mixv_supported(p.d.n))
     return fail(GFFT_ERR_UNSUPPORTED, "tile-major layouts: plain complex register-kernel passes only");
   int lg = 0;
   while ((1 << lg) < tile) ++lg;

@@ -282,13 +282,13 @@ def test_two_pass_235_lengths(n):
     _check((2, n, 3), (1,), 'F')
 
 
-@pytest.mark.parametrize('n', [240, 480, 960, 1920, 3840, 720, 1440, 2880, 1200, 2400])
+@pytest.mark.parametrize('n', [240, 480, 960, 1920, 3840, 720, 1440, 2880, 1200, 2400, 112, 224, 448, 896, 1792, 3584])
 @pytest.mark.parametrize('dt', ['D', 'F'])
 def test_one_pass_kernels_for_3x5x2k_lengths(n, dt):
-    """Round 5: lengths 3 x 5 x 2^k (and 9 x 5 x 2^k, 3 x 25 x 2^k) as ONE register-kernel pass whose stages keep different
-    numbers of values per thread (csrc/fft_mix15_*.hip, Geo / StageV): rows, strided columns (whole and ragged tiles),
+    """Round 5: lengths 3 x 5 x 2^k (and 9 x 5 x 2^k, 3 x 25 x 2^k) and 7 x 2^k as ONE register-kernel pass whose stages keep different
+    numbers of values per thread (csrc/fft_mixv_*.hip, Geo / StageV): rows, strided columns (whole and ragged tiles),
     middle axis; values against the oracle; the planner says one pass; and the same lines through the two-pass plans of
-    rounds 1-4 (option mix15 = 0) agree to rounding.  The reference's tests exercise such sizes: tests/test_libfft.py:26-27."""
+    rounds 1-4 (option mixv = 0) agree to rounding.  The reference's tests exercise such sizes: tests/test_libfft.py:26-27."""
     from mpi4py_fft_amd import FFT, asdevice, _lib
     for shape, axes in (((3, n), (1,)), ((n, 10), (0,)), ((n, 37), (0,)), ((2, n, 19), (1,)), ((70, n), (1,))):
         fft = FFT(shape, axes, dtype=dt)
@@ -307,18 +307,18 @@ def test_one_pass_kernels_for_3x5x2k_lengths(n, dt):
     A = O.rng_array((5, n), dt, 3)
     got = {}
     for opt in (1, 0):
-        _lib.set_option('mix15', opt)
+        _lib.set_option('mixv', opt)
         try:
             fft = FFT((5, n), (1,), dtype=dt)
             got[opt] = np.asarray(fft.forward(asdevice(A))).copy()
             fft.destroy()
         finally:
-            _lib.set_option('mix15', 1)
+            _lib.set_option('mixv', 1)
     assert np.abs(got[0] - got[1]).max() <= (1e-13 if dt == 'D' else 1e-5) * np.abs(got[0]).max()
 
 
 @pytest.mark.parametrize('shape,dt', [((240, 480, 240), 'D'), ((480, 240, 720), 'F'), ((240, 240, 960), 'd'), ((960, 240, 64), 'D'),
-                                      ((240, 720, 480), 'f'), ((128, 240, 1920), 'd')])
+                                      ((240, 720, 480), 'f'), ((128, 240, 1920), 'd'), ((224, 448, 112), 'D'), ((112, 224, 896), 'd')])
 def test_3x5x2k_lengths_in_the_one_rank_3d_schedule(shape, dt):
     """... and inside the single-GPU 3-D schedule (plan.cpp plan_fused3: pitched workspace, reordered passes); a real
     transform takes them on its two complex axes."""

@@ -30,10 +30,10 @@ cat gpurun_out/r05r/c2_pairs.txt
 
 # 960^3: the two-pass plans of rounds 1-4 against the one-pass kernels, then the rocprofv3 passes of the new kernels
 {
-python tools/ab_combo_probe.py -n 960 -d D "mix15=0" "mix15=1"
-python tools/ab_combo_probe.py -n 960 -d F "mix15=0" "mix15=1"
-python tools/ab_combo_probe.py -n 960 -d d "mix15=0" "mix15=1"
-python tools/ab_combo_probe.py -n 720x1200x480 -d D "mix15=0" "mix15=1"
+python tools/ab_combo_probe.py -n 960 -d D "mixv=0" "mixv=1"
+python tools/ab_combo_probe.py -n 960 -d F "mixv=0" "mixv=1"
+python tools/ab_combo_probe.py -n 960 -d d "mixv=0" "mixv=1"
+python tools/ab_combo_probe.py -n 720x1200x480 -d D "mixv=0" "mixv=1"
 } 2>&1 | grep -v "^/opt\|AMD Radeon" > gpurun_out/r05r/ab_mix15.txt
 cat gpurun_out/r05r/ab_mix15.txt
 bash tools/prof.sh r05_c960 python tools/prof_cases.py c960 c960f > gpurun_out/r05r/prof_c960.log 2>&1
