@@ -376,8 +376,10 @@ class _Aligned:
         CS0 = p0 * BS0                          # one chunk region on the strided stage's side
         # ---- geometry of T1
         bw1, tw1 = Wq - Wq % TW, Wq % TW            # (the same split as T0's: a stage between the two sees one body)
-        # body rows of a T1 slab lie RP entries apart: bw1 (whole lines already), plus GFFT_T1_ROWPAD entries (A/B, tools/stage_probe.py)
-        RP = bw1 + (int(os.environ.get('GFFT_T1_ROWPAD', 0)) if bw1 else 0)
+        # (body rows of a T1 slab lie bw1 entries apart -- 4 / 8 KiB at the BASELINE shapes, powers of two: pitching them 128 ...
+        # 512 bytes further apart was measured in round 5 and moves no stage of C4 / C5 by more than +-2 %,
+        # profiles/r05_t1_rowpad.txt: the segments of a strided tile there are whole rows of the slab, not far strides)
+        RP = bw1
         E = _pitch(N1b * (RP + tw1), isz)
         BS1 = N0 * E
         CS1 = p1 * BS1

@@ -34,7 +34,7 @@ python tools/ab_combo_probe.py -n 960 -d D "mixv=0" "mixv=1"
 python tools/ab_combo_probe.py -n 960 -d F "mixv=0" "mixv=1"
 python tools/ab_combo_probe.py -n 960 -d d "mixv=0" "mixv=1"
 python tools/ab_combo_probe.py -n 720x1200x480 -d D "mixv=0" "mixv=1"
-} 2>&1 | grep -v "^/opt\|AMD Radeon" > gpurun_out/r05r/ab_mix15.txt
-cat gpurun_out/r05r/ab_mix15.txt
+} 2>&1 | grep -v "^/opt\|AMD Radeon" > gpurun_out/r05r/ab_mixv.txt
+cat gpurun_out/r05r/ab_mixv.txt
 bash tools/prof.sh r05_c960 python tools/prof_cases.py c960 c960f > gpurun_out/r05r/prof_c960.log 2>&1
 bash tools/prof.sh r05_r2c_d2048 python tools/prof_cases.py r2c_d2048 > gpurun_out/r05r/prof_r2c.log 2>&1
