@@ -38,3 +38,17 @@ python tools/ab_combo_probe.py -n 720x1200x480 -d D "mixv=0" "mixv=1"
 cat gpurun_out/r05r/ab_mixv.txt
 bash tools/prof.sh r05_c960 python tools/prof_cases.py c960 c960f > gpurun_out/r05r/prof_c960.log 2>&1
 bash tools/prof.sh r05_r2c_d2048 python tools/prof_cases.py r2c_d2048 > gpurun_out/r05r/prof_r2c.log 2>&1
+# what bounds the stand-alone strided pass (needs mpi4py-fft_amd/libgfft_var.so: fft_pow2_f64.hip built with -DGFFT_VARIANTS)
+if [ -e mpi4py-fft_amd/libgfft_var.so ]; then
+  GFFT_AB_LIB=libgfft_var.so python tools/strided_bound_probe.py 2>&1 | grep -v "^/opt" > gpurun_out/r05r/strided_bound.txt; cat gpurun_out/r05r/strided_bound.txt
+fi
+python tools/gate_probe.py 2>&1 | grep -v "^/opt" > gpurun_out/r05r/gate_cost.txt
+# the headline: four rocprofv3 passes over bench.py, then two plain runs (the second with the cpu_baseline leg at 1024^3)
+bash tools/prof.sh r05_bench python bench.py --steps 6 --warmup 2 --no-cpu > gpurun_out/r05r/prof_bench.log 2>&1
+timeout 600 python bench.py --no-cpu > gpurun_out/r05r/bench_plain.json 2> gpurun_out/r05r/bench_plain.err
+timeout 1500 python bench.py > gpurun_out/r05r/bench_plain_cpu.json 2> gpurun_out/r05r/bench_plain_cpu.err
+timeout 900 python tools/survey.py > gpurun_out/r05r/survey.txt 2>&1
+STAGE_PROBE_ONLY=aligned bash tools/prof.sh r05_c5odd python tools/stage_probe.py c5odd > gpurun_out/r05r/prof_c5odd.log 2>&1
+timeout 600 python tools/stage_probe.py all > gpurun_out/r05r/stage_probe.txt 2>&1
+timeout 900 python tools/stress.py 5 120 mid > gpurun_out/r05r/stress.txt 2>&1; tail -3 gpurun_out/r05r/stress.txt
+timeout 600 python tools/stress_serial.py 5 90 > gpurun_out/r05r/stress_serial.txt 2>&1; tail -3 gpurun_out/r05r/stress_serial.txt

@@ -29,7 +29,7 @@ if mode == 'mid':
     # the lengths the big configurations run (register kernels with wide tiles, line-rounded
     # workspace passes, packed-real rows, 513-style widths) at sizes the oracle still does in seconds
     pool = [16, 20, 34, 64, 66, 100, 128, 192, 256, 256, 320, 384, 500, 512, 512, 640, 768, 1000, 1024, 1024,
-            1536, 2048, 4096]
+            1536, 2048, 4096, 240, 480, 960, 896, 448, 720]      # (round 5: + the unequal-width stage kernels' lengths)
     limit = 48_000_000
 t0, done, skipped = time.time(), 0, 0
 while time.time() - t0 < budget:

@@ -12,10 +12,11 @@ seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 120.0
 rng = np.random.default_rng(seed)
 LONG = [64, 128, 256, 512, 1024, 2048, 4096, 8192, 48, 96, 192, 384, 768, 1536, 3072, 1152, 20, 40, 80, 160, 320,
-        640, 1000, 1280, 2000, 2560, 896, 448, 1792, 704, 1408, 832, 960, 1920, 1232, 97, 251, 1021, 2049]
+        640, 1000, 1280, 2000, 2560, 896, 448, 1792, 704, 1408, 832, 960, 1920, 1232, 97, 251, 1021, 2049,
+        240, 480, 3840, 720, 1440, 2880, 1200, 2400, 112, 224, 3584, 7680, 1792 * 2]      # (round 5: the unequal-width stage kernels, and real lines of twice such lengths)
 SHORT = [1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 17, 33, 64, 65, 128, 130]
 mode = sys.argv[3] if len(sys.argv) > 3 else 'small'
-MID = [16, 34, 66, 100, 128, 192, 256, 257, 384, 512, 513, 640, 768, 1000, 1024, 1536, 2048, 4096]
+MID = [16, 34, 66, 100, 128, 192, 256, 257, 384, 512, 513, 640, 768, 1000, 1024, 1536, 2048, 4096, 240, 480, 960, 896, 720, 1200, 448]
 t0, done = time.time(), 0
 while time.time() - t0 < budget:
     nd = int(rng.integers(1, 4))
