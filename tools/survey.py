@@ -75,8 +75,8 @@ pfft_case('    PFFT 1152^3 c64', (1152,) * 3, 'F')
 pfft_case('    PFFT 1000^3 c64 (R=20 kernels)', (1000,) * 3, 'F')
 pfft_case('    PFFT 1000^3 c128', (1000,) * 3, 'D')
 pfft_case('    PFFT 640^3 r2c f64', (640,) * 3, 'd')
-pfft_case('    PFFT 960^3 c128 (two-pass 48x20)', (960,) * 3, 'D')
-pfft_case('    PFFT 896^3 c128 (two-pass 128x7)', (896,) * 3, 'D')
+pfft_case('    PFFT 960^3 c128 (15 x 16 x 4, one pass)', (960,) * 3, 'D')
+pfft_case('    PFFT 896^3 c128 (7 x 16 x 8, one pass) ', (896,) * 3, 'D')
 plan_case('C2  batched 1-D 2^20 c128, B=64', (64, 1 << 20), 'D', (1,))
 plan_case('    batched 1-D 2^20 c64, B=128', (128, 1 << 20), 'F', (1,))
 plan_case('    1-D 2^24-ish: 4096x4096 rows c128', (4096, 4096), 'D', (1,))
