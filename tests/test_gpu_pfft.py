@@ -458,3 +458,18 @@ def test_padded_distributed_transform_with_a_mix5_length_keeps_the_staged_wire()
     for r, (piped, uh) in enumerate(cases.run_ranks(P, body)):
         assert not piped, 'a stage without fused adapters cannot be pipelined'
         assert uh.shape == want[r].shape and np.abs(uh - want[r]).max() <= 2e-10 * np.abs(want[r]).max()
+
+
+@pytest.mark.parametrize('P,shape,dt,kw', [
+    (4, (240, 112, 480), 'D', {}),                                  # 3 x 5 x 2^k / 7 x 2^k lengths on every axis, pencil grid
+    (2, (240, 240, 224), 'd', {}),                                  # real: packed rows of 2 x 112, half spectrum 113 wide
+    (8, (240, 240, 240), 'F', {}),
+    (4, (160, 160, 160), 'D', dict(padding=[1.5, 1.5, 1.5])),       # 3/2-rule ONTO 240: truncation / padding on their own kernels
+    (2, (240, 448), 'D', dict(collapse=True)),
+    (4, (112, 240, 64), 'D', dict(grid=(-1,))),                     # slab
+])
+def test_unequal_width_stage_lengths_in_distributed_transforms(P, shape, dt, kw):
+    """Round 5 lengths (csrc/fft_mixv_*.hip) inside multi-rank PFFTs: their plans refuse exchange-buffer layouts
+    (gfft_plan_set_split / _set_tiles) and fused truncation, so these transforms take pack / unpack kernels, the staged
+    wire and the stand-alone truncate / pad kernels -- same values as the oracle, same geometry as the reference."""
+    cases.check_pfft_vs_oracle(P, shape, dt, **kw)
