@@ -282,7 +282,26 @@ def test_two_pass_235_lengths(n):
     _check((2, n, 3), (1,), 'F')
 
 
-@pytest.mark.parametrize('n', [240, 480, 960, 1920, 3840, 720, 1440, 2880, 1200, 2400, 112, 224, 448, 896, 1792, 3584])
+MIXV_ALL = [98, 112, 120, 140, 150, 168, 180, 210, 224, 240, 250, 252, 280, 300, 336, 350, 360, 392, 420, 448, 450, 480, 490, 540, 560, 588,
+            600, 672, 700, 720, 750, 784, 840, 896, 900, 960, 980, 1008, 1050, 1120, 1200, 1260, 1344, 1400, 1440, 1500, 1680, 1792, 1800,
+            1920, 2100, 2160, 2240, 2250, 2400, 2700, 2800, 2880, 3000, 3584, 3600, 3840]      # (tools/gen_mixv_tables.py prints this list)
+
+
+@pytest.mark.parametrize('dt', ['D', 'F'])
+def test_every_generated_unequal_width_plan(dt):
+    """All 62 lengths of csrc/fft_mixv_*.hip (generated: tools/gen_mixv_tables.py): one pass, rows and ragged strided tiles and
+    real lines of twice the length, against the oracle."""
+    from mpi4py_fft_amd import FFT, _lib
+    for n in MIXV_ALL:
+        for shape, axes, d in (((3, n), (1,), dt), ((n, 21), (0,), dt), ((5, 2 * n), (1,), dt.lower())):
+            fft = FFT(shape, axes, dtype=d)
+            desc = _lib.engine().plan_describe(fft.fwd._plan)
+            assert desc.count('kernel=regs') == 1 and '1 passes' in desc, (n, desc)
+            fft.destroy()
+            _check(shape, axes, d, seed=n)
+
+
+@pytest.mark.parametrize('n', [240, 480, 960, 1920, 3840, 720, 1440, 2880, 1200, 2400, 112, 224, 448, 896, 1792, 3584, 336, 600, 840, 1008, 1680, 3000, 3600])
 @pytest.mark.parametrize('dt', ['D', 'F'])
 def test_one_pass_kernels_for_3x5x2k_lengths(n, dt):
     """Round 5: lengths 3 x 5 x 2^k (and 9 x 5 x 2^k, 3 x 25 x 2^k) and 7 x 2^k as ONE register-kernel pass whose stages keep different
