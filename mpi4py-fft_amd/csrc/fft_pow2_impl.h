@@ -1408,7 +1408,7 @@ hipError_t launch_pow2_one(const PassDesc &d, const void *in, void *out, hipStre
   constexpr int NT = Geo<N, R, RADS...>::TPC;
   constexpr int threads = T * NT;
   // (plans whose stages keep different numbers of values per thread: plain natural-layout complex passes only)
-  if (!Geo<N, R, RADS...>::UNIFORM && (d.in_lgp || d.out_lgp || d.in_tlg || d.out_tlg || d.tr_dir || d.tw_hi)) return hipErrorInvalidValue;
+  if (!Geo<N, R, RADS...>::UNIFORM && (d.in_lgp || d.out_lgp || d.in_tlg || d.out_tlg || d.tw_hi || d.tr_jump)) return hipErrorInvalidValue;
   static_assert(threads >= 64 && threads <= 1024, "workgroup size");
   constexpr size_t lds_x = (sizeof...(RADS) > 1 || (FLAGS & 32) || MODE == MODE_R2C_H || MODE == MODE_C2R_H) ? (size_t)T * Lds<N, COLS, T, (SPLIT && sizeof(real) == 4), FirstRadix<RADS...>::value>::CS * (SPLIT ? sizeof(real) : 2 * sizeof(real)) : 0;
   constexpr size_t lds_f = (FLAGS & 16) ? (size_t)T * 2 * sizeof(real) : 0;

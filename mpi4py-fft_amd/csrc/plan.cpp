@@ -266,7 +266,8 @@ bool fused_pad_ok(int64_t n_axis) {
   (void)n_axis;
   return true;
 #else
-  return !(n_axis <= 4096 && (mix5_supported((int)n_axis) || mixv_supported((int)n_axis)));
+  // (the unequal-width stage kernels carry the adapters on lengths divisible by 3: what the 3/2-rule makes of 5 x 2^k, 7 x 2^k ...)
+  return !(n_axis <= 4096 && (mix5_supported((int)n_axis) || (mixv_supported((int)n_axis) && n_axis % 3 != 0)));
 #endif
 }
 
@@ -1258,7 +1259,7 @@ int plan_fused3(gfft_plan_s *pl) {
     p.d.out_es = 1;
     p.src = src; p.dst = dst;
     if (mode != MODE_C2C && opts().real_half && n2 % 2 == 0 &&
-        (real_half_supported((int)(n2 / 2)) || real_half_mix_supported((int)(n2 / 2)) || (!tr && real_half_mixv_ok(n2 / 2)))) {
+        (real_half_supported((int)(n2 / 2)) || real_half_mix_supported((int)(n2 / 2)) || real_half_mixv_ok(n2 / 2))) {
       // packed-real form: complex length n2/2, the real side (the user's natural array) in pairs
       p.d.n = (int)(n2 / 2);
       p.d.mode = mode == MODE_R2C ? MODE_R2C_H : MODE_C2R_H;
@@ -1727,12 +1728,15 @@ int gfft_plan_create_padded(gfft_plan *plan, const int64_t *padded, const int64_
   if (rc) return rc;
   // the all-axes schedule needs one register-kernel pass per axis (packed-real rows on a real axis)
   if (!opts().fused3) return fail(GFFT_ERR_UNSUPPORTED, "fused 3-D plans are switched off");
-  for (int i = 0; i < 3; ++i)
-    if (!regk_ok(padded[i], precision) || (kept[i] < (i == 2 && real ? padded[i] / 2 + 1 : padded[i]) &&
-                                           !fused_pad_ok(i == 2 && real ? padded[i] / 2 : padded[i])))
+  for (int i = 0; i < 3; ++i) {
+    const bool real_axis = i == 2 && real;
+    const bool one_pass = regk_ok(padded[i], precision) ||
+                          (real_axis ? (padded[i] % 2 == 0 && real_half_mixv_ok(padded[i] / 2)) : regk_c2c_ok(padded[i], precision, MODE_C2C));
+    if (!one_pass || (kept[i] < (real_axis ? padded[i] / 2 + 1 : padded[i]) && !fused_pad_ok(real_axis ? padded[i] / 2 : padded[i])))
       return fail(GFFT_ERR_UNSUPPORTED, "padded length without a single-pass kernel");
+  }
   if (real && !(opts().real_half && padded[2] % 2 == 0 &&
-                (real_half_supported((int)(padded[2] / 2)) || real_half_mix_supported((int)(padded[2] / 2)))))
+                (real_half_supported((int)(padded[2] / 2)) || real_half_mix_supported((int)(padded[2] / 2)) || real_half_mixv_ok(padded[2] / 2))))
     return fail(GFFT_ERR_UNSUPPORTED, "real axis without a packed-real row kernel");
   const int64_t bytes = padded[0] * padded[1] * padded[2] * (real ? 1 : 2) * precision;
   if (bytes < opts().fused3_min_bytes) return fail(GFFT_ERR_UNSUPPORTED, "below the size where the workspace schedule pays");

@@ -360,7 +360,9 @@ def test_reference_docs_convolution_example(P):
 @pytest.mark.parametrize('dt', 'dfDF')
 @pytest.mark.parametrize('shape,padding', [((32, 32, 64), [1.5] * 3), ((64, 32, 128), [1.5] * 3),
                                            ((32, 64, 32), [1.5, 1, 2]), ((43, 32, 64), [1.5] * 3),
-                                           ((128, 43, 64), [1.5, 1.5, 1.5])])      # (odd kept lengths: 43 -> 64)
+                                           ((128, 43, 64), [1.5, 1.5, 1.5]),      # (odd kept lengths: 43 -> 64)
+                                           # round 5: 3/2-rule ONTO unequal-width stage lengths (160 -> 240, 224 -> 336, 320 -> 480)
+                                           ((160, 224, 320), [1.5] * 3), ((80, 160, 160), [1.5, 1.5, 1.5])])
 def test_padded_transform_as_one_plan(dt, shape, padding, monkeypatch):
     """One rank, padding: the three padded stages run as ONE plan through libgfft's pitched workspace
     (gfft_plan_create_padded).  Forward against the oracle (libfft.py:263-311 per stage), forward and

@@ -356,6 +356,30 @@ def test_mix5_3d(shape, dt):
 
 
 @pytest.mark.parametrize('dt', ['D', 'd', 'F', 'f'])
+def test_fused_truncation_and_padding_on_unequal_width_lengths(dt):
+    """Round 5: the 3/2-rule applied to 5 x 2^k / 7 x 2^k grids lands on 3 x 5 x 2^k / 3 x 7 x 2^k lengths (160 -> 240, 640 -> 960,
+    448 -> 672); their kernels (csrc/fft_mixv_*.hip) carry the truncating store / zero-padding load where the length
+    divides by 3 -- values against the oracle, even and odd kept lengths, rows / strided / real lines."""
+    from mpi4py_fft_amd import FFT, asdevice
+    # (shapes are the TRANSFORMED, i.e. padded, ones: 240 keeps 160, 960 keeps 640, 672 keeps 448 ...)
+    for shp, axis, padding in (((240, 6), 0, 1.5), ((5, 960), 1, 1.5), ((4, 480, 3), 1, 1.5), ((672, 5), 0, 1.5), ((3, 1920), 1, 1.5),
+                               ((2, 336), 1, 1.5), ((7, 240), 1, 240 / 161.), ((840, 20), 0, 1.5), ((2, 3600), 1, 1.5)):
+        fft = FFT(shp, axis, dtype=dt, padding=padding)
+        # (a REAL transform along a strided axis has no kernel on these lengths -- LDS kernel + separate truncation: still checked)
+        assert fft._fused_trunc or (dt in 'df' and axis != len(shp) - 1), (shp, axis, padding)
+        ref = O.OFFT(shp, axis, dt, padding=padding)
+        A = O.rng_array(shp, dt, 23)
+        B = np.asarray(fft.forward(asdevice(A))).copy()
+        Bref = ref.forward(A)
+        tol = _tol(dt)
+        assert B.shape == Bref.shape and B.dtype == Bref.dtype
+        assert np.abs(B - Bref).max() <= tol * np.abs(Bref).max(), (shp, axis, padding, dt)
+        A1 = np.asarray(fft.backward(asdevice(Bref))).copy()
+        assert np.abs(A1 - ref.backward(Bref)).max() <= 10 * tol * np.abs(A).max(), (shp, axis, padding, dt)
+        fft.destroy()
+
+
+@pytest.mark.parametrize('dt', ['D', 'd', 'F', 'f'])
 def test_fused_truncation_and_padding(dt):
     """3/2-rule truncation / zero padding fused into the transform (gfft_plan_set_truncation) on
     register-kernel lengths: values vs the oracle, even and odd truncated lengths, contiguous and

@@ -154,6 +154,12 @@ namespace gfft {
 
 #define %(X)s(N, R, T, COLS, MINW, ...) \\
   launch_pow2_inst<%(real)s, N, R, T, COLS, true, MINW, 8, __VA_ARGS__>(d, in, out, s)
+// lengths divisible by 3 -- what the 3/2-rule makes of 2^k, 5 x 2^k, 7 x 2^k ... (640 -> 960, 1280 -> 1920, 448 -> 672) -- also carry
+// the fused truncating store (forward) and zero-padding load (backward) of libfft.py:263-311 (FLAGS 16, 16 | 64)
+#define %(X)sT(N, R, T, COLS, MINW, ...)                                                                                          \\
+  (d.tr_dir == 1 ? launch_pow2_one<%(real)s, N, R, T, COLS, true, MINW, 16, MODE_C2C, false, __VA_ARGS__>(d, in, out, s)           \\
+   : d.tr_dir == 2 ? launch_pow2_one<%(real)s, N, R, T, COLS, true, MINW, 16 | 64, MODE_C2C, false, __VA_ARGS__>(d, in, out, s) \\
+                   : launch_pow2_inst<%(real)s, N, R, T, COLS, true, MINW, 8, __VA_ARGS__>(d, in, out, s))
 %(supp)s
 hipError_t launch_mixv_%(sfx)s(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s) {
   if (d.mode != MODE_C2C) return hipErrorInvalidValue;
@@ -173,7 +179,15 @@ hipError_t launch_mixv_%(sfx)s(const PassDesc &d, bool cols, const void *in, voi
 // the geometry of the side it sits on (after the last stage for r2c, before the first for c2r).  Plain rows only.
 template <int MODE>
 static hipError_t halfv_%(sfx)s(const PassDesc &d, const void *in, void *out, hipStream_t s) {
-  if (d.tr_dir || d.ub_p > 1) return hipErrorInvalidValue;
+  if (d.ub_p > 1) return hipErrorInvalidValue;
+  if (d.tr_dir) {      // fused truncating store (r2c) / zero-padding load (c2r): the lengths divisible by 3
+    if ((MODE == MODE_R2C_H) != (d.tr_dir == 1)) return hipErrorInvalidValue;
+    constexpr int TF = MODE == MODE_R2C_H ? 16 : (16 | 64);
+    switch (d.n) {
+%(halft)s
+    }
+    return hipErrorInvalidValue;
+  }
   switch (d.n) {
 %(half)s
   }
@@ -200,8 +214,10 @@ def emit(real, sfx, X, real_bytes, hdr, with_supp):
         supp = '\nbool mixv_supported(int n) {\n  switch (n) {\n%s\n      return true;\n  }\n  return false;\n}\n' % '\n'.join(lines)
     txt = hdr + BODY % dict(
         X=X, real=real, sfx=sfx, supp=supp,
-        rows='\n'.join('      case %d: return %s(%d, %d, %d, false, 1, %s);' % (n, X, n, R, t, r) for n, R, t, r in rows),
-        cols='\n'.join('      case %d: return %s(%d, %d, %d, true, %d, %s);' % (n, X, n, R, T, mw, r) for n, R, T, mw, r in cols),
+        rows='\n'.join('      case %d: return %s(%d, %d, %d, false, 1, %s);' % (n, X + ('T' if n % 3 == 0 else ''), n, R, t, r) for n, R, t, r in rows),
+        cols='\n'.join('      case %d: return %s(%d, %d, %d, true, %d, %s);' % (n, X + ('T' if n % 3 == 0 else ''), n, R, T, mw, r) for n, R, T, mw, r in cols),
+        halft='\n'.join('      case %d: return launch_pow2_one<%s, %d, %d, %d, false, true, 1, TF, MODE, false, %s>(d, in, out, s);'
+                        % (n, real, n, R, t, r) for n, R, t, r in rows if n % 3 == 0),
         half='\n'.join('    case %d: return launch_pow2_one<%s, %d, %d, %d, false, true, 1, 0, MODE, false, %s>(d, in, out, s);'
                        % (n, real, n, R, t, r) for n, R, t, r in rows))
     open(os.path.join(CSRC, 'fft_mixv_%s.hip' % sfx), 'w').write(txt)
