@@ -86,10 +86,25 @@ struct Fused512R32 {
 // with variant 1, tools/ab_combo_probe.py, profiles/r04_ab_fuse2_variants.txt); 2 / 4 = (make VARIANTS=1) 8 lines per tile,
 // two workgroups per CU, with 16 / 32 values per thread: 40.6 / 39.7 ms per step, a quarter SLOWER -- what bounds the fused
 // launch is the traffic its CUs can move across the L2 boundary, and 128-byte pieces move less of it
+// Round 5: the 3-D schedule's pair [strided n -> rows n] on two of the unequal-width stage lengths (fft_mixv_f64.hip): 16 values
+// per thread on 1024-thread workgroups (the radix-15 / radix-7 stage keeps 15 / 14 of them), 16 lines per tile
+struct Fused960 {
+  typedef PassCfg<double, 960, 16, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 15, 16, 4> ColsToRing;
+  typedef PassCfg<double, 960, 16, 16, false, true, 2 | 4096 | 8192, MODE_C2C, false, 15, 16, 4> RowsFromRing;
+};
+struct Fused896 {
+  typedef PassCfg<double, 896, 16, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 7, 16, 8> ColsToRing;
+  typedef PassCfg<double, 896, 16, 16, false, true, 2 | 4096 | 8192, MODE_C2C, false, 7, 16, 8> RowsFromRing;
+};
+// (the same pairs on 32 values per thread / 512 threads, as the 2^k pairs run since round 4, were built and measured: level,
+// profiles/r05_ab_mixv_wide.txt -- not kept)
+int g_fuse2_mixv = 1;          // option fuse2_mixv
+
 extern int g_fuse2_n512;
 bool fused2_supported_f64(int kind, int variant, int n_a, int n_b) {
   (void)kind;
   if (n_a != n_b) return false;
+  if (n_a == 960 || n_a == 896) return g_fuse2_mixv != 0 && variant == 1 && kind == FUSED_COLS_ROWS;
 #ifdef GFFT_VARIANTS
   if (variant == 2 || variant == 4) return n_a == 1024;
 #endif
@@ -106,6 +121,12 @@ int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &
   if (variant == 2) return fused2_tiles_kind<Fused1024x8>(kind, dA, dB, tiles_a, tiles_b);
   if (variant == 4) return fused2_tiles_kind<Fused1024x8R32>(kind, dA, dB, tiles_a, tiles_b);
 #endif
+  if (dA.n == 960 || dA.n == 896) {
+    if (kind != FUSED_COLS_ROWS) return -1;
+    *tiles_a = (int)(dA.n == 960 ? Fused960::ColsToRing::ntiles(dA) : Fused896::ColsToRing::ntiles(dA));
+    *tiles_b = (int)(dA.n == 960 ? Fused960::RowsFromRing::ntiles(dB) : Fused896::RowsFromRing::ntiles(dB));
+    return 0;
+  }
   if (variant == 3) return fused2_tiles_kind<FusedCfgs<double, 1024>>(kind, dA, dB, tiles_a, tiles_b);
   if (dA.n == 512) return fused2_tiles_kind<Fused512R32>(kind, dA, dB, tiles_a, tiles_b);
   return fused2_tiles_kind<Fused1024R32>(kind, dA, dB, tiles_a, tiles_b);
@@ -117,6 +138,9 @@ hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const Pa
   if (variant == 2) return launch_fused2_kind<Fused1024x8>(kind, dA, dB, dev_descs, f, in, ring, out, s);
   if (variant == 4) return launch_fused2_kind<Fused1024x8R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);
 #endif
+  if (dA.n == 960 && kind == FUSED_COLS_ROWS) return launch_fused2<Fused960::ColsToRing, Fused960::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s);
+  if (dA.n == 896 && kind == FUSED_COLS_ROWS) return launch_fused2<Fused896::ColsToRing, Fused896::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s);
+  if (dA.n == 960 || dA.n == 896) return hipErrorInvalidValue;
   if (variant == 3) return launch_fused2_kind<FusedCfgs<double, 1024>>(kind, dA, dB, dev_descs, f, in, ring, out, s);
   if (dA.n == 512) return launch_fused2_kind<Fused512R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);
   return launch_fused2_kind<Fused1024R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);

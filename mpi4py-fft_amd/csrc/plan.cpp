@@ -1585,6 +1585,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "fuse2_f32")) opts().fuse2_f32 = value;
   else if (!strcmp(key, "fuse2_n512")) gfft::g_fuse2_n512 = value;
   else if (!strcmp(key, "c2r_2048")) gfft::g_c2r_2048 = value;
+  else if (!strcmp(key, "fuse2_mixv")) gfft::g_fuse2_mixv = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "ws_plane_skew")) opts().ws_plane_skew = value;

@@ -71,6 +71,39 @@ def test_fused_3d_schedule_matches_the_unfused_one(shape, dt):
         b1.destroy()
 
 
+@pytest.mark.parametrize('n', [960, 896])
+def test_fused_3d_pair_on_unequal_width_stage_lengths(n):
+    """Round 5: [axis 0 -> rows] of the complex 3-D schedule at n0 = n2 = 960 / 896 (csrc/fft_fused_f64.hip Fused960 / Fused896: the
+    tiles' stages keep different numbers of values per thread): against the unfused plans, numpy, run to run."""
+    from mpi4py_fft_amd import _lib
+    shape = (n, 40, n)
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    a0, f0, b0 = _plans(shape, (0, 1, 2), 0)
+    assert 'fused pair' not in _lib.engine().plan_describe(f0._plan)
+    a0[...] = x
+    want = np.asarray(f0.execute_scaled(a0, f0.output_array, 1.0)).copy()
+    ref = np.fft.fftn(x)
+    assert np.abs(want - ref).max() <= 2e-10 * np.abs(ref).max()
+    f0.destroy()
+    b0.destroy()
+    for ring, lag in ((8, 4), (12, 6), (5, 2)):
+        a1, f1, b1 = _plans(shape, (0, 1, 2), 1, ring, lag, 126)
+        assert 'fused pair (strided -> rows)' in _lib.engine().plan_describe(f1._plan), _lib.engine().plan_describe(f1._plan)
+        assert 'fused pair (strided -> rows)' in _lib.engine().plan_describe(b1._plan)
+        a1[...] = x
+        for rep in range(3):
+            got = np.asarray(f1.execute_scaled(a1, f1.output_array, 1.0))
+            assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), (ring, lag, rep)
+            if rep == 0:
+                first = got.copy()
+            assert np.array_equal(got, first)
+            back = np.asarray(b1.execute_scaled(f1.output_array, b1.output_array, 1.0 / x.size))
+            assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
+        f1.destroy()
+        b1.destroy()
+
+
 @pytest.mark.parametrize('shape,dt', [((32, 1 << 20), 'D'), ((64, 1 << 20), 'F')])      # (complex64: round 5, csrc/fft_fused_f32.hip)
 def test_fused_four_step_matches_the_two_launch_form(shape, dt):
     from mpi4py_fft_amd import _lib

@@ -129,7 +129,8 @@ def configs(real_bytes):
         sizes.append(n)
         r = ', '.join(map(str, rads))
         rows.append((n, R, t, r))
-        cols.append((n, Rc, T, minw, r))
+        wide = None      # (fp64 on 32 values per thread / 512 threads was generated and measured in round 5: level, profiles/r05_ab_mixv_wide.txt)
+        cols.append((n, Rc, T, minw, r, wide))
     return sizes, rows, cols
 
 
@@ -152,7 +153,7 @@ BODY = '''#include "fft_pow2_impl.h"
 
 namespace gfft {
 
-#define %(X)s(N, R, T, COLS, MINW, ...) \\
+%(wide_decl)s#define %(X)s(N, R, T, COLS, MINW, ...) \\
   launch_pow2_inst<%(real)s, N, R, T, COLS, true, MINW, 8, __VA_ARGS__>(d, in, out, s)
 // lengths divisible by 3 -- what the 3/2-rule makes of 2^k, 5 x 2^k, 7 x 2^k ... (640 -> 960, 1280 -> 1920, 448 -> 672) -- also carry
 // the fused truncating store (forward) and zero-padding load (backward) of libfft.py:263-311 (FLAGS 16, 16 | 64)
@@ -214,8 +215,12 @@ def emit(real, sfx, X, real_bytes, hdr, with_supp):
         supp = '\nbool mixv_supported(int n) {\n  switch (n) {\n%s\n      return true;\n  }\n  return false;\n}\n' % '\n'.join(lines)
     txt = hdr + BODY % dict(
         X=X, real=real, sfx=sfx, supp=supp,
+        wide_decl='',
         rows='\n'.join('      case %d: return %s(%d, %d, %d, false, 1, %s);' % (n, X + ('T' if n % 3 == 0 else ''), n, R, t, r) for n, R, t, r in rows),
-        cols='\n'.join('      case %d: return %s(%d, %d, %d, true, %d, %s);' % (n, X + ('T' if n % 3 == 0 else ''), n, R, T, mw, r) for n, R, T, mw, r in cols),
+        cols='\n'.join('      case %d: %sreturn %s(%d, %d, %d, true, %d, %s);' % (
+                            n, ('if (g_mixv_wide && !d.tr_dir) return launch_pow2_inst<%s, %d, %d, %d, true, true, %d, 8 | 3, %s>(d, in, out, s);\n                '
+                                % (real, n, w[0], w[1], w[2], r)) if w else '',
+                            X + ('T' if n % 3 == 0 else ''), n, R, T, mw, r) for n, R, T, mw, r, w in cols),
         halft='\n'.join('      case %d: return launch_pow2_one<%s, %d, %d, %d, false, true, 1, TF, MODE, false, %s>(d, in, out, s);'
                         % (n, real, n, R, t, r) for n, R, t, r in rows if n % 3 == 0),
         half='\n'.join('    case %d: return launch_pow2_one<%s, %d, %d, %d, false, true, 1, 0, MODE, false, %s>(d, in, out, s);'
@@ -229,4 +234,4 @@ s32, r32, c32 = emit('float', 'f32', 'X32', 4, HDR32, False)
 assert s64 == s32, (sorted(set(s64) ^ set(s32)))
 print(len(s64), 'lengths:', s64)
 for a, b in zip(c64, c32):
-    print(a, b)
+    print(a, b[:5])
