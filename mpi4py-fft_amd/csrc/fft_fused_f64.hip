@@ -96,8 +96,8 @@ struct Fused896 {
   typedef PassCfg<double, 896, 16, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 7, 16, 8> ColsToRing;
   typedef PassCfg<double, 896, 16, 16, false, true, 2 | 4096 | 8192, MODE_C2C, false, 7, 16, 8> RowsFromRing;
 };
-// (the same pairs on 32 values per thread / 512 threads, as the 2^k pairs run since round 4, were built and measured: level,
-// profiles/r05_ab_mixv_wide.txt -- not kept)
+// (the same pairs on 32 values per thread / 512 threads, as the 2^k pairs run since round 4, compile without spills -- 219 VGPRs --
+// but were not measured properly and are not built)
 int g_fuse2_mixv = 1;          // option fuse2_mixv
 
 extern int g_fuse2_n512;

@@ -129,7 +129,7 @@ def configs(real_bytes):
         sizes.append(n)
         r = ', '.join(map(str, rads))
         rows.append((n, R, t, r))
-        wide = None      # (fp64 on 32 values per thread / 512 threads was generated and measured in round 5: level, profiles/r05_ab_mixv_wide.txt)
+        wide = None      # (fp64 on 32 values per thread / 512 threads compiles -- 212 VGPRs at n = 960 -- but has not been measured: not generated)
         cols.append((n, Rc, T, minw, r, wide))
     return sizes, rows, cols
 
