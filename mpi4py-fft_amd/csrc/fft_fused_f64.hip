@@ -86,18 +86,20 @@ struct Fused512R32 {
 // with variant 1, tools/ab_combo_probe.py, profiles/r04_ab_fuse2_variants.txt); 2 / 4 = (make VARIANTS=1) 8 lines per tile,
 // two workgroups per CU, with 16 / 32 values per thread: 40.6 / 39.7 ms per step, a quarter SLOWER -- what bounds the fused
 // launch is the traffic its CUs can move across the L2 boundary, and 128-byte pieces move less of it
-// Round 5: the 3-D schedule's pair [strided n -> rows n] on two of the unequal-width stage lengths (fft_mixv_f64.hip): 16 values
-// per thread on 1024-thread workgroups (the radix-15 / radix-7 stage keeps 15 / 14 of them), 16 lines per tile
+// Round 5: the 3-D schedule's pair [strided n -> rows n] on two of the unequal-width stage lengths (fft_mixv_f64.hip): 32 values per
+// thread on 512-thread workgroups of up to 256 VGPRs (219, no spills; the radix-15 / radix-7 stage keeps 30 / 28 of the 32), 16
+// lines per tile.  Same arrays, plans alternating: 960^3 c128 per step 34.07 -> 30.54 ms with the pair on 16 values per thread / 1024
+// threads (profiles/r05_ab_fuse2_mixv.txt), its launch 9.66 / 9.76 -> 9.58 / 9.62 ms on 32 values; 896^3 26.96 -> 26.03 ms, the launch
+// 8.11 / 8.19 -> 7.80 / 7.83 ms (profiles/r05_ab_mixv_variants.txt).  (The STAND-ALONE strided kernels of these lengths lose 3-16 % on
+// 32 values per thread, same file: they keep 16.)
 struct Fused960 {
-  typedef PassCfg<double, 960, 16, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 15, 16, 4> ColsToRing;
-  typedef PassCfg<double, 960, 16, 16, false, true, 2 | 4096 | 8192, MODE_C2C, false, 15, 16, 4> RowsFromRing;
+  typedef PassCfg<double, 960, 32, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 15, 16, 4> ColsToRing;
+  typedef PassCfg<double, 960, 32, 16, false, true, 2 | 4096 | 8192, MODE_C2C, false, 15, 16, 4> RowsFromRing;
 };
 struct Fused896 {
-  typedef PassCfg<double, 896, 16, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 7, 16, 8> ColsToRing;
-  typedef PassCfg<double, 896, 16, 16, false, true, 2 | 4096 | 8192, MODE_C2C, false, 7, 16, 8> RowsFromRing;
+  typedef PassCfg<double, 896, 32, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 7, 16, 8> ColsToRing;
+  typedef PassCfg<double, 896, 32, 16, false, true, 2 | 4096 | 8192, MODE_C2C, false, 7, 16, 8> RowsFromRing;
 };
-// (the same pairs on 32 values per thread / 512 threads, as the 2^k pairs run since round 4, compile without spills -- 219 VGPRs --
-// but were not measured properly and are not built)
 int g_fuse2_mixv = 1;          // option fuse2_mixv
 
 extern int g_fuse2_n512;

@@ -217,8 +217,8 @@ hipError_t launch_mix3_f64(const PassDesc &d, bool cols, const void *in, void *o
 hipError_t launch_mix3_f32(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
 // lengths 3 x 5 x 2^k and neighbours, stages of unequal width (fft_mixv_*.hip): plain complex passes only
 bool mixv_supported(int n);
-hipError_t launch_mixv_f64(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
-hipError_t launch_mixv_f32(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
+hipError_t launch_mixv_f64(const PassDesc &d, bool cols, int variant, const void *in, void *out, hipStream_t s);
+hipError_t launch_mixv_f32(const PassDesc &d, bool cols, int variant, const void *in, void *out, hipStream_t s);
 hipError_t launch_real_half_mixv_f64(const PassDesc &d, const void *in, void *out, hipStream_t s);     // packed-real rows, d.n = complex length
 hipError_t launch_real_half_mixv_f32(const PassDesc &d, const void *in, void *out, hipStream_t s);
 // lengths 5^c * 2^k with R = 20 (fft_mix5_*.hip)

@@ -72,6 +72,7 @@ struct Options {
   int real_half = 1;         // contiguous real lines as half-length complex transforms (fft_real_*.hip)
   int debug_flat = 0;        // gfft_debug_pass: tiles over the flattened (mid, inner) index
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
+  int mixv_variant = 0;      // A/B: alternative kernels of the unequal-width lengths (tools/gen_mixv_tables.py)
   int mixv = 1;              // one-pass kernels for 3 x 5 x 2^k lengths (fft_mixv_*.hip); 0: the two-pass plans of rounds 1-4 (A/B)
   int pitch129 = 1;          // 3-D schedules: avoid workspace pitches of 129 x 2^k entries (plan_fused3)
   int pitch_extra = 0;       // A/B: lines (128 B) added to the workspace pitch
@@ -392,6 +393,7 @@ struct gfft_plan_s {
   double flops = 0, bytes = 0;
   int variant_rows = 0, variant_cols = 0, xcd_swizzle = 0;
   bool fused3 = false;
+  int mixv_variant = 0;                        // option mixv_variant at plan time (fft_mixv_*.hip: measured alternatives)
   int64_t ws_pitch = 0;                        // plan_fused3: entries between consecutive rows of the workspace
   std::vector<int64_t> trunc;                  // gfft_plan_create_padded: kept entries per axis (else empty)
   std::vector<std::vector<hipEvent_t>> prof;   // per execute: events before pass 0 and after each pass
@@ -1511,7 +1513,7 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
     return pl->precision == 8 ? launch_mix5_f64(d, p.cols, in, out, s) : launch_mix5_f32(d, p.cols, in, out, s);
   }
   if (p.regk && mixv_supported(d.n)) {
-    return pl->precision == 8 ? launch_mixv_f64(d, p.cols, in, out, s) : launch_mixv_f32(d, p.cols, in, out, s);
+    return pl->precision == 8 ? launch_mixv_f64(d, p.cols, pl->mixv_variant, in, out, s) : launch_mixv_f32(d, p.cols, pl->mixv_variant, in, out, s);
   }
   if (p.regk) {
     const int variant = p.cols ? pl->variant_cols : pl->variant_rows;
@@ -1591,6 +1593,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "ws_plane_skew")) opts().ws_plane_skew = value;
   else if (!strcmp(key, "pitch129")) opts().pitch129 = value;
   else if (!strcmp(key, "mixv")) opts().mixv = value;
+  else if (!strcmp(key, "mixv_variant")) opts().mixv_variant = value;
   else if (!strcmp(key, "pitch_extra")) opts().pitch_extra = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
   else if (!strcmp(key, "debug_tile_side")) opts().debug_tile_side = value;
@@ -1641,6 +1644,7 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
   pl->axes = ax;
   pl->variant_rows = opts().variant_rows;
   pl->variant_cols = opts().variant_cols;
+  pl->mixv_variant = opts().mixv_variant;
   pl->xcd_swizzle = opts().xcd_swizzle;
 
   rc = GFFT_OK;
@@ -1752,6 +1756,7 @@ int gfft_plan_create_padded(gfft_plan *plan, const int64_t *padded, const int64_
   pl->trunc = spec;
   pl->variant_rows = opts().variant_rows;
   pl->variant_cols = opts().variant_cols;
+  pl->mixv_variant = opts().mixv_variant;
   pl->xcd_swizzle = opts().xcd_swizzle;
   rc = plan_fused3(pl);
   if (rc) {
@@ -1793,6 +1798,7 @@ int gfft_plan_create_r2r(gfft_plan *plan, int ndims, const int64_t *sizes, int n
   pl->axes = ax;
   pl->variant_rows = opts().variant_rows;
   pl->variant_cols = opts().variant_cols;
+  pl->mixv_variant = opts().mixv_variant;
   pl->xcd_swizzle = opts().xcd_swizzle;
   for (int i = naxes - 1; i >= 0 && !rc; --i) {
     int64_t outer = 1, inner = 1;
@@ -2154,6 +2160,7 @@ int gfft_plan_create_guru_padded(gfft_plan *plan, int precision, int kind, const
   pl->precision = precision;
   pl->variant_rows = opts().variant_rows;
   pl->variant_cols = opts().variant_cols;
+  pl->mixv_variant = opts().mixv_variant;
   pl->xcd_swizzle = opts().xcd_swizzle;
   Pass p;
   p.regk = true;

@@ -9,6 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), 'mpi4py-fft_amd', 'csrc')
 RADS = [20, 16, 15, 12, 10, 8, 7, 5, 4, 3, 2]
+ALTS = set()      # lengths that carry the measured alternatives: {960, 896, 840, 672, 480, 1440} for profiles/r05_ab_mixv_variants.txt, none since
 
 HAND = {240: (15, 16), 480: (15, 16, 2), 960: (15, 16, 4), 1920: (15, 16, 8), 3840: (15, 16, 16),
         720: (15, 3, 16), 1440: (15, 3, 16, 2), 2880: (15, 3, 16, 4), 1200: (15, 5, 16), 2400: (15, 5, 16, 2),
@@ -129,7 +130,24 @@ def configs(real_bytes):
         sizes.append(n)
         r = ', '.join(map(str, rads))
         rows.append((n, R, t, r))
-        wide = None      # (fp64 on 32 values per thread / 512 threads compiles -- 212 VGPRs at n = 960 -- but has not been measured: not generated)
+        # measured alternatives, selected per PLAN by option mixv_variant (tools/ab_combo_probe.py): 1 = fp64 on twice the values per
+        # thread, 512-thread workgroups of up to 256 VGPRs, non-temporal loads and stores (what the 2^k tables' n = 512 / 1024 strided
+        # kernels run since round 4); 2 = fp32 on the fp64 plan's values per thread (no spills, half the segment width)
+        wide = None
+        if n in ALTS and real_bytes == 8 and 2 * R <= 32 and geometry(n, 2 * R, rads) is not None:
+            _, tpc_w = geometry(n, 2 * R, rads)
+            Tw = pow2_floor(max(1, min(16, 512 // tpc_w)))
+            while Tw >= 4 and Tw * lds_words(n, Tw, False) * 8 > 160 * 1024:
+                Tw //= 2
+            if Tw >= T and Tw * tpc_w >= 64:
+                wide = ('1', 2 * R, Tw, 2 if Tw * tpc_w > 256 else 1, '8 | 3')
+        if n in ALTS and real_bytes == 4 and Rc != R:
+            _, tpc_n = geometry(n, R, rads)
+            Tn = pow2_floor(max(1, min(32, 1024 // tpc_n)))
+            while Tn >= 4 and Tn * lds_words(n, Tn, True) * 4 > 160 * 1024:
+                Tn //= 2
+            if Tn >= 4 and Tn * tpc_n >= 64:
+                wide = ('2', R, Tn, 4 if Tn * tpc_n > 512 else (2 if Tn * tpc_n > 256 else 1), '8')
         cols.append((n, Rc, T, minw, r, wide))
     return sizes, rows, cols
 
@@ -162,7 +180,8 @@ namespace gfft {
    : d.tr_dir == 2 ? launch_pow2_one<%(real)s, N, R, T, COLS, true, MINW, 16 | 64, MODE_C2C, false, __VA_ARGS__>(d, in, out, s) \\
                    : launch_pow2_inst<%(real)s, N, R, T, COLS, true, MINW, 8, __VA_ARGS__>(d, in, out, s))
 %(supp)s
-hipError_t launch_mixv_%(sfx)s(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s) {
+hipError_t launch_mixv_%(sfx)s(const PassDesc &d, bool cols, int variant, const void *in, void *out, hipStream_t s) {
+  (void)variant;
   if (d.mode != MODE_C2C) return hipErrorInvalidValue;
   if (!cols) {
     switch (d.n) {      // rows: whole rows per workgroup
@@ -218,8 +237,8 @@ def emit(real, sfx, X, real_bytes, hdr, with_supp):
         wide_decl='',
         rows='\n'.join('      case %d: return %s(%d, %d, %d, false, 1, %s);' % (n, X + ('T' if n % 3 == 0 else ''), n, R, t, r) for n, R, t, r in rows),
         cols='\n'.join('      case %d: %sreturn %s(%d, %d, %d, true, %d, %s);' % (
-                            n, ('if (g_mixv_wide && !d.tr_dir) return launch_pow2_inst<%s, %d, %d, %d, true, true, %d, 8 | 3, %s>(d, in, out, s);\n                '
-                                % (real, n, w[0], w[1], w[2], r)) if w else '',
+                            n, ('if (variant == %s && !d.tr_dir) return launch_pow2_inst<%s, %d, %d, %d, true, true, %d, %s, %s>(d, in, out, s);\n                '
+                                % (w[0], real, n, w[1], w[2], w[3], w[4], r)) if w else '',
                             X + ('T' if n % 3 == 0 else ''), n, R, T, mw, r) for n, R, T, mw, r, w in cols),
         halft='\n'.join('      case %d: return launch_pow2_one<%s, %d, %d, %d, false, true, 1, TF, MODE, false, %s>(d, in, out, s);'
                         % (n, real, n, R, t, r) for n, R, t, r in rows if n % 3 == 0),
