@@ -111,6 +111,43 @@ def test_1024cubed_roundtrip_c128():
     fft.destroy()
 
 
+@pytest.mark.parametrize('n', [960, 896, 840])
+def test_unequal_width_cubes_at_full_size_c128(n):
+    """Round 5: n^3 complex128 at n = 960 (15 x 16 x 4), 896 (7 x 16 x 8), 840 (12 x 10 x 7) -- one pass per axis on stages of unequal
+    width, the fused [axis 0 -> rows] pair at 960 / 896 -- at full size: Parseval, six lines against the DFT by definition (float64
+    sums on the device, the last axis in long double: oracle/dft_oracle.c), round trip <= 1e-10."""
+    import torch
+    free, total = torch.cuda.mem_get_info()
+    if free < 80 * 2 ** 30:
+        pytest.skip('needs ~80 GiB of HBM')
+    from mpi4py_fft_amd import PFFT, comm
+    fft = PFFT(comm.COMM_SELF, (n, n, n), dtype='D')
+    desc = fft._fused_plans[0]._eng.plan_describe(fft._fused_plans[0]._plan)
+    assert ('fused pair' in desc) == (n in (960, 896)), desc
+    assert desc.count('n=%d' % n) >= 2 and 'n=48' not in desc and 'n=128 ' not in desc, desc       # one pass per axis
+    u = fft.forward.input_array
+    g = torch.Generator(device='cuda').manual_seed(n)
+    ur = torch.view_as_real(u.tensor)
+    for i in range(0, n, 64):
+        ur[i:i + 64].copy_(torch.randn(ur[i:i + 64].shape, generator=g, device='cuda', dtype=torch.float64))
+    u0 = u.tensor.clone()
+    uh = fft.forward()
+    e_phys = float((torch.view_as_real(u0) ** 2).sum().item()) / u0.numel()
+    e_spec = float((torch.view_as_real(uh.tensor) ** 2).sum().item())
+    assert abs(e_phys - e_spec) <= 1e-10 * e_phys
+    from tests.test_gpu_c5 import _c_dft
+    dft = _c_dft()
+    for k0, k1 in [(3, 5), (n - 1, n - 1), (n // 2, 1), (n // 2 + 7, n // 4 + 3), (0, n // 2), (17, 0)]:
+        want = dft(_line_partial(u0, (0, 0, 0), k0, k1, n, n), -1, n, 'D') / float(n) ** 3
+        got = uh.tensor[k0, k1].cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-10 * np.abs(want).max(), (k0, k1, np.abs(got - want).max() / np.abs(want).max())
+    back = fft.backward()
+    num = float(((torch.view_as_real(back.tensor) - torch.view_as_real(u0)) ** 2).sum().sqrt().item())
+    den = float((torch.view_as_real(u0) ** 2).sum().sqrt().item())
+    assert num / den <= 1e-10, num / den
+    fft.destroy()
+
+
 # ((64, 128, 2048) / (32, 64, 4096): 1025- and 2049-wide half spectra and 2048-long complex rows, whose line-rounded
 # workspace pitches used to be 129 x 2^k entries -- the pitch rule of plan_fused3)
 @pytest.mark.parametrize('shape', [(128, 128, 128), (64, 128, 256), (256, 64, 128), (128, 256, 64), (32, 512, 1024), (64, 128, 2048),
