@@ -207,15 +207,17 @@ def default_lines(shape):
 
 
 def forward_gate(fft, world, u0, uh=None, lines=None):
-    """max over `lines` of |forward - DFT| / max|DFT| for a 3-D complex transform over all axes whose
-    input pencil keeps axis 2 whole (the default plan): `u0` = this rank's block of the input (natural
+    """max over `lines` of |forward - DFT| / max|DFT| for a 3-D transform over all axes -- complex, or real with the
+    half spectrum along the last axis -- whose input pencil keeps axis 2 whole (the default plan): `u0` = this rank's block of the input (natural
     layout, left untouched), `uh` = this rank's block of the forward output (default: the planned output
     array, which must hold forward(u0)).  Collective over `world`."""
     import torch
     pin, pout = fft.pencil
     shape = tuple(int(s) for s in pin.shape)
     assert len(shape) == 3 and pin.subshape[2] == shape[2], 'forward_gate: 3-D plans with the last axis whole in the input'
-    assert tuple(pout.shape) == shape and u0.is_complex(), 'forward_gate: complex-to-complex transforms'
+    # complex-to-complex, or real-to-complex with the half spectrum along the last axis (xfftn.py:231-232)
+    assert tuple(pout.shape[:2]) == shape[:2] and pout.shape[2] == (shape[2] if u0.is_complex() else shape[2] // 2 + 1), \
+        'forward_gate: c2c transforms, or r2c with the halved axis last'
     if uh is None:
         uh = fft.forward.output_array.tensor
     assert tuple(u0.shape) == tuple(pin.subshape) and tuple(uh.shape) == tuple(pout.subshape)
@@ -232,7 +234,7 @@ def forward_gate(fft, world, u0, uh=None, lines=None):
                      -2 * np.pi * torch.remainder(k0[:, None] * i0[None, :], n0) / n0)
     w1 = torch.polar(torch.ones(len(lines), l1, dtype=torch.float64, device=dev),
                      -2 * np.pi * torch.remainder(k1[:, None] * i1[None, :], n1) / n1)
-    x = u0 if u0.dtype == torch.complex128 else None
+    x = u0 if u0.dtype == torch.complex128 else None      # (anything else -- complex64, real input -- is widened slab by slab)
     acc = torch.zeros(len(lines), n2, dtype=torch.complex128, device=dev)
     step = max(1, min(l0, (1 << 22) // max(1, l1 * n2) * 8 or 1))
     for a in range(0, l0, step):

@@ -148,6 +148,33 @@ def test_unequal_width_cubes_at_full_size_c128(n):
     fft.destroy()
 
 
+@pytest.mark.parametrize('shape,dt', [((960, 960, 960), 'd'), ((896, 896, 896), 'd'), ((1024, 1024, 2048), 'd'), ((960, 960, 960), 'F')])
+def test_full_size_forward_lines_of_real_and_fp32_plans(shape, dt):
+    """mpi4py-fft_amd/selftest.forward_gate (what bench.py admits plans on) on the reference's DEFAULT dtype (real,
+    mpifft.py:202) at full size: six lines of the half spectrum against the DFT by definition in float64 on the device, for the
+    round-5 shapes -- real rows of 960 / 896 entries on unequal-width stages, the 1025-wide half spectrum on its new pitch."""
+    import torch
+    from mpi4py_fft_amd import PFFT, comm, selftest
+    free, total = torch.cuda.mem_get_info()
+    if free < 80 * 2 ** 30:
+        pytest.skip('needs ~80 GiB of HBM')
+    fft = PFFT(comm.COMM_SELF, shape, dtype=dt)
+    u = fft.forward.input_array
+    g = torch.Generator(device='cuda').manual_seed(7)
+    ur = torch.view_as_real(u.tensor) if u.tensor.is_complex() else u.tensor
+    for i in range(0, shape[0], 64):
+        ur[i:i + 64].copy_(torch.randn(ur[i:i + 64].shape, generator=g, device='cuda', dtype=ur.dtype))
+    u0 = u.tensor.clone()
+    uh = fft.forward().tensor
+    err = selftest.forward_gate(fft, comm.COMM_SELF, u0, uh)
+    assert err <= (2e-10 if dt in 'dD' else 2e-4), err
+    back = fft.backward().tensor
+    num = float(((back - u0).abs() ** 2).sum().sqrt().item())
+    den = float((u0.abs() ** 2).sum().sqrt().item())
+    assert num / den <= (1e-10 if dt in 'dD' else 1e-4), num / den
+    fft.destroy()
+
+
 # ((64, 128, 2048) / (32, 64, 4096): 1025- and 2049-wide half spectra and 2048-long complex rows, whose line-rounded
 # workspace pitches used to be 129 x 2^k entries -- the pitch rule of plan_fused3)
 @pytest.mark.parametrize('shape', [(128, 128, 128), (64, 128, 256), (256, 64, 128), (128, 256, 64), (32, 512, 1024), (64, 128, 2048),
