@@ -419,14 +419,17 @@ def test_late_messages_are_waited_for():
     assert neg.returncode == 0 and 'results WRONG' in neg.stdout, neg.stdout[-2000:]
 
 
-@pytest.mark.parametrize('P,shape,kw', [
-    (2, (64, 64, 64), {}),
-    (4, (64, 64, 64), {}),
-    (8, (64, 64, 128), {}),
-    (8, (32, 32, 1024), {}),                       # line-aligned exchange buffers (pipeline._Aligned)
-    (4, (64, 128, 64), dict(grid=(-1,))),          # slab
+@pytest.mark.parametrize('P,shape,kw,dt', [
+    (2, (64, 64, 64), {}, 'D'),
+    (4, (64, 64, 64), {}, 'D'),
+    (8, (64, 64, 128), {}, 'D'),
+    (8, (32, 32, 1024), {}, 'D'),                  # line-aligned exchange buffers (pipeline._Aligned)
+    (4, (64, 128, 64), dict(grid=(-1,)), 'D'),     # slab
+    (4, (64, 64, 128), {}, 'd'),                   # the reference's default dtype: uneven 33 | 32 half-spectrum blocks
+    (8, (32, 32, 1024), {}, 'd'),                  # ... on line-aligned buffers (513 = 512 + 1)
+    (2, (64, 64, 64), {}, 'F'),
 ])
-def test_admission_gates_on_every_wire_and_route(P, shape, kw, monkeypatch):
+def test_admission_gates_on_every_wire_and_route(P, shape, kw, dt, monkeypatch):
     """bench.py's admission gates (mpi4py-fft_amd/selftest.py) on the HIP engine: the positional exchange check of
     every Transfer -- packed sides written / read by the neighbouring kernels included -- and of every chunk exchange
     of the pipeline, the forward against the DFT by definition, and word-for-word identity of the plans, on the staged
@@ -437,14 +440,14 @@ def test_admission_gates_on_every_wire_and_route(P, shape, kw, monkeypatch):
     from mpi4py_fft_amd import PFFT, newDistArray, pipeline, selftest
     monkeypatch.setattr(pipeline.Pipeline, 'MIN_CHUNK_BYTES', 0)
     monkeypatch.setattr(pipeline.Pipeline, 'MIN_WIDTH', 4)
-    G = O.rng_array(shape, 'D', 5)
+    G = O.rng_array(shape, dt, 5)
 
     def body(comm):
         k = {a: (list(b) if isinstance(b, list) else b) for a, b in kw.items()}
         out = []
         prints = None
         for wire, exchange in (('torch', 'direct'), ('torch', 'relay'), ('native', 'direct'), ('native', 'relay')):
-            f = PFFT(comm, shape, dtype='D', wire=wire, exchange=exchange, **k)
+            f = PFFT(comm, shape, dtype=dt, wire=wire, exchange=exchange, **k)
             chk = selftest.exchange_check(f, comm)
             u = newDistArray(f, False)
             u[...] = G[f.local_slice(False)]
@@ -470,13 +473,13 @@ def test_admission_gates_on_every_wire_and_route(P, shape, kw, monkeypatch):
         for wire, exchange, chk, err, same, packed, routes, piped, bad in rows:
             assert chk['result'] == 'bit-exact', (r, wire, exchange, chk)
             assert (chk.get('pipeline_chunk_exchanges', 0) > 0) == piped
-            assert err <= 2e-10 and same, (r, wire, exchange, err, same)
+            assert err <= (2e-10 if dt in 'dD' else 2e-4) and same, (r, wire, exchange, err, same)
             if wire == 'torch':
                 assert any(a or b for a, b in packed), packed        # the kernels' own exchange-buffer layouts were checked
             if bad is not None:
                 rt, chk2, err2 = bad
-                assert rt < 1e-12                                    # the round trip cannot see it
+                assert rt < (1e-12 if dt in 'dD' else 1e-5)         # the round trip cannot see it
                 assert chk2['result'] == 'FAILED' and 'misplaced' in chk2['failures'][0], chk2
                 assert err2 > 1e-3                                   # ... the forward gate can
-    if P > 2 and not kw:
+    if P > 2 and not kw and dt == 'D':
         assert any(row[8] is not None for row in res[0])
