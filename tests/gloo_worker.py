@@ -49,7 +49,7 @@ def main():
         uh = np.asarray(fft.forward(u))
         assert uh.shape == want.shape, (uh.shape, want.shape)
         assert np.abs(uh - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (shape, dt, kw)
-        if dt == 'D' and len(shape) == 3 and not kw.get('padding'):
+        if dt in 'Dd' and len(shape) == 3 and not kw.get('padding'):      # (complex, and real with the halved axis last)
             import torch
             u0 = torch.from_numpy(np.ascontiguousarray(G[fft.local_slice(False)]))
             assert selftest.forward_gate(fft, world, u0) <= 1e-13, (shape, kw, mode)
