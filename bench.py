@@ -796,6 +796,7 @@ def run(args, guard, state):
             'config': {'workload': 'PFFT 3D c2c %d^3 complex128 forward+backward per step' % n,
                        'grid': grid, 'exchange': exchange_report(f),
                        'round_trip_rel_err': err['round_trip_rel_err'],
+                       **({'tuned_ws_offsets_kib': list(f.ws_skews)} if getattr(f, 'ws_skews', None) else {}),
                        'forward_rel_err': err['forward_rel_err'],
                        'exchange_check': err['exchange_check'],
                        'gates': dict({k: v for k, v in err.items() if not k.startswith('_')},

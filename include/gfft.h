@@ -102,6 +102,12 @@ int gfft_plan_create_r2r(gfft_plan *plan, int ndims, const int64_t *sizes, int n
  * on it when it reads a caller's array in place (Transform.__call__). */
 int gfft_execute(gfft_plan plan, const void *d_in, void *d_out, double scale, void *stream);
 int gfft_plan_destroy(gfft_plan plan);
+/* Where inside the shared per-stream workspace this plan's regions start (KiB; < 0: the library default).  Results do not depend
+ * on it; the time of the strided passes does, by a few per cent, through how the workspace and the caller's arrays share the memory
+ * channels -- FFTW_MEASURE territory (the reference plans with FFTW_MEASURE by default, libfft.py:52): with GFFT_TUNE=measure the
+ * Python host times a few offsets on the planned arrays when it builds a large one-rank plan (mpifft.PFFT._tune_placement; off by
+ * default: over three boxes the effect did not stand out from process-to-process placement, profiles/r05_tune_ab.txt). */
+int gfft_plan_set_ws_skew(gfft_plan plan, int kib);
 int gfft_scratch_release(void);           /* frees the shared per-stream workspaces, pinned ones included */
 /* Errors of launches that have already returned GFFT_OK (execution is asynchronous): a fused pass-pair launch
  * whose workgroups waited longer than option "fuse2_wait_ms" (default 2000) for one another -- a device shared

@@ -393,6 +393,7 @@ struct gfft_plan_s {
   double flops = 0, bytes = 0;
   int variant_rows = 0, variant_cols = 0, xcd_swizzle = 0;
   bool fused3 = false;
+  int ws_skew_kib = -1;                        // >= 0: this plan's workspace starts that many KiB into the shared buffer (gfft_plan_set_ws_skew)
   int mixv_variant = 0;                        // option mixv_variant at plan time (fft_mixv_*.hip: measured alternatives)
   int64_t ws_pitch = 0;                        // plan_fused3: entries between consecutive rows of the workspace
   std::vector<int64_t> trunc;                  // gfft_plan_create_padded: kept entries per axis (else empty)
@@ -1837,7 +1838,9 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
   }
   void *scratch = nullptr;
   if (total) {
-    const size_t skew = (size_t)opts().ws_skew_kib << 10;     // (tools/placement_probe.py)
+    // (the plan's own offset, gfft_plan_set_ws_skew -- chosen by measurement at planning, mpifft.PFFT._tune_placement -- else the
+    // developer option, tools/skew_sweep.py)
+    const size_t skew = (size_t)(pl->ws_skew_kib >= 0 ? pl->ws_skew_kib : opts().ws_skew_kib) << 10;
     int rc = scratch_pool().get(s, total + skew, &scratch);
     if (rc) return rc;
     scratch = static_cast<char *>(scratch) + skew;
@@ -2319,6 +2322,12 @@ int gfft_scratch_release(void) { return scratch_pool().release(true); }
 /* Did a fused launch give up a wait since the last look?  GFFT_OK, or GFFT_ERR_HIP once per event with the plan
  * named in gfft_last_error().  Does not synchronise: call it after the stream (or device) has been synchronised to
  * learn whether the results that synchronisation waited for are valid. */
+int gfft_plan_set_ws_skew(gfft_plan pl, int kib) {
+  if (!pl) return fail(GFFT_ERR_INVALID, "null plan");
+  if (kib > (1 << 20)) return fail(GFFT_ERR_INVALID, "workspace offset beyond 1 GiB");
+  pl->ws_skew_kib = kib < 0 ? -1 : kib;
+  return GFFT_OK;
+}
 int gfft_async_error(void) { return poll_async_error(nullptr); }
 int gfft_plan_status(gfft_plan pl) {
   if (!pl) return fail(GFFT_ERR_INVALID, "null plan");
