@@ -74,6 +74,7 @@ struct Options {
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
   int mixv_variant = 0;      // A/B: alternative kernels of the unequal-width lengths (tools/gen_mixv_tables.py)
   int mixv = 1;              // one-pass kernels for 3 x 5 x 2^k lengths (fft_mixv_*.hip); 0: the two-pass plans of rounds 1-4 (A/B)
+  int wtile = 1;             // tile-major workspace under the complex 3-D pair schedule (plan_fused3; A/B)
   int pitch129 = 1;          // 3-D schedules: avoid workspace pitches of 129 x 2^k entries (plan_fused3)
   int pitch_extra = 0;       // A/B: lines (128 B) added to the workspace pitch
   int ws_plane_skew = 0;     // 3-D schedules: elements added to the FAR stride of the workspace (planes a little more than n * pitch apart)
@@ -396,6 +397,7 @@ struct gfft_plan_s {
   int ws_skew_kib = -1;                        // >= 0: this plan's workspace starts that many KiB into the shared buffer (gfft_plan_set_ws_skew)
   int mixv_variant = 0;                        // option mixv_variant at plan time (fft_mixv_*.hip: measured alternatives)
   int64_t ws_pitch = 0;                        // plan_fused3: entries between consecutive rows of the workspace
+  int ws_tile = 0;                             // ... or: columns of a tile of its tile-major layout
   std::vector<int64_t> trunc;                  // gfft_plan_create_padded: kept entries per axis (else empty)
   std::vector<std::vector<hipEvent_t>> prof;   // per execute: events before pass 0 and after each pass
   std::vector<void *> device_allocs;            // small device buffers the plan owns (descriptors of fused launches)
@@ -1229,6 +1231,10 @@ int plan_fused3(gfft_plan_s *pl) {
   // strides on both its sides, and the pass that touches the user's natural array does so along
   // axis 1, the near axis of the natural layout (measured: near pad->pad 7.2 ms, far 7.9 ms).
   int64_t w_i0 = P, w_i1 = n0 * P;
+  // tile-major workspace (option wtile, decided below once the pair is known): W[i0][tile of TWc columns][k1][TWc], planes w_i0 apart
+  bool wtile = false;
+  int wt_lg = 0;
+  int64_t TWc = 0, wtS = 0;          // columns of a tile; entries from one tile to the next
   // Forward r2c with rows that are not whole lines wide (odd n/2 + 1): the pass that writes the
   // caller's array would store 256-byte segments off the line grid (4.6-5.0 ms per 1024^3 pass
   // against 3.4 aligned).  Stores hurt more than loads (tools/flat_probe.py), so that pass becomes
@@ -1260,6 +1266,8 @@ int plan_fused3(gfft_plan_s *pl) {
     }
     p.d.in_es = 1;
     p.d.out_es = 1;
+    if (wtile && in_ws) { p.d.in_os = TWc; p.d.in_tlg = wt_lg; p.d.in_tS = wtS; }          // (o = k1: one row of a tile; the line itself tile-major)
+    if (wtile && out_ws) { p.d.out_os = TWc; p.d.out_tlg = wt_lg; p.d.out_tS = wtS; }
     p.src = src; p.dst = dst;
     if (mode != MODE_C2C && opts().real_half && n2 % 2 == 0 &&
         (real_half_supported((int)(n2 / 2)) || real_half_mix_supported((int)(n2 / 2)) || real_half_mixv_ok(n2 / 2))) {
@@ -1289,6 +1297,8 @@ int plan_fused3(gfft_plan_s *pl) {
     }
     p.d.in_os = in_ws ? w_i0 : t1 * nc;   p.d.in_es = in_ws ? w_i1 : nc;
     p.d.out_os = out_ws ? w_i0 : t1 * nc; p.d.out_es = out_ws ? w_i1 : nc;
+    if (wtile && in_ws) { p.d.in_es = TWc; p.d.in_ilg = wt_lg; p.d.in_iS = wtS; }
+    if (wtile && out_ws) { p.d.out_es = TWc; p.d.out_ilg = wt_lg; p.d.out_iS = wtS; }      // every tile one contiguous run
     p.src = src; p.dst = dst;
     keep(p, t1, n1);
     return p;
@@ -1302,6 +1312,11 @@ int plan_fused3(gfft_plan_s *pl) {
     p.data_inner = nc;
     p.d.in_os = w_i1;  p.d.in_es = w_i0;
     p.d.out_os = w_i1; p.d.out_es = w_i0;
+    if (wtile) {          // k1 advances by one row of a tile, the columns are tile-major
+      p.d.in_os = p.d.out_os = TWc;
+      p.d.in_ilg = p.d.out_ilg = wt_lg;
+      p.d.in_iS = p.d.out_iS = wtS;
+    }
     p.src = src; p.dst = dst;
     keep(p, t0, n0);      // in place: a column is loaded whole before its first entry is stored
     return p;
@@ -1347,6 +1362,20 @@ int plan_fused3(gfft_plan_s *pl) {
   // ... and the workspace then is W[i0][k1][c]: the stand-alone axis-1 pass stores on NEAR strides (stores are
   // what far strides hurt), the fused pair's axis-0 tiles read the far (pitched) ones
   if (pair_cols_rows && opts().fuse2_wlayout) { w_i0 = n1 * P; w_i1 = P; }
+  // Tile-major workspace under that schedule (option wtile): the stand-alone axis-1 pass then WRITES every tile of 256-byte segments
+  // as one contiguous 256 KiB run -- measured on the pass alone, same buffers (tools/tile_major_probe.py): 6.48 -> 5.84 ms at 1024^3
+  // complex128, reading such a buffer is level -- and the pair's strided tiles read W[i0][tile][k1][.] one 256-byte row per plane.
+  // In the whole schedule, same arrays (profiles/r05_ab_wtile.txt): 1024^3 c128 31.7 -> 31.0 ms per step (the pass 6.15 -> 5.85 ms,
+  // the pair level), (1024,512,1024) -2.0 %, 512^3 -0.9 %, 1024^3 c64 -0.5 %; 960^3 -0.4 %, 896^3 +1.0 %, (1024,2048,1024) +0.4 %:
+  // taken where axis 1 is a power of two up to 1024 (option wtile = 2: wherever the layout fits).
+  const bool wtile_len = (n1 & (n1 - 1)) == 0 && n1 <= 1024;
+  if (pair_cols_rows && opts().fuse2_wlayout && opts().wtile && (wtile_len || opts().wtile >= 2) && Pu % (256 / esz) == 0) {
+    wtile = true;
+    TWc = 256 / esz;
+    pl->ws_tile = (int)TWc;
+    while (((int64_t)1 << wt_lg) < TWc) ++wt_lg;
+    wtS = n1 * TWc;          // (rows of padding after every tile -- 1, 3, 8 -- measured level: profiles/r05_ab_wtile.txt)
+  }
   if (opts().ws_plane_skew > 0) {
     // (A/B, tools/skew_sweep.py: consecutive planes of the workspace a few lines further apart than rows * pitch, so that
     // the rows a far-axis tile walks differ in their LOW address bits too)
@@ -1403,7 +1432,16 @@ int plan_fused3(gfft_plan_s *pl) {
       PassDesc dA = p2.d, dB = p3.d;                  // axis 0: W[i1][k0][c] -> slot[i0][c];  rows slot -> OUT
       dA.batch = Pu; dA.in_os = 0; dA.out_os = 0; dA.out_es = P;
       dB.batch = n0; dB.inner = 1; dB.in_is = 0; dB.out_is = 0; dB.in_os = P; dB.out_os = n1 * n2;
-      ok = make_fused2(pl, FUSED_COLS_ROWS, p2, p3, dA, dB, (int)n1, w_i1 * esz, n2 * esz, n0 * P * esz, &f);
+      int64_t a_plane = w_i1 * esz;
+      if (wtile) {
+        // the pair's kernels take natural-layout descriptors only (FLAGS 8192): the tile-major columns as (tile, column in tile)
+        dA.mid = Pu / TWc; dA.inner = TWc;
+        dA.in_ms = wtS; dA.in_is = 1; dA.in_ilg = 0; dA.in_iS = 0;
+        dA.out_ms = TWc;     dA.out_is = 1; dA.out_ilg = 0; dA.out_iS = 0;
+        dB.in_tlg = 0; dB.in_tS = 0;                   // (B reads the slot, natural rows)
+        a_plane = TWc * esz;                           // plane k1 = one row of every tile
+      }
+      ok = make_fused2(pl, FUSED_COLS_ROWS, p2, p3, dA, dB, (int)n1, a_plane, n2 * esz, n0 * P * esz, &f);
       if (ok) { f.bytes2 = 1; pl->passes[base + 1] = f; pl->passes.erase(pl->passes.begin() + base + 2); }
     }
   }
@@ -1593,6 +1631,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "ws_plane_skew")) opts().ws_plane_skew = value;
   else if (!strcmp(key, "pitch129")) opts().pitch129 = value;
+  else if (!strcmp(key, "wtile")) opts().wtile = value;
   else if (!strcmp(key, "mixv")) opts().mixv = value;
   else if (!strcmp(key, "mixv_variant")) opts().mixv_variant = value;
   else if (!strcmp(key, "pitch_extra")) opts().pitch_extra = value;
@@ -2348,7 +2387,8 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
   const char *kn = pl->kind == GFFT_C2C_FORWARD ? "c2c-forward" : pl->kind == GFFT_C2C_BACKWARD ? "c2c-backward"
                    : pl->kind == GFFT_R2C ? "r2c" : "c2r";
   char sched[96] = "";
-  if (pl->fused3) snprintf(sched, sizeof sched, " [3-D schedule: padded-pitch workspace, rows %lld entries apart]", (long long)pl->ws_pitch);
+  if (pl->fused3 && pl->ws_tile) snprintf(sched, sizeof sched, " [3-D schedule: tile-major workspace, tiles of %d columns]", pl->ws_tile);
+  else if (pl->fused3) snprintf(sched, sizeof sched, " [3-D schedule: padded-pitch workspace, rows %lld entries apart]", (long long)pl->ws_pitch);
   snprintf(line, sizeof line, "gfft plan: %s %s, %d dims, %zu passes%s\n", kn, pl->precision == 8 ? "f64" : "f32",
            pl->ndims, pl->passes.size(), sched);
   s += line;

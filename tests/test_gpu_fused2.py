@@ -19,7 +19,7 @@ def _opts(**kw):
 @pytest.fixture(autouse=True)
 def _restore():
     yield
-    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=126, fuse2_wait_ms=2000, fuse2_f32=1)
+    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=126, fuse2_wait_ms=2000, fuse2_f32=1, wtile=1)
 
 
 def _plans(shape, axes, fuse, ring=8, lag=4, kinds=15, dt='D'):
@@ -31,9 +31,14 @@ def _plans(shape, axes, fuse, ring=8, lag=4, kinds=15, dt='D'):
     return a, f, b
 
 
-@pytest.mark.parametrize('shape,dt', [((1024, 16, 1024), 'D'), ((1024, 40, 1024), 'D')])
-def test_fused_3d_schedule_matches_the_unfused_one(shape, dt):
+# (axis 1 a power of two: the tile-major workspace W[i0][tile of 16 columns][k1][16] under the pair [axis 0 -> rows], plan_fused3 option
+# wtile; 40: pitched rows, and the tile-major layout forced with wtile = 2)
+@pytest.mark.parametrize('shape,dt,wtile', [((1024, 16, 1024), 'D', 1), ((1024, 40, 1024), 'D', 1), ((1024, 64, 1024), 'D', 1),
+                                            ((1024, 40, 1024), 'D', 2), ((1024, 64, 1024), 'D', 0)])
+def test_fused_3d_schedule_matches_the_unfused_one(shape, dt, wtile):
     from mpi4py_fft_amd import _lib
+    _opts(wtile=wtile)
+    tiled = wtile == 2 or (wtile == 1 and shape[1] & (shape[1] - 1) == 0)
     rng = np.random.default_rng(5)
     x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(dt)
     eps = 1e-13 if dt == 'D' else 1e-5
@@ -55,6 +60,7 @@ def test_fused_3d_schedule_matches_the_unfused_one(shape, dt):
         desc = _lib.engine().plan_describe(f1._plan)
         assert ('fused pair (strided -> rows)' if kinds == 15 else 'fused pair (rows -> strided)') in desc, desc
         assert 'ring of %d slots' % ring in desc, desc
+        assert ('tile-major workspace, tiles of 16 columns' in desc) == (tiled and kinds == 15), desc
         assert ('fused pair (strided -> rows)' in _lib.engine().plan_describe(b1._plan)) == (kinds == 15)
         a1[...] = x
         for rep in range(3):
@@ -223,7 +229,7 @@ def test_fused_plans_execute_in_place(shape, axes):
     f1.destroy()
 
 
-@pytest.mark.parametrize('shape,axes', [((1024, 40, 1024), (0, 1, 2)), ((32, 1 << 20), (1,))])
+@pytest.mark.parametrize('shape,axes', [((1024, 40, 1024), (0, 1, 2)), ((1024, 64, 1024), (0, 1, 2)), ((32, 1 << 20), (1,))])
 def test_a_fused_launch_that_gives_up_a_wait_is_an_error_and_the_plan_recovers(shape, axes):
     """A wait inside a fused launch that outlasts `fuse2_wait_ms` (a device shared with a long foreign kernel, a
     debugger) voids the launch: no hang, no trap that would poison the HIP context and every other plan of the
@@ -236,6 +242,8 @@ def test_a_fused_launch_that_gives_up_a_wait_is_an_error_and_the_plan_recovers(s
     ref = np.fft.fftn(x, axes=axes)
     a, f, b = _plans(shape, axes, 1, 8, 4, 31)
     assert 'fused pair' in _lib.engine().plan_describe(f._plan)
+    # ((1024, 64, 1024): the stand-alone forms then run on the tile-major workspace the plan was laid out for)
+    assert ('tile-major workspace' in _lib.engine().plan_describe(f._plan)) == (shape == (1024, 64, 1024))
     a[...] = x
     good = np.asarray(f.execute_scaled(a, f.output_array, 1.0)).copy()       # the healthy launch first
     assert np.abs(good - ref).max() <= 2e-10 * np.abs(ref).max()
@@ -373,11 +381,11 @@ def test_fused_pairs_of_real_transforms(shape):
     assert np.abs(res[0][1] - res[1][1]).max() <= 1e-13 * np.abs(x).max()
 
 
-def test_fused_pair_of_the_complex64_schedule():
+@pytest.mark.parametrize('shape', [(1024, 48, 1024), (1024, 64, 1024)])          # (48 planes: just enough for the ring of 24)
+def test_fused_pair_of_the_complex64_schedule(shape):
     """[axis 0 -> rows] of the complex64 3-D schedule (csrc/fft_fused_f32.hip), on a ring sized in bytes: against numpy
-    in double precision and against the unfused plans, reproducible."""
+    in double precision and against the unfused plans, reproducible.  64 planes: on the tile-major workspace (tiles of 32 columns)."""
     from mpi4py_fft_amd import _lib
-    shape = (1024, 48, 1024)          # 48 planes: just enough for the ring of 24
     rng = np.random.default_rng(31)
     x = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype('F')
     ref = np.fft.fftn(x.astype('D'))
@@ -388,6 +396,7 @@ def test_fused_pair_of_the_complex64_schedule():
         assert ('fused pair (strided -> rows)' in desc) == bool(fuse), desc
         if fuse:
             assert 'ring of 24 slots' in desc, desc          # 8.25 MiB planes: twice the slots of the complex128 pair
+            assert ('tile-major workspace, tiles of 32 columns' in desc) == (shape[1] == 64), desc
         a[...] = x
         for rep in range(3):
             got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
