@@ -240,6 +240,18 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
 
 bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
 
+/* threads per line (NT = n / R) of the power-of-two ROW kernels, as the tables in fft_pow2_f64.hip /
+ * fft_pow2_f32.hip instantiate them (default variants); launch_pow2_one re-checks at launch */
+static int pow2_rows_nt(int64_t n, int precision) {
+  if (!is_pow2(n) || n < 16 || n > 4096) return 0;
+  if (n <= 32) return 4;
+  if (n == 64) return 8;
+  if (n == 128) return 16;
+  if (n == 256) return precision == 8 ? 32 : 16;
+  if (n <= 1024) return 64;
+  return (int)(n / 16);
+}
+
 // lengths served by the register-resident kernels: 2^k (16..4096), 3^b 2^k (48..3456), 5^c 2^k (20..4000)
 bool regk_ok(int64_t n, int precision) {
   if (opts().force_generic) return false;
@@ -1369,7 +1381,12 @@ int plan_fused3(gfft_plan_s *pl) {
   // the pair level), (1024,512,1024) -2.0 %, 512^3 -0.9 %, 1024^3 c64 -0.5 %; 960^3 -0.4 %, 896^3 +1.0 %, (1024,2048,1024) +0.4 %:
   // taken where axis 1 is a power of two up to 1024 (option wtile = 2: wherever the layout fits).
   const bool wtile_len = (n1 & (n1 - 1)) == 0 && n1 <= 1024;
-  if (pair_cols_rows && opts().fuse2_wlayout && opts().wtile && (wtile_len || opts().wtile >= 2) && Pu % (256 / esz) == 0) {
+  // (The UNFUSED complex schedules on this layout: the pass that fills W gains as much -- 768^3 c128 3.40 -> 3.15 ms, 1152^3 c64
+  // 6.60 -> 5.59 -- and the in-place pass, now on the far stride, loses more -- 2.94 -> 3.51, 5.94 -> 6.35: +2.7 % / -1.4 % per step,
+  // profiles/r05_ab_wtile.txt part 4; they keep W[i1][i0][c].)
+  // The stand-alone forms of a voided pair read the rows tile-major: their thread layout has to advance by whole tiles.
+  const bool wtile_rows = pow2_rows_nt(n2, prec) > 0 && pow2_rows_nt(n2, prec) % (int)(256 / esz) == 0 && is_pow2(n0);
+  if (pair_cols_rows && opts().fuse2_wlayout && opts().wtile && wtile_rows && (wtile_len || opts().wtile >= 2) && Pu % (256 / esz) == 0) {
     wtile = true;
     TWc = 256 / esz;
     pl->ws_tile = (int)TWc;
@@ -2253,17 +2270,6 @@ int gfft_plan_create_guru_padded(gfft_plan *plan, int precision, int kind, const
 }
 
 
-/* threads per line (NT = n / R) of the power-of-two ROW kernels, as the tables in fft_pow2_f64.hip /
- * fft_pow2_f32.hip instantiate them (default variants); launch_pow2_one re-checks at launch */
-static int pow2_rows_nt(int64_t n, int precision) {
-  if (!is_pow2(n) || n < 16 || n > 4096) return 0;
-  if (n <= 32) return 4;
-  if (n == 64) return 8;
-  if (n == 128) return 16;
-  if (n == 256) return precision == 8 ? 32 : 16;
-  if (n <= 1024) return 64;
-  return (int)(n / 16);
-}
 
 /* Tile-major layouts of exchange buffers (see include/gfft.h). */
 int gfft_plan_set_tiles(gfft_plan pl, int side, int tile, int64_t tile_stride) {
