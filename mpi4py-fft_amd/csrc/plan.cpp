@@ -196,7 +196,8 @@ int get_bigtw(int64_t big_n, int precision, BigTw *out) {
 //   FS   the transposed intermediate of a four-step axis
 //   AUX  the embedding buffer of a Bluestein / real-as-complex axis
 //   RING the hand-off ring (+ its counters) of a fused pass pair (PK_FUSED2)
-enum Buf { BUF_IN = 0, BUF_OUT = 1, BUF_WS = 2, BUF_FS = 3, BUF_AUX = 4, BUF_RING = 5, BUF_COUNT = 6 };
+//   FS2  the intermediate of the outer level of a three-pass axis (lengths beyond 2^24, plan_long)
+enum Buf { BUF_IN = 0, BUF_OUT = 1, BUF_WS = 2, BUF_FS = 3, BUF_AUX = 4, BUF_RING = 5, BUF_FS2 = 6, BUF_COUNT = 7 };
 
 enum PassKind { PK_FFT = 0, PK_EMBED, PK_MULB, PK_EXTRACT, PK_FUSED2 };
 
@@ -402,7 +403,7 @@ struct gfft_plan_s {
   std::vector<int64_t> sizes_in, sizes_out;
   std::vector<int> axes;
   std::vector<Pass> passes;
-  size_t region_bytes[BUF_COUNT] = {0, 0, 0, 0, 0, 0};   // WS / FS / AUX / RING sizes
+  size_t region_bytes[BUF_COUNT] = {0, 0, 0, 0, 0, 0, 0};   // WS / FS / AUX / RING / FS2 sizes
   double flops = 0, bytes = 0;
   int variant_rows = 0, variant_cols = 0, xcd_swizzle = 0;
   bool fused3 = false;
@@ -773,7 +774,7 @@ int plan_fourstep(gfft_plan_s *pl, const Line &L, int64_t n1, int64_t n2) {
 // Pick n1*n2 = n with both factors plannable in one pass; prefers the register-kernel sizes.
 bool split_fourstep(int64_t n, int prec, int64_t *n1, int64_t *n2) {
   const int gmax = generic_max_n(prec);
-  if (n >= ((int64_t)1 << 24)) return false;
+  if (n > ((int64_t)1 << 24)) return false;
   if (is_pow2(n)) {
     int lg = 0;
     while (((int64_t)1 << lg) < n) ++lg;
@@ -796,6 +797,65 @@ bool split_fourstep(int64_t n, int prec, int64_t *n1, int64_t *n2) {
   *n1 = n / best;
   *n2 = best;
   return true;
+}
+
+// ---- lengths beyond 2^24: n = n1 * n2 with n2 a four-step (or single-pass) length again ------------------------------
+// FFTW plans any length (/root/reference/mpi4py_fft/fftw/fftw_planxfftn.c:52-75).  One more level of the same
+// decomposition: the strided pass of length n1 with the twiddle W_n^(i2 k1) on its store leaves tmp[o][i2][k1][i] --
+// which IS the natural layout [outer][n2][inner'] of a batch of lines of length n2 with inner' = n1 * inner, and the
+// result of transforming those lines in place of i2, out[o][k2][k1][i], is the natural order k = k2 n1 + k1 of the long
+// transform.  So the rest is plan_line on that batch (a four-step transform with inner > 1: two passes through FS):
+// three HBM round trips in all, the intermediate of this level in its own region (FS2).  Inverse: conj . forward . conj
+// level by level -- this pass conjugates on load AND on store, the inner line conjugates again on its load.
+int plan_long(gfft_plan_s *pl, const Line &L, int64_t n1, int64_t n2) {
+  const int prec = pl->precision;
+  const int64_t esz = 2 * prec, n = L.n, inner = L.inner, outer = L.outer;
+  BigTw bt;
+  int rc = get_bigtw(n, prec, &bt);
+  if (rc) return rc;
+  const int64_t S2 = n1 * inner;
+  Pass a;
+  a.d = natural_desc(L);
+  a.d.n = (int)n1;
+  a.d.batch = outer * n2 * inner;
+  a.d.mid = n2;
+  a.d.inner = inner;
+  a.d.in_os = n * inner;  a.d.in_ms = inner;  a.d.in_is = 1;  a.d.in_es = n2 * inner;
+  a.d.out_os = n2 * S2;   a.d.out_ms = S2;    a.d.out_is = 1; a.d.out_es = inner;
+  a.d.conj_in = L.inverse ? 1 : 0;
+  a.d.conj_out = L.inverse ? 1 : 0;
+  a.d.tw_hi = bt.hi;  a.d.tw_lo = bt.lo;  a.d.tw_L = bt.L;  a.d.big_n = n;
+  a.src = L.src;
+  a.dst = BUF_FS2;
+  a.logical_first = true;
+  a.regk = true;
+  a.cols = true;
+  rc = get_twiddles(n1, prec, &a.d.tw);
+  if (rc) return rc;
+  need(pl, BUF_FS2, (size_t)outer * n * inner * esz);
+  pl->passes.push_back(a);
+  const Line rest{outer, S2, n2, n2, n2, MODE_C2C, L.inverse, BUF_FS2, L.dst};
+  return plan_line(pl, rest, false);
+}
+
+// n1 for plan_long: a register-kernel length whose cofactor plan_line takes in one or two passes; powers of two split
+// three ways as evenly as the tables allow (2^30 = 1024 x (1024 x 1024))
+bool split_long(int64_t n, int prec, int64_t *n1) {
+  if (n <= ((int64_t)1 << 24) || n >= ((int64_t)1 << 31)) return false;
+  int64_t t1 = 0, t2 = 0;
+  if (is_pow2(n)) {
+    int lg = 0;
+    while (((int64_t)1 << lg) < n) ++lg;
+    *n1 = (int64_t)1 << (lg - 2 * (lg / 3));
+    return true;
+  }
+  for (int64_t a = 4096; a >= 16; --a) {
+    if (n % a || !regk_ok(a, prec)) continue;
+    const int64_t b = n / a;
+    if (b > ((int64_t)1 << 24)) break;
+    if (regk_ok(b, prec) || split_fourstep(b, prec, &t1, &t2)) { *n1 = a; return true; }
+  }
+  return false;
 }
 
 // ---- embedding fallbacks: Bluestein, and real transforms beyond the single-pass limit --------
@@ -875,7 +935,7 @@ int plan_embedded(gfft_plan_s *pl, const Line &L, bool bluestein) {
   if (bluestein) {
     Lw = 1;
     while (Lw < 2 * L.n - 1) Lw <<= 1;
-    if (Lw >= ((int64_t)1 << 24)) return fail(GFFT_ERR_UNSUPPORTED, "transform length too large for Bluestein");
+    if (Lw > ((int64_t)1 << 26)) return fail(GFFT_ERR_UNSUPPORTED, "transform length too large for Bluestein");
     int rc = get_bluestein(L.n, Lw, prec, &chirp, &B);
     if (rc) return rc;
   }
@@ -1154,6 +1214,10 @@ int plan_line(gfft_plan_s *pl, const Line &L, bool top) {
     if (rc) return rc;
     pl->passes.push_back(p);
     return GFFT_OK;
+  }
+  if (max_prime_factor(n) <= GENERIC_MAX_PRIME && split_long(n, prec, &n1)) {
+    if (L.mode == MODE_C2C) return plan_long(pl, L, n1, n / n1);
+    return plan_embedded(pl, L, false);                                       // real: as a complex line of the same length
   }
   const bool splittable = max_prime_factor(n) <= GENERIC_MAX_PRIME && split_fourstep(n, prec, &n1, &n2);
   if (L.mode == MODE_C2C && splittable) return plan_fourstep(pl, L, n1, n2);
@@ -1887,7 +1951,7 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
     return fail(GFFT_ERR_INVALID, "in-place real transforms are not supported");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // scratch regions: carved from the stream's shared buffer (scratch_pool)
-  size_t off[BUF_COUNT] = {0, 0, 0, 0, 0, 0}, total = 0;
+  size_t off[BUF_COUNT] = {0, 0, 0, 0, 0, 0, 0}, total = 0;
   for (int b = BUF_WS; b < BUF_COUNT; ++b) {
     off[b] = total;
     total += align256(pl->region_bytes[b]);
@@ -1901,7 +1965,7 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
     if (rc) return rc;
     scratch = static_cast<char *>(scratch) + skew;
   }
-  void *bufs[BUF_COUNT] = {const_cast<void *>(d_in), d_out, nullptr, nullptr, nullptr, nullptr};
+  void *bufs[BUF_COUNT] = {const_cast<void *>(d_in), d_out, nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int b = BUF_WS; b < BUF_COUNT; ++b)
     if (pl->region_bytes[b]) bufs[b] = static_cast<char *>(scratch) + off[b];
 
@@ -2398,7 +2462,7 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
   snprintf(line, sizeof line, "gfft plan: %s %s, %d dims, %zu passes%s\n", kn, pl->precision == 8 ? "f64" : "f32",
            pl->ndims, pl->passes.size(), sched);
   s += line;
-  static const char *bufn[] = {"IN", "OUT", "WS", "FS", "AUX", "RING"};
+  static const char *bufn[] = {"IN", "OUT", "WS", "FS", "AUX", "RING", "FS2"};
   for (const Pass &p : pl->passes) {
     if (p.kind == PK_FUSED2) {
       static const char *fk[] = {"rows -> strided", "strided -> rows", "four-step", "2-D planes: rows -> strided", "four-step: strided -> rows, transposed on store",

@@ -131,7 +131,58 @@ def test_in_place_and_implicit_arrays():
 def test_plan_failure_raises():
     from mpi4py_fft_amd import fftw
     with pytest.raises(RuntimeError):
-        fftw.fftn(fftw.aligned((2, 1 << 25), dtype='D'), axes=(1,))   # length >= 2^24
+        fftw.fftn(fftw.aligned((1, (1 << 26) + 1), dtype='D'), axes=(1,))   # 5 x 53 x 157 x 1613: Bluestein on 2^28 points, beyond its table limit
+
+
+@pytest.mark.parametrize('n', [1 << 24, 1 << 25, 3 << 23, 5 << 23])
+def test_lengths_of_2pow24_and_beyond(n):
+    """FFTW plans any length (/root/reference/mpi4py_fft/fftw/fftw_planxfftn.c:52-75).  2^24 = 4096 x 4096 is a plain four-step
+    transform; beyond it one more strided pass in front of a four-step transform of the cofactor (plan.cpp plan_long),
+    three passes in all: against the oracle, both directions, as rows and along a strided axis."""
+    from mpi4py_fft_amd import fftw, _lib
+    a = fftw.aligned((1, n), dtype='D')
+    plan = fftw.fftn(a, axes=(1,))
+    desc = _lib.engine().plan_describe(plan._plan)
+    assert desc.count('\n  n=') + 2 * desc.count('fused pair') == (2 if n == 1 << 24 else 3), desc          # HBM round trips
+    assert ('FS2' in desc) == (n > 1 << 24), desc
+    plan.destroy()
+    _check((1, n), (1,), 'D')
+    if n <= 1 << 25:
+        _check((n, 2), (0,), 'D')
+
+
+def test_long_lengths_real_single_precision_and_prime():
+    _check((2, 1 << 25), (1,), 'F')
+    _check((1, 1 << 25), (1,), 'd')             # real: as a complex line of the same length
+    _check((1, 3 << 23), (1,), 'f')
+    _check((1, 16777259), (1,), 'D')            # a prime beyond 2^24: Bluestein on 2^26 points, themselves a three-pass transform
+
+
+def test_length_2pow28_against_the_dft_by_definition():
+    """2^28 complex128 (4 GiB a side), too long for the CPU oracle inside a test: six output entries against the DFT sum,
+    accumulated on the device in float64 with the phase reduced exactly (j k mod n in integers), and the round trip."""
+    import torch
+    from mpi4py_fft_amd import fftw, DeviceArray
+    n = 1 << 28
+    a = fftw.aligned((n,), dtype='D')
+    out = fftw.aligned((n,), dtype='D')
+    g = torch.Generator(device='cuda').manual_seed(7)
+    torch.view_as_real(a.tensor).copy_(torch.randn((n, 2), dtype=torch.float64, device='cuda', generator=g))
+    keep = a.tensor.clone()
+    fwd = fftw.fftn(a, axes=(0,), output_array=out)
+    bwd = fftw.ifftn(out, axes=(0,), output_array=fftw.aligned((n,), dtype='D'))
+    fwd()
+    j = torch.arange(n, dtype=torch.int64, device='cuda')
+    scale = float(keep.abs().max().item()) * n ** 0.5
+    for k in (0, 1, 12345, n // 2 + 3, n - 1, 177777777):
+        ph = ((j * k) % n).to(torch.float64) * (-2.0 * np.pi / n)
+        ref = torch.sum(keep * torch.complex(torch.cos(ph), torch.sin(ph)))
+        got = out.tensor[k]
+        assert abs(complex(got.item()) - complex(ref.item())) <= 1e-10 * scale, (k, got, ref)
+        del ph
+    back = bwd(out, normalize=True)
+    assert float((back.tensor - keep).abs().max().item()) <= 1e-12 * float(keep.abs().max().item())
+    fwd.destroy(); bwd.destroy()
 
 
 @pytest.mark.parametrize('dt', ['D', 'd', 'F'])
