@@ -545,6 +545,23 @@ bool fused2_ring(int precision, int n_a, int n_b, int64_t slot_bytes, int planes
   return true;
 }
 
+// The hand-off protocol of the fused pairs leans on gfx94x / gfx950 specifics (make_fused2): elsewhere the pairs stay off, and
+// plan_fused3 asks BEFORE it lays the workspace out for a pair it would not get.
+bool fused2_arch_ok() {
+  static int arch_ok[kMaxDevices] = {};          // 0 unknown, 1 yes, -1 no
+  const int dev = current_device();
+  if (!arch_ok[dev]) {
+    hipDeviceProp_t prop;
+    arch_ok[dev] = -1;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+      if (!strncmp(prop.gcnArchName, "gfx942", 6) || !strncmp(prop.gcnArchName, "gfx950", 6)) arch_ok[dev] = 1;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  return arch_ok[dev] > 0;
+}
+
 bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const PassDesc &dA, const PassDesc &dB, int planes,
                  int64_t a_in_plane, int64_t b_out_plane, int64_t slot_bytes, Pass *out) {
   // auto: 12 slots with the producer 6 planes ahead where there are planes enough, else 8 / 4.  Swept on one box, plans
@@ -556,20 +573,7 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   // through / never served from a stale L2 line), stores counted by vmcnt -- so that s_waitcnt(0) means "write-through
   // acknowledged" --, relaxed agent-scope atomics as the only ordering.  On a target with another memory model (a
   // separate store counter, other policy bits) the pairs stay off: the stand-alone passes are always correct.
-  {
-    static int arch_ok[kMaxDevices] = {};          // 0 unknown, 1 yes, -1 no
-    const int dev = current_device();
-    if (!arch_ok[dev]) {
-      hipDeviceProp_t prop;
-      arch_ok[dev] = -1;
-      if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
-        if (!strncmp(prop.gcnArchName, "gfx942", 6) || !strncmp(prop.gcnArchName, "gfx950", 6)) arch_ok[dev] = 1;
-      } else {
-        (void)hipGetLastError();
-      }
-    }
-    if (arch_ok[dev] < 0) return false;
-  }
+  if (!fused2_arch_ok()) return false;
   int ring = 0, lag = 0;
   if (!fused2_ring(pl->precision, dA.n, dB.n, slot_bytes, planes, &ring, &lag)) return false;
   if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1)) return false;
@@ -1416,7 +1420,7 @@ int plan_fused3(gfft_plan_s *pl) {
   // rows 16 MiB apart), which costs nothing, where the mirror pair [rows -> axis 0] READS them scattered and
   // loses what the fusion gains (1024^3 c128, tools/fused2_probe.py: 20.0 ms against 18.4 ms).
   int ring_probe = 0, lag_probe = 0;
-  const bool pair_cols_rows = !real && !tr && !flat_out && Pu == nc && opts().fuse2 &&
+  const bool pair_cols_rows = !real && !tr && !flat_out && Pu == nc && opts().fuse2 && fused2_arch_ok() &&
                               ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && fused2_ring(prec, (int)n0, (int)n2, n0 * P * esz, (int)n1, &ring_probe, &lag_probe) &&
                               (prec == GFFT_F64 ? fused2_supported_f64(FUSED_COLS_ROWS, (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1, (int)n0, (int)n2)
                                                 : (opts().fuse2_f32 && fused2_supported_f32(FUSED_COLS_ROWS, (int)n0, (int)n2)));
@@ -1428,7 +1432,7 @@ int plan_fused3(gfft_plan_s *pl) {
     // profiles/r04_real_pairs_f32.txt -- so they need option fuse2_f32 = 2)
     return prec == GFFT_F64 ? fused2_real_supported_f64(kind, na, nb) : (opts().fuse2_f32 >= 2 && fused2_real_supported_f32(kind, na, nb));
   };
-  const bool pair_real = real && !tr && opts().fuse2 && n2 % 2 == 0 && opts().real_half &&
+  const bool pair_real = real && !tr && opts().fuse2 && fused2_arch_ok() && n2 % 2 == 0 && opts().real_half &&
                          (inverse ? (((opts().fuse2_kinds >> FUSED_COLS_C2R) & 1) && real_ok(FUSED_COLS_C2R, (int)n0, (int)(n2 / 2)) &&
                                      fused2_ring(prec, (int)n0, (int)(n2 / 2), n0 * P * esz, (int)n1, &ring_probe, &lag_probe))
                                   : (((opts().fuse2_kinds >> FUSED_R2C_PLANES) & 1) && flat_out && real_ok(FUSED_R2C_PLANES, (int)(n2 / 2), (int)n1) &&
