@@ -8,6 +8,8 @@ os.environ.setdefault('GFFT_TUNE', '0')       # (A/B of planning options: no per
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mpi4py_fft_amd import PFFT, comm, _lib
+if os.environ.get('GFFT_AB_LIB'):          # (a build next to libgfft.so: A/B of compile-time choices, process against process)
+    _lib.LIBPATH = os.path.join(os.path.dirname(_lib.LIBPATH), os.environ['GFFT_AB_LIB'])
 
 args = sys.argv[1:]
 n, dt = 1024, 'D'
