@@ -1074,6 +1074,27 @@ struct SysBuf {
   }
 };
 
+// Unequal-width stage kernels (fft_mixv_f64.hip) in which this compiler (hipcc of ROCm 7.2) waits for EVERY load of a tile before
+// it issues the next when the sign of conjugation-on-load is applied to each value as it arrives -- chains of 5 ... 17 loads each
+// followed by s_waitcnt vmcnt(0), found by scanning the ISA (hipcc -S --cuda-device-only; tools/scan_serial_loads.py) --
+// under their register pressure (scalar spills into VGPR lanes).  They apply the sign once, behind the loads (fft_pow2_body.inc
+// DEFER_SIGN): 750^3 c128 23.5 -> 19.7 ms per step, 1050^3 60.2 -> 52.3, 1260^3 97.3 -> 84.9.  The kernels that were NOT
+// serialised lose 1-2.5 % under the same change (840^3, 960^3, (720,1200,480)) and keep the sign on the load
+// (profiles/r05_ab_serial_loads.txt).
+constexpr bool in_lengths(int n, const int *list, int count) {
+  for (int i = 0; i < count; ++i)
+    if (list[i] == n) return true;
+  return false;
+}
+constexpr bool serial_loads_f64(int n, bool cols, bool trunc) {
+  constexpr int rows_plain[] = {112, 140, 280, 450, 540, 750, 900, 980, 1050, 1260, 1400, 1792, 2100, 2240, 2800, 3000, 3584};
+  constexpr int rows_trunc[] = {1050, 1260, 1680, 2100};
+  constexpr int cols_plain[] = {168, 250, 280, 350, 450, 750, 900, 1050, 1260, 1800, 2160};
+  constexpr int cols_trunc[] = {150, 180, 450, 540, 588, 750, 840, 900, 1008, 1050, 1260, 1500, 1800, 2160, 2250, 2700};
+  return cols ? (trunc ? in_lengths(n, cols_trunc, sizeof cols_trunc / sizeof(int)) : in_lengths(n, cols_plain, sizeof cols_plain / sizeof(int)))
+              : (trunc ? in_lengths(n, rows_trunc, sizeof rows_trunc / sizeof(int)) : in_lengths(n, rows_plain, sizeof rows_plain / sizeof(int)));
+}
+
 // FLAGS: 1 = non-temporal loads, 2 = non-temporal stores, 4 = skip the transform (access-pattern
 // probe), 8 = c2c only, 16 = fused truncation / padding adapters (d.tr_dir: 1 store, 2 load),
 // 32 = transposing store (strided kernels whose OUTPUT is contiguous along the transform axis:
