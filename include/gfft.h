@@ -179,6 +179,28 @@ int gfft_plan_create_guru(gfft_plan *plan, int precision, int kind, const gfft_i
 int gfft_plan_create_guru_padded(gfft_plan *plan, int precision, int kind, const gfft_iodim *dim, int64_t n_keep,
                                  int howmany_rank, const gfft_iodim *howmany, int in_blocks, int64_t in_block_stride,
                                  int out_blocks, int64_t out_block_stride);
+/* The two LOCAL stages of a slab-decomposed transform as one plan.  The reference joins consecutive stages whose
+ * redistribution stays on one rank with a whole-array self-Alltoallw (mpifft.py:324-331, pencil.py:168-183); the
+ * staged form here elides that copy and runs two plans; this entry runs both transforms as ONE launch per
+ * direction, plane by plane, the plane handed from the first pass to the second inside the Infinity Cache
+ * (fft_pow2_impl.h fft_fused2_kernel) -- and the all-to-all buffer of the NEXT (previous) redistribution is
+ * addressed by the strided pass itself, as gfft_plan_create_guru's blocks are.
+ *   rows    the contiguous transformed axis (is = os = 1)
+ *   cols    the strided transformed axis: n, is / os = distance between consecutive rows of a plane
+ *   planes  the batch: n planes, is / os = distance between consecutive planes
+ *   cols_first = 0: [rows, then cols] -- the forward order: input planes natural, `out_blocks` equal blocks of the
+ *     cols axis start `out_block_stride` elements apart on the output side (the send buffer of an all-to-all that
+ *     scatters that axis); = 1: [cols, then rows] -- the backward order, `in_blocks` / `in_block_stride` describe
+ *     the input side (the receive buffer).  The side of the row pass takes no blocks (GFFT_ERR_UNSUPPORTED).
+ * kind: GFFT_C2C_FORWARD / _BACKWARD; gfft_execute's d_in / d_out are the addresses of element 0 and must not
+ * overlap unless both sides have the same natural layout; the input is preserved otherwise.  Where the pair has
+ * no fused kernels (lengths other than 512 / 1024 in fp64, 1024 in fp32; too few planes for a hand-off ring) the
+ * plan runs two stand-alone passes -- the first one carries the data across, the second works in place on the
+ * output -- with the same results up to nothing: the arithmetic of a pass does not depend on its launch form.
+ * GFFT_ERR_UNSUPPORTED when a length has no single-pass register kernel or the block count does not fit. */
+int gfft_plan_create_guru2(gfft_plan *plan, int precision, int kind, const gfft_iodim *cols, const gfft_iodim *rows,
+                           const gfft_iodim *planes, int cols_first, int in_blocks, int64_t in_block_stride,
+                           int out_blocks, int64_t out_block_stride);
 /* Layouts of INTERNAL exchange buffers (between two stages of a distributed transform; never of a
  * caller's array, which keeps the reference's C order, pencil.py:347-354).  All three act on one-pass
  * plans (gfft_plan_create_guru, or gfft_plan_create on one axis) and return GFFT_ERR_UNSUPPORTED,

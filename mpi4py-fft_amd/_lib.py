@@ -55,6 +55,8 @@ def _declare(lib):
                                             c.c_int, c.c_int64, c.c_int, c.c_int64]),
         'gfft_plan_create_guru_padded': (c.c_int, [c.POINTER(vp), c.c_int, c.c_int, c.POINTER(IoDim), c.c_int64, c.c_int,
                                                    c.POINTER(IoDim), c.c_int, c.c_int64, c.c_int, c.c_int64]),
+        'gfft_plan_create_guru2': (c.c_int, [c.POINTER(vp), c.c_int, c.c_int, c.POINTER(IoDim), c.POINTER(IoDim), c.POINTER(IoDim),
+                                             c.c_int, c.c_int, c.c_int64, c.c_int, c.c_int64]),
         'gfft_plan_set_tiles': (c.c_int, [vp, c.c_int, c.c_int, c.c_int64]),
         'gfft_plan_set_flat': (c.c_int, [vp, c.c_int64, c.c_int64, c.c_int64]),
         'gfft_plan_set_split_slabs': (c.c_int, [vp, c.c_int, c.c_int, c.c_int64, c.c_int]),
@@ -208,6 +210,21 @@ class HipEngine:
         rc = lib().gfft_plan_create_guru_padded(ctypes.byref(h), int(precision), int(kind), ctypes.byref(IoDim(*[int(x) for x in dim])),
                                                 int(n_keep), len(howmany), hm, int(in_blocks), int(in_block_stride),
                                                 int(out_blocks), int(out_block_stride))
+        if rc == -2:
+            return None
+        check(rc)
+        return h
+
+    def plan_create_guru2(self, precision, kind, cols, rows, planes, cols_first=False, in_blocks=1, in_block_stride=0,
+                          out_blocks=1, out_block_stride=0):
+        """Batched 2-D plan, plane by plane, as ONE launch where a fused pair exists (gfft_plan_create_guru2): the two
+        local stages of a slab-decomposed transform.  cols / rows / planes are (n, is, os).  None when the engine has
+        no single-pass kernels for the lengths; `plan_cost(h)[2]` tells whether it runs as one launch or two."""
+        h = ctypes.c_void_p()
+        io = lambda d: ctypes.byref(IoDim(*[int(x) for x in d]))
+        rc = lib().gfft_plan_create_guru2(ctypes.byref(h), int(precision), int(kind), io(cols), io(rows), io(planes),
+                                          1 if cols_first else 0, int(in_blocks), int(in_block_stride), int(out_blocks),
+                                          int(out_block_stride))
         if rc == -2:
             return None
         check(rc)

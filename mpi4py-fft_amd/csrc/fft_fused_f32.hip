@@ -25,18 +25,23 @@ struct Fused1024F32 {
   typedef PassCfg<float, 1024, 16, 16, false, false, 1 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> RowsToRing;
   typedef PassCfg<float, 1024, 32, 32, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> ColsFromRing;
   typedef PassCfg<float, 1024, 32, 32, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirst;
+  // the strided side of the slab pairs: the array side is an all-to-all buffer of equal blocks (FLAGS 32768, FUSED_PLANES_2D_B / _CR_B)
+  typedef PassCfg<float, 1024, 32, 32, true, true, 1 | 8 | 2048 | 8192 | 32768, MODE_C2C, false, 16, 16, 4> ColsToRingB;
+  typedef PassCfg<float, 1024, 32, 32, true, true, 2 | 8 | 4096 | 8192 | 32768, MODE_C2C, false, 16, 16, 4> ColsFromRingB;
 };
 
 bool fused2_supported_f32(int kind, int n_a, int n_b) {
   if (n_a != 1024 || n_b != 1024) return false;
-  return kind == FUSED_COLS_ROWS || kind == FUSED_FOURSTEP || kind == FUSED_PLANES_2D;
+  return kind == FUSED_COLS_ROWS || kind == FUSED_FOURSTEP || kind == FUSED_PLANES_2D || kind == FUSED_PLANES_2D_B || kind == FUSED_PLANES_CR_B;
 }
 
 int fused2_tiles_f32(int kind, const PassDesc &dA, const PassDesc &dB, int *ta, int *tb) {
   switch (kind) {
     case FUSED_COLS_ROWS: *ta = (int)ColsToRingF32::ntiles(dA); *tb = (int)RowsFromRingF32::ntiles(dB); return 0;
     case FUSED_FOURSTEP: *ta = (int)Fused1024F32::FourStepFirst::ntiles(dA); *tb = (int)Fused1024F32::ColsFromRing::ntiles(dB); return 0;
+    case FUSED_PLANES_2D_B:
     case FUSED_PLANES_2D: *ta = (int)Fused1024F32::RowsToRing::ntiles(dA); *tb = (int)Fused1024F32::ColsFromRing::ntiles(dB); return 0;
+    case FUSED_PLANES_CR_B: *ta = (int)Fused1024F32::ColsToRingB::ntiles(dA); *tb = (int)RowsFromRingF32::ntiles(dB); return 0;
   }
   return -1;
 }
@@ -47,6 +52,8 @@ hipError_t launch_fused2_f32(int kind, const PassDesc &dA, const PassDesc &dB, c
     case FUSED_COLS_ROWS: return launch_fused2<ColsToRingF32, RowsFromRingF32>(dA, dB, dev, f, in, ring, out, s);
     case FUSED_FOURSTEP: return launch_fused2<Fused1024F32::FourStepFirst, Fused1024F32::ColsFromRing>(dA, dB, dev, f, in, ring, out, s);
     case FUSED_PLANES_2D: return launch_fused2<Fused1024F32::RowsToRing, Fused1024F32::ColsFromRing>(dA, dB, dev, f, in, ring, out, s);
+    case FUSED_PLANES_2D_B: return launch_fused2<Fused1024F32::RowsToRing, Fused1024F32::ColsFromRingB>(dA, dB, dev, f, in, ring, out, s);
+    case FUSED_PLANES_CR_B: return launch_fused2<Fused1024F32::ColsToRingB, RowsFromRingF32>(dA, dB, dev, f, in, ring, out, s);
   }
   return hipErrorInvalidValue;
 }

@@ -66,6 +66,9 @@ struct Fused1024R32 {
   typedef PassCfg<double, 1024, 32, 16, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 32, 32> FourStepFirst;
   typedef PassCfg<double, 1024, 32, 16, true, true, 1 | 2048 | 8192, MODE_C2C, true, 32, 32> FourStepFirstNat;
   typedef PassCfg<double, 1024, 32, 16, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 32, 32> RowsFromRingT;
+  // the strided side of the slab pairs: the array side is an all-to-all buffer of equal blocks (FLAGS 32768, FUSED_PLANES_2D_B / _CR_B)
+  typedef PassCfg<double, 1024, 32, 16, true, true, 1 | 8 | 2048 | 8192 | 32768, MODE_C2C, false, 32, 32> ColsToRingB;
+  typedef PassCfg<double, 1024, 32, 16, true, true, 2 | 8 | 4096 | 8192 | 32768, MODE_C2C, false, 32, 32> ColsFromRingB;
 };
 
 // n = 512: 32 values per thread, radices 32 x 16, 256-thread workgroups on 16 lines -- 128 KiB tiles, TWO workgroups per CU
@@ -79,6 +82,8 @@ struct Fused512R32 {
   typedef PassCfg<double, 512, 32, 16, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 32, 16> FourStepFirst;
   typedef PassCfg<double, 512, 32, 16, true, true, 1 | 2048 | 8192, MODE_C2C, true, 32, 16> FourStepFirstNat;
   typedef PassCfg<double, 512, 32, 16, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 32, 16> RowsFromRingT;
+  typedef PassCfg<double, 512, 32, 16, true, true, 1 | 8 | 2048 | 8192 | 32768, MODE_C2C, false, 32, 16> ColsToRingB;
+  typedef PassCfg<double, 512, 32, 16, true, true, 2 | 8 | 4096 | 8192 | 32768, MODE_C2C, false, 32, 16> ColsFromRingB;
 };
 
 // variant: 1 = the default, 32 values per thread / one exchange (Fused1024R32); 3 = 16 values per thread / two exchanges
@@ -113,7 +118,8 @@ bool fused2_supported_f64(int kind, int variant, int n_a, int n_b) {
   // (n = 512: measured for the 3-D schedule's pair only -- 512^3 per step 4.82 -> 4.27 ms with 24 planes of 4 MiB ahead,
   // 5.34 ms with 16: profiles/r04_ab_fuse2_n512.txt)
   // (... and the batched 2-D kind, [rows -> strided] on contiguous planes: (256,512,512) axes (1,2) 0.78 -> 0.69 ms, (512,512,512) 1.57 -> 1.34 ms)
-  if (variant == 1 && n_a == 512) return g_fuse2_n512 != 0 && (kind == FUSED_COLS_ROWS || kind == FUSED_PLANES_2D);
+  if (variant == 1 && n_a == 512) return g_fuse2_n512 != 0 && (kind == FUSED_COLS_ROWS || kind == FUSED_PLANES_2D || kind == FUSED_PLANES_2D_B || kind == FUSED_PLANES_CR_B);
+  if (kind == FUSED_PLANES_2D_B || kind == FUSED_PLANES_CR_B) return variant == 1 && n_a == 1024;
   return (variant == 1 || variant == 3) && n_a == 1024;
 }
 int g_fuse2_n512 = 1;
@@ -129,6 +135,11 @@ int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &
     *tiles_b = (int)(dA.n == 960 ? Fused960::RowsFromRing::ntiles(dB) : Fused896::RowsFromRing::ntiles(dB));
     return 0;
   }
+  if (kind == FUSED_PLANES_2D_B || kind == FUSED_PLANES_CR_B) {
+    // (same tile shapes as kinds 3 / 1: the block jump changes addresses, not tiles)
+    const int k = kind == FUSED_PLANES_2D_B ? FUSED_PLANES_2D : FUSED_COLS_ROWS;
+    return dA.n == 512 ? fused2_tiles_kind<Fused512R32>(k, dA, dB, tiles_a, tiles_b) : fused2_tiles_kind<Fused1024R32>(k, dA, dB, tiles_a, tiles_b);
+  }
   if (variant == 3) return fused2_tiles_kind<FusedCfgs<double, 1024>>(kind, dA, dB, tiles_a, tiles_b);
   if (dA.n == 512) return fused2_tiles_kind<Fused512R32>(kind, dA, dB, tiles_a, tiles_b);
   return fused2_tiles_kind<Fused1024R32>(kind, dA, dB, tiles_a, tiles_b);
@@ -143,6 +154,12 @@ hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const Pa
   if (dA.n == 960 && kind == FUSED_COLS_ROWS) return launch_fused2<Fused960::ColsToRing, Fused960::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s);
   if (dA.n == 896 && kind == FUSED_COLS_ROWS) return launch_fused2<Fused896::ColsToRing, Fused896::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s);
   if (dA.n == 960 || dA.n == 896) return hipErrorInvalidValue;
+  if (kind == FUSED_PLANES_2D_B)
+    return dA.n == 512 ? launch_fused2<Fused512R32::RowsToRing, Fused512R32::ColsFromRingB>(dA, dB, dev_descs, f, in, ring, out, s)
+                       : launch_fused2<Fused1024R32::RowsToRing, Fused1024R32::ColsFromRingB>(dA, dB, dev_descs, f, in, ring, out, s);
+  if (kind == FUSED_PLANES_CR_B)
+    return dA.n == 512 ? launch_fused2<Fused512R32::ColsToRingB, Fused512R32::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s)
+                       : launch_fused2<Fused1024R32::ColsToRingB, Fused1024R32::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s);
   if (variant == 3) return launch_fused2_kind<FusedCfgs<double, 1024>>(kind, dA, dB, dev_descs, f, in, ring, out, s);
   if (dA.n == 512) return launch_fused2_kind<Fused512R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);
   return launch_fused2_kind<Fused1024R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);

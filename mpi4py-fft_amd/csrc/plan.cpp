@@ -83,7 +83,7 @@ struct Options {
   int fuse2_group = 1;       // tiles per ticket
   int fuse2_defer = 0;       // settle an A tile's counter behind the next tile's loads (A/B)
   int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
-  int fuse2_kinds = 126;     // which pairs (bit = FusedKind): measured per kind, see make_fused2
+  int fuse2_kinds = 510;     // which pairs (bit = FusedKind): measured per kind, see make_fused2
   int fuse2_f32 = 1;         // 1: complex64 pairs (fft_fused_f32.hip); 2: the real fp32 pairs too (fft_fused_real_f32.hip: measured level, off)
   int fuse2_wait_ms = 2000;  // wall-clock limit of one wait inside a fused launch before the launch is voided (0: at once -- test hook)
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
@@ -2083,7 +2083,7 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
   if (p.kind == PK_FUSED2) {
     // two axis passes in one launch: the algorithmic bytes of both (one read + one write of the array each)
     static const char *fk[] = {"fused rows+cols", "fused cols+rows", "fused four-step", "fused 2-D rows+cols", "fused four-step (rows)",
-                               "fused r2c-rows+cols", "fused cols+c2r-rows"};
+                               "fused r2c-rows+cols", "fused cols+c2r-rows", "fused 2-D rows+cols(blocks)", "fused 2-D cols(blocks)+rows"};
     snprintf(buf, len, "%s n=%dx%d", fk[p.fused_kind], p.d.n, p.d2.n);
     if (bytes) *bytes = p.bytes2 > 1 ? p.bytes2 : (double)p.fused.planes * 2.0 * pl->precision *
                         ((double)p.d.batch * 2.0 * p.d.n + (double)p.d2.batch * 2.0 * p.d2.n);
@@ -2339,6 +2339,125 @@ int gfft_plan_create_guru_padded(gfft_plan *plan, int precision, int kind, const
 
 
 
+/* The two local stages of a slab-decomposed transform as one plan (see include/gfft.h). */
+int gfft_plan_create_guru2(gfft_plan *plan, int precision, int kind, const gfft_iodim *cols, const gfft_iodim *rows,
+                           const gfft_iodim *planes, int cols_first, int in_blocks, int64_t in_block_stride,
+                           int out_blocks, int64_t out_block_stride) {
+  if (!plan || !cols || !rows || !planes) return fail(GFFT_ERR_INVALID, "null argument");
+  *plan = nullptr;
+  if (precision != GFFT_F32 && precision != GFFT_F64) return fail(GFFT_ERR_INVALID, "precision must be 4 or 8");
+  if (kind != GFFT_C2C_FORWARD && kind != GFFT_C2C_BACKWARD) return fail(GFFT_ERR_UNSUPPORTED, "guru plans are complex-to-complex");
+  const int64_t n1 = cols->n, n2 = rows->n, np = planes->n;
+  if (n1 < 1 || n2 < 1 || np < 1) return fail(GFFT_ERR_INVALID, "bad length");
+  if (rows->is != 1 || rows->os != 1) return fail(GFFT_ERR_UNSUPPORTED, "the row axis must be contiguous on both sides");
+  if (in_blocks < 1 || out_blocks < 1) return fail(GFFT_ERR_INVALID, "bad block count");
+  // the row pass sits on the side whose rows lie whole; the strided pass carries the blocks
+  if (cols_first ? out_blocks != 1 : in_blocks != 1)
+    return fail(GFFT_ERR_UNSUPPORTED, "blocks belong to the side of the strided pass (input when it runs first, output otherwise)");
+  int rc = check_device();
+  if (rc) return rc;
+  if (!regk_ok(n1, precision) || !regk_ok(n2, precision) || mixv_supported((int)n1))
+    return fail(GFFT_ERR_UNSUPPORTED, "no single-pass register kernel for one of the lengths");
+  const int nb_ = cols_first ? in_blocks : out_blocks;
+  const int64_t bstride = cols_first ? in_block_stride : out_block_stride;
+  {
+    const int max_blocks = is_pow2(n1) ? (n1 >= 32 ? 8 : 4) : 4;           // whole thread slots per block (gfft_plan_set_split)
+    if ((nb_ & (nb_ - 1)) || nb_ > max_blocks || n1 % nb_) return fail(GFFT_ERR_UNSUPPORTED, "block count not supported for this length");
+  }
+  if ((double)np * (double)n1 >= 2147483648.0 || (double)np * (double)n2 >= 2147483648.0) return fail(GFFT_ERR_UNSUPPORTED, "batch exceeds 2^31");
+  const bool inverse = kind == GFFT_C2C_BACKWARD;
+  const int64_t esz = 2 * (int64_t)precision;
+  int lg = 0;
+  while ((1 << lg) < nb_) ++lg;
+  const int64_t per = n1 / nb_;
+
+  gfft_plan_s *pl = new gfft_plan_s;
+  pl->ndims = 0;
+  pl->kind = kind;
+  pl->precision = precision;
+  pl->variant_rows = opts().variant_rows;
+  pl->variant_cols = opts().variant_cols;
+  pl->mixv_variant = opts().mixv_variant;
+  pl->xcd_swizzle = opts().xcd_swizzle;
+  auto base = [&](int64_t n, bool strided) {
+    Pass p;
+    p.regk = true;
+    p.cols = strided;
+    p.logical_first = true;
+    p.d.n = (int)n;
+    p.d.mode = MODE_C2C;
+    p.d.conj_in = p.d.conj_out = inverse ? 1 : 0;
+    p.d.mid = 1;
+    p.d.inner = 1;
+    p.d.in_is = p.d.out_is = 1;
+    p.d.in_es = p.d.out_es = 1;
+    p.d.scale = 1.0;
+    return p;
+  };
+  // the stand-alone forms: the first pass carries the data across (IN -> OUT), the second runs in place on OUT
+  Pass pr = base(n2, false), pc = base(n1, true);
+  pc.d.batch = np * n2;
+  pc.d.inner = n2;
+  pr.d.batch = np * n1;
+  if (!cols_first) {
+    // rows: row (plane o, block m, row i of the block) from its natural place to its place in the blocked output
+    pr.d.mid = nb_;  pr.d.inner = per;
+    pr.d.in_os = planes->is;   pr.d.in_ms = per * cols->is;  pr.d.in_is = cols->is;
+    pr.d.out_os = planes->os;  pr.d.out_ms = nb_ > 1 ? bstride : per * cols->os;  pr.d.out_is = cols->os;
+    pr.src = BUF_IN;  pr.dst = BUF_OUT;
+    pc.d.in_os = pc.d.out_os = planes->os;
+    pc.d.in_es = pc.d.out_es = cols->os;
+    if (nb_ > 1) { pc.d.in_lgp = pc.d.out_lgp = lg;  pc.d.in_jump = pc.d.out_jump = bstride - per * cols->os; }
+    pc.blocks[0] = pc.blocks[1] = nb_;  pc.bstride[0] = pc.bstride[1] = nb_ > 1 ? bstride : 0;
+    pc.src = BUF_OUT;  pc.dst = BUF_OUT;
+  } else {
+    pc.d.in_os = planes->is;   pc.d.in_es = cols->is;
+    pc.d.out_os = planes->os;  pc.d.out_es = cols->os;
+    if (nb_ > 1) { pc.d.in_lgp = lg;  pc.d.in_jump = bstride - per * cols->is; }
+    pc.blocks[0] = nb_;  pc.bstride[0] = nb_ > 1 ? bstride : 0;
+    pc.src = BUF_IN;  pc.dst = BUF_OUT;
+    pr.d.inner = n1;
+    pr.d.in_os = pr.d.out_os = planes->os;
+    pr.d.in_is = pr.d.out_is = cols->os;
+    pr.src = BUF_OUT;  pr.dst = BUF_OUT;
+  }
+  rc = get_twiddles(n2, precision, &pr.d.tw);
+  if (!rc) rc = get_twiddles(n1, precision, &pc.d.tw);
+  if (rc) { delete pl; return rc; }
+  // ... and as ONE persistent launch, plane by plane through the Infinity Cache
+  bool fused = false;
+  if (np < ((int64_t)1 << 30)) {
+    int64_t P = n2;                                       // slot rows pitched off the power of two
+    if ((P * esz) % 2048 == 0) P += 256 / esz;
+    PassDesc dA, dB;
+    Pass f;
+    if (!cols_first) {
+      dA = pr.d;  dB = pc.d;
+      dA.batch = n1;  dA.mid = 1;  dA.inner = 1;  dA.in_os = cols->is;  dA.in_ms = 0;  dA.in_is = 0;  dA.out_os = P;  dA.out_ms = 0;  dA.out_is = 0;
+      dB.batch = n2;  dB.in_os = 0;  dB.out_os = 0;  dB.in_es = P;  dB.in_lgp = 0;  dB.in_jump = 0;
+      fused = make_fused2(pl, nb_ > 1 ? FUSED_PLANES_2D_B : FUSED_PLANES_2D, pr, pc, dA, dB, (int)np, planes->is * esz, planes->os * esz, n1 * P * esz, &f);
+    } else {
+      dA = pc.d;  dB = pr.d;
+      dA.batch = n2;  dA.in_os = 0;  dA.out_os = 0;  dA.out_es = P;
+      dB.batch = n1;  dB.inner = 1;  dB.in_os = P;  dB.in_is = 0;  dB.out_os = cols->os;  dB.out_is = 0;
+      fused = make_fused2(pl, nb_ > 1 ? FUSED_PLANES_CR_B : FUSED_COLS_ROWS, pc, pr, dA, dB, (int)np, planes->is * esz, planes->os * esz, n1 * P * esz, &f);
+    }
+    if (fused) pl->passes.push_back(f);
+  }
+  if (!fused) {
+    if (!cols_first) { pl->passes.push_back(pr); pl->passes.push_back(pc); }
+    else { pl->passes.push_back(pc); pl->passes.push_back(pr); }
+  }
+  pl->passes.back().carries_scale = true;
+  const double elems = (double)np * (double)n1 * (double)n2;
+  pl->flops = 5.0 * elems * std::log2((double)n1 * (double)n2);
+  pl->bytes = 4.0 * elems * (double)esz;
+  *plan = pl;
+  ++g_live_plans;
+  return GFFT_OK;
+}
+
+
 /* Tile-major layouts of exchange buffers (see include/gfft.h). */
 int gfft_plan_set_tiles(gfft_plan pl, int side, int tile, int64_t tile_stride) {
   if (!pl) return fail(GFFT_ERR_INVALID, "null plan");
@@ -2470,7 +2589,7 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
   for (const Pass &p : pl->passes) {
     if (p.kind == PK_FUSED2) {
       static const char *fk[] = {"rows -> strided", "strided -> rows", "four-step", "2-D planes: rows -> strided", "four-step: strided -> rows, transposed on store",
-                                 "r2c rows -> strided", "strided -> c2r rows"};
+                                 "r2c rows -> strided", "strided -> c2r rows", "2-D planes: rows -> strided into blocks", "2-D planes: strided from blocks -> rows"};
       if (pl->fused_off)
         snprintf(line, sizeof line, "  pair (%s) n=%d then n=%d as two stand-alone passes (a fused launch gave up a wait)%s  %s -> %s\n",
                  fk[p.fused_kind], p.d.n, p.d2.n, p.carries_scale ? " [scale]" : "", bufn[p.src], bufn[p.dst]);

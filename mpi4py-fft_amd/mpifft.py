@@ -26,11 +26,14 @@ from . import comm as _comm
 class Transform:
     """A parallel transform, forward or backward: serial transforms interleaved with global
     redistributions (mpifft.py:8-79)."""
-    def __init__(self, xfftn, transfer, pencil, fused=None, pipe=None):
+    def __init__(self, xfftn, transfer, pencil, fused=None, pipe=None, pairs=None):
         assert len(xfftn) == len(transfer) + 1 and len(pencil) == 2
         self._xfftn = tuple(xfftn)
         self._transfer = tuple(transfer)
         self._pencil = tuple(pencil)
+        # {position k: callable}: stages k and k + 1 of this direction, joined by a single-rank redistribution,
+        # run as ONE launch (PFFT._fuse_pairs); the stage objects and their arrays stay as they are
+        self._pairs = dict(pairs or {})
         # single-rank shortcut: one all-axes plan from input_array to output_array (see PFFT)
         self._fused = fused
         # (pipeline.Pipeline, is_forward): chunked execution overlapped with the exchanges
@@ -105,17 +108,23 @@ class Transform:
                 output_array[...] = self.output_array
             return self.output_array if output_array is None else output_array
         last = len(self._transfer)
-        for i in range(last):
-            self._xfftn[i](**(dict(kw, **io) if i == 0 else kw))
-            arrayA = self._xfftn[i].output_array
-            arrayB = self._xfftn[i + 1].input_array
-            if arrayA is not arrayB:          # single-rank transfers share the buffer
-                self._transfer[i](arrayA, arrayB)
-        if dst is not None and not (last and self._xfftn[last].input_array.data_ptr == dst.data_ptr):
-            kw = dict(kw, dst=dst)
-        else:
-            dst = None
-        self._xfftn[last](**(dict(kw, **io) if last == 0 else kw))
+        pos = 0
+        while pos <= last:
+            pair = self._pairs.get(pos)
+            end = pos + 1 if pair is not None else pos          # the last stage position this step covers
+            opts = dict(kw, **io) if pos == 0 else dict(kw)
+            if end == last:
+                if dst is not None and not (last and self._xfftn[pos].input_array.data_ptr == dst.data_ptr):
+                    opts['dst'] = dst
+                else:
+                    dst = None
+            (pair if pair is not None else self._xfftn[pos])(**opts)
+            if end < last:
+                arrayA = self._xfftn[end].output_array
+                arrayB = self._xfftn[end + 1].input_array
+                if arrayA is not arrayB:          # single-rank transfers share the buffer
+                    self._transfer[end](arrayA, arrayB)
+            pos = end + 1
         if output_array is not None and dst is None:
             output_array[...] = self.output_array
         return self.output_array if output_array is None else output_array
@@ -145,11 +154,21 @@ class Transform:
             t0 = sync()
             self._fused()
             return [('fft fused', sync() - t0)]
+        skip = -1
         for i, x in enumerate(self._xfftn):
+            if i == skip:
+                continue
+            pair = self._pairs.get(i)
             t0 = sync()
-            x()
-            owner = getattr(getattr(x, 'xfftn', None), '__self__', None)
-            out.append(('fft axes=%s' % (tuple(getattr(owner, 'axes', ())),), sync() - t0))
+            (pair if pair is not None else x)()
+            axes = ()
+            for y in ((x, self._xfftn[i + 1]) if pair is not None else (x,)):
+                owner = getattr(getattr(y, 'xfftn', None), '__self__', None)
+                axes += tuple(getattr(owner, 'axes', ()))
+            out.append(('fft axes=%s%s' % (axes, ' (one launch)' if pair is not None else ''), sync() - t0))
+            if pair is not None:
+                skip = i + 1
+                i, x = i + 1, self._xfftn[i + 1]
             if i < len(self._transfer):
                 arrayA, arrayB = x.output_array, self._xfftn[i + 1].input_array
                 if arrayA is not arrayB:
@@ -191,6 +210,7 @@ class PFFT:
         Default: GFFT_WIRE, else 'auto' ('overlap' when the grid runs on RCCL).
     fuse : single-GPU transforms run as one all-axes plan (default True)
     fuse_pack : serial transforms write / read the exchange buffers directly (default True)
+    fuse_pairs : stages joined by a single-rank redistribution run as one launch (slab grids; default True)
     """
     def __init__(self, comm, shape=None, axes=None, dtype=float, grid=None, padding=False,
                  collapse=False, backend='fftw', transforms=None, darray=None, **kw):
@@ -200,6 +220,7 @@ class PFFT:
         fuse = kw.pop('fuse', True)
         fuse_pack = kw.pop('fuse_pack', os.environ.get('GFFT_FUSE_PACK', '1') != '0')
         slab = kw.pop('slab', False)
+        kw_fuse_pairs = kw.pop('fuse_pairs', os.environ.get('GFFT_FUSE_PAIRS', '1') != '0')
         if shape is None:
             assert darray is not None
             shape = darray.pencil.shape
@@ -235,9 +256,13 @@ class PFFT:
             fused_fwd, fused_bck = self._plan_fused()
         elif local and transforms is None and len(self.xfftn) == 3 and fuse:
             fused_fwd, fused_bck = self._plan_fused_padded()
+        self._pair_plans = []
+        pairs_fwd, pairs_bck = {}, {}
         if not local:
             if fuse_pack:
                 self._fuse_packs()
+            if kw_fuse_pairs:
+                pairs_fwd, pairs_bck = self._fuse_pairs()
             # the route of every exchange (relay.py): collective over the grid, same order everywhere
         self.pipeline = None
         if not local and transforms is None:
@@ -257,11 +282,11 @@ class PFFT:
         self.forward = Transform(
             [o.forward for o in self.xfftn],
             [o.forward for o in self.transfer],
-            self.pencil, fused_fwd, None if self.pipeline is None else (self.pipeline, True))
+            self.pencil, fused_fwd, None if self.pipeline is None else (self.pipeline, True), pairs_fwd)
         self.backward = Transform(
             [o.backward for o in self.xfftn[::-1]],
             [o.backward for o in self.transfer[::-1]],
-            self.pencil[::-1], fused_bck, None if self.pipeline is None else (self.pipeline, False))
+            self.pencil[::-1], fused_bck, None if self.pipeline is None else (self.pipeline, False), pairs_bck)
         if os.environ.get('GFFT_CHECK', '0') not in ('0', ''):
             self.forward._check = self.backward._check = self.check
 
@@ -472,6 +497,65 @@ class PFFT:
                     continue
                 setattr(tr, attr, True)
 
+    def _fuse_pairs(self):
+        """Consecutive stages joined by a single-rank redistribution -- the reference builds a whole-array self-Alltoallw
+        there (mpifft.py:324-331, pencil.py:168-183), `_chain` lets them share one buffer -- as ONE launch per direction:
+        [rows along axis 2 -> strided along axis 1] forward, the plane handed over inside the Infinity Cache and the
+        strided pass storing straight into the send buffer of the NEXT redistribution where `_fuse_packs` made that
+        stage's output a packed one; [strided from the receive buffer -> rows] backward (gfft_plan_create_guru2).  Slab
+        grids -- (2,1,1), (8,1,1) -- are where this applies: their first two stages are local.  The stage objects,
+        `len(self.xfftn) == len(self.axes)` and the stage arrays stay; the shared middle buffer is simply not touched.
+        Taken only where libgfft runs the pair as one launch (else the two stage plans are the same work).
+        Returns ({position: callable} forward, {position: callable} backward) for the two Transforms."""
+        from . import _lib
+        eng = _lib.engine()
+        fwd, bck = {}, {}
+        if not hasattr(eng, 'plan_create_guru2') or self._transforms is not None:
+            return fwd, bck
+        L = len(self.xfftn)
+        i = 0
+        while i < len(self.transfer):
+            tr = self.transfer[i]
+            a, b = self.xfftn[i], self.xfftn[i + 1]
+            U, W, V = a.forward.input_array, a.forward.output_array, b.forward.output_array
+            ok = (tr.comm.Get_size() == 1 and len(U.shape) == 3 and tuple(a.axes) == (2,) and tuple(b.axes) == (1,)
+                  and not a._padded and not b._padded and np.dtype(U.dtype).kind == 'c'
+                  and W.data_ptr == b.forward.input_array.data_ptr and U.data_ptr != V.data_ptr
+                  and tuple(U.shape) == tuple(V.shape) == tuple(W.shape) and U.dtype == V.dtype)
+            if not ok:
+                i += 1
+                continue
+            N0, N1, N2 = (int(n) for n in U.shape)
+            p = 1
+            if i + 1 < len(self.transfer) and self.transfer[i + 1].packedA:
+                p = self.transfer[i + 1].comm.Get_size()
+            nb = N1 // p
+            plane_out, bstride = (nb * N2, N0 * nb * N2) if p > 1 else (N1 * N2, 0)
+            prec = _lib.precision_of(U.dtype)
+            hf = eng.plan_create_guru2(prec, -1, (N1, N2, N2), (N2, 1, 1), (N0, N1 * N2, plane_out), False, 1, 0, p, bstride)
+            hb = None if hf is None else eng.plan_create_guru2(prec, +1, (N1, N2, N2), (N2, 1, 1), (N0, plane_out, N1 * N2),
+                                                               True, p, bstride, 1, 0)
+            if hf is None or hb is None or eng.plan_cost(hf)[2] != 1 or eng.plan_cost(hb)[2] != 1:
+                for h in (hf, hb):
+                    if h is not None:
+                        eng.plan_destroy(h)
+                i += 1
+                continue
+            self._pair_plans += [hf, hb]
+            M = a.M * b.M
+
+            def forward(src=None, dst=None, hf=hf, U=U, V=V, M=M, **kw):
+                eng.execute_ptr(hf, (U if src is None else src).data_ptr, (V if dst is None else dst).data_ptr,
+                                M if kw.pop('normalize', True) else 1.0)
+
+            def backward(src=None, dst=None, hb=hb, U=U, V=V, M=M, **kw):
+                eng.execute_ptr(hb, (V if src is None else src).data_ptr, (U if dst is None else dst).data_ptr,
+                                M if kw.pop('normalize', False) else 1.0)
+            fwd[i] = forward
+            bck[L - 2 - i] = backward
+            i += 2
+        return fwd, bck
+
     def _plan_fused(self):
         """All ranks-local case (one GPU): every stage's redistribution is the identity, so the
         whole transform is ONE serial multi-axis plan from the first stage's input array to the
@@ -616,6 +700,10 @@ class PFFT:
         if self._fused_plans:
             for p in self._fused_plans:
                 p.destroy()
+        from . import _lib
+        for h in getattr(self, '_pair_plans', []):
+            _lib.engine().plan_destroy(h)
+        self._pair_plans = []
 
     def shape(self, forward_output=True):
         """Local shape of the spectral (True) or physical (False) array (mpifft.py:355-366)."""

@@ -264,6 +264,55 @@ class _SlabStage:
             self.plan = None
 
 
+class _PairStage:
+    """The two LOCAL stages of a slab-decomposed complex transform -- rows along axis 2 and the strided transform along
+    axis 1, joined in the reference by a self-Alltoallw (mpifft.py:324-331) -- as ONE launch per chunk of planes
+    (gfft_plan_create_guru2: the plane is handed from the first pass to the second inside the Infinity Cache).  The
+    chunks cut array axis 0, the axis the redistribution gathers; the buffer side is [chunk][peer][plane][E] with the
+    planes E elements apart (_pitch), which the strided pass addresses itself: forward natural -> buffer, backward
+    buffer -> natural.  The stage on the far side transforms axis 0 and takes the chunks all at once (_FarStage)."""
+    def __init__(self, shape, p, K, E, forward, precision):
+        N0, N1, N2 = (int(v) for v in shape)
+        N0c = N0 // K
+        eng = _lib.engine()
+        self.plan = None
+        self.launches = 0
+        if not hasattr(eng, 'plan_create_guru2'):
+            return
+        if forward:
+            h = eng.plan_create_guru2(precision, -1, (N1, N2, N2), (N2, 1, 1), (N0c, N1 * N2, E), False, 1, 0, p, N0c * E)
+        else:
+            h = eng.plan_create_guru2(precision, +1, (N1, N2, N2), (N2, 1, 1), (N0c, E, N1 * N2), True, p, N0c * E, 1, 0)
+        if h is None:
+            return
+        self.plan = h
+        self.launches = eng.plan_cost(h)[2]
+        self.nchunks = K
+        self.iter_side = 'out' if forward else 'in'
+        isz = 2 * precision
+        nat_step, buf_step = N0c * N1 * N2 * isz, p * N0c * E * isz
+        self.step_in, self.step_out = (nat_step, buf_step) if forward else (buf_step, nat_step)
+        side = type('Side', (), dict(K=K, p=p))()
+        natural = type('Side', (), dict(K=1, p=1))()
+        self.lay_in, self.lay_out = (natural, side) if forward else (side, natural)
+
+    def execute(self, eng, c, pin, pout, scale):
+        eng.execute_ptr(self.plan, pin + c * self.step_in, pout + c * self.step_out, scale)
+
+    def destroy(self):
+        if self.plan is not None:
+            _lib.engine().plan_destroy(self.plan)
+            self.plan = None
+
+
+class _FarStage(_WholeStage):
+    """_WholeStage that owns its plan: the axis-0 stage behind a _PairStage, on slabs E elements apart."""
+    def destroy(self):
+        if self.plan is not None:
+            _lib.engine().plan_destroy(self.plan)
+            self.plan = None
+
+
 def _places(desc, c):
     """Byte offset of every peer's message of chunk c on one side of an exchange: chunk-major
     ([chunk][peer], messages back to back) unless the side places them itself (`peer_stride`: the
@@ -634,6 +683,11 @@ class Pipeline:
                              widths=[_blockdist(t.shape[a], p, r)[0] for r in range(p)] if uneven else None))
         if all(e['p'] == 1 for e in plan):
             return None
+        if (len(stages) == 3 and plan[0]['p'] == 1 and plan[1]['p'] > 1 and not real0 and not any(x._padded for x in stages)
+                and os.environ.get('GFFT_FUSE_PAIRS', '1') != '0' and (layout or os.environ.get('GFFT_PIPE_LAYOUT', 'aligned')) == 'aligned'):
+            pair = cls._build_slab_pair(pfft, plan[1], dtype)
+            if pair is not None:
+                return pair
 
         self = cls()
         self.pfft = pfft
@@ -778,6 +832,77 @@ class Pipeline:
             self.destroy()
             return None
         self.M = [x.M for x in stages]
+        self.comm_stream = _streams()[1]
+        self._events, self._works = {}, {}
+        self._want_relays = False
+        return self
+
+    @classmethod
+    def _build_slab_pair(cls, pfft, e, dtype):
+        """Slab grids -- (2,1,1), (8,1,1): the first redistribution stays on the rank -- as [axis 2 + axis 1 in one launch per
+        chunk of planes] -> redistribution over all ranks -> [axis 0] (see _PairStage).  None where libgfft has no fused
+        pair for the shape (the caller then builds the stage-by-stage pipeline)."""
+        import torch
+        stages = pfft.xfftn
+        eng = _lib.engine()
+        s0, s1, s2 = stages
+        if [tuple(x.axes) for x in stages] != [(2,), (1,), (0,)] or (e['a'], e['b']) != (1, 0):
+            return None
+        wire, p = e['wire'], e['p']
+        if not wire.owns_stream and not hasattr(wire, 'exchange_placed'):
+            return None
+        sh0 = tuple(int(v) for v in s0.forward.input_array.shape)
+        sh2 = tuple(int(v) for v in s2.forward.input_array.shape)
+        if tuple(int(v) for v in s1.forward.input_array.shape) != sh0 or tuple(int(v) for v in s1.forward.output_array.shape) != sh0:
+            return None
+        N0, N1, N2 = sh0
+        M0, N1b, W = sh2
+        if M0 != p * N0 or N1 != p * N1b or W != N2:
+            return None                                     # both cut axes split evenly: every rank cuts the same slabs
+        isz = dtype.itemsize
+        prec = _lib.precision_of(dtype)
+        E = _pitch(N1b * W, isz)
+        # chunks of planes: as many as the exchange policy allows among those the pair still runs as ONE launch on
+        # (a launch needs planes enough for its hand-off ring, plan.cpp fused2_ring)
+        nbytes = N0 * N1 * N2 * isz
+        cands = [k for k in range(min(cls.CHUNKS, N0), 1, -1) if N0 % k == 0 and nbytes // k >= cls.MIN_CHUNK_BYTES] + [1]
+        pf = pb = None
+        for K in cands:
+            pf, pb = _PairStage(sh0, p, K, E, True, prec), _PairStage(sh0, p, K, E, False, prec)
+            if pf.launches == 1 and pb.launches == 1:
+                break
+            pf.destroy()
+            pb.destroy()
+            pf = pb = None
+        if pf is None:
+            return None
+        N0c = N0 // K
+        hf = eng.plan_create_guru(prec, -1, (M0, E, N1b * W), [(N1b, W, W), (W, 1, 1)], 1, 0, 1, 0)
+        hb = eng.plan_create_guru(prec, +1, (M0, N1b * W, E), [(N1b, W, W), (W, 1, 1)], 1, 0, 1, 0)
+        if hf is None or hb is None:
+            for h in (hf, hb):
+                if h is not None:
+                    eng.plan_destroy(h)
+            pf.destroy()
+            pb.destroy()
+            return None
+        self = cls()
+        self.pfft, self.dtype, self.isz = pfft, dtype, isz
+        self.precision = prec
+        self.layout = 'slab-pair'
+        e = dict(e, f=0, K=K, uneven=False, widths=None, no_relay=True)
+        e['A'] = dict(chunk=p * N0c * E * isz, sizes=[N0c * E * isz] * p)
+        e['B'] = dict(sizes=[N0c * E * isz] * p, chunk_stride=N0c * E * isz, peer_stride=N0 * E * isz)
+        self.tplan = [e]
+        dev = s0.forward.input_array.tensor.device
+        tdt = s0.forward.input_array.tensor.dtype
+        send = torch.empty(K * p * N0c * E, dtype=tdt, device=dev)
+        recv = torch.empty(M0 * E, dtype=tdt, device=dev)
+        self.in_buf = [s0.forward.input_array.tensor, recv]
+        self.out_buf = [send, s2.forward.output_array.tensor]
+        self.fwd = [pf, _FarStage(hf, K_in=K)]
+        self.bwd = [pb, _FarStage(hb, K_out=K)]
+        self.M = [s0.M * s1.M, s2.M]
         self.comm_stream = _streams()[1]
         self._events, self._works = {}, {}
         self._want_relays = False

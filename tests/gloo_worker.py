@@ -80,11 +80,19 @@ def main():
     pipeline.Pipeline.MIN_WIDTH = 2
     misplaced_chunks = []
     os.environ['GFFT_RELAY'] = '0'
-    # (the last three take the line-aligned exchange buffers of pipeline._Aligned: tile-major T0, pitched T1)
+    # (the 256-wide ones take the line-aligned exchange buffers of pipeline._Aligned: tile-major T0, pitched T1; complex
+    # transforms on slab grids run their two local stages as one launch per chunk of planes, pipeline._PairStage --
+    # and stage by stage with GFFT_FUSE_PAIRS=0)
     for shape, dt, kw, layout in (((32, 16, 64), 'D', {}, None), ((16, 32, 32), 'F', {}, None),
-                                  ((32, 32, 16), 'D', dict(grid=(-1,)), None),
+                                  ((32, 32, 16), 'D', dict(grid=(-1,)), 'slab-pair'),
                                   ((16, 32, 256), 'D', {}, 'aligned'), ((32, 16, 256), 'F', {}, 'aligned'),
-                                  ((32, 32, 64), 'D', dict(grid=(-1,)), 'aligned')):
+                                  ((64, 32, 64), 'F', dict(grid=(-1,)), 'slab-pair'),
+                                  ((32, 32, 64), 'D', dict(grid=(-1,), fuse_pairs=None), 'aligned')):
+        kw = dict(kw)
+        os.environ['GFFT_FUSE_PAIRS'] = '0' if 'fuse_pairs' in kw else '1'
+        if P == 2 and layout == 'aligned' and 'fuse_pairs' not in kw:
+            layout = 'slab-pair'                   # (two ranks: the default grid IS a slab)
+        kw.pop('fuse_pairs', None)
         if any(n % 8 for n in shape) and P == 8:
             continue
         ref = O.OPFFT(P, shape, dtype=dt, **{k: (list(v) if isinstance(v, list) else v) for k, v in kw.items()})
@@ -117,6 +125,7 @@ def main():
                 w.exchange_chunk = good
             assert selftest.exchange_check(piped, world)['result'] == 'bit-exact'
         piped.destroy()
+    os.environ['GFFT_FUSE_PAIRS'] = '1'
     assert misplaced_chunks
     # DistArray.redistribute over the real communicator (tests/test_darray.py:50-57)
     N = (8, 10, 12)

@@ -88,6 +88,42 @@ class HostEngine:
                     howmany=[tuple(int(x) for x in d) for d in howmany], inb=(in_blocks, in_block_stride),
                     outb=(out_blocks, out_block_stride))
 
+    def plan_create_guru2(self, precision, kind, cols, rows, planes, cols_first=False, in_blocks=1, in_block_stride=0,
+                          out_blocks=1, out_block_stride=0):
+        """gfft_plan_create_guru2: batched 2-D transform plane by plane, the strided axis in blocks on one side"""
+        n1, n2 = int(cols[0]), int(rows[0])
+        if n1 & (n1 - 1) or n2 & (n2 - 1) or n1 < 16 or n2 < 16 or tuple(rows[1:]) != (1, 1):
+            return None
+        if (out_blocks if cols_first else in_blocks) != 1:
+            return None
+        nb = in_blocks if cols_first else out_blocks
+        if nb & (nb - 1) or nb > 8 or n1 % nb:
+            return None
+        return dict(guru2=True, precision=precision, kind=kind, cols=tuple(int(x) for x in cols), n2=n2,
+                    planes=tuple(int(x) for x in planes), inb=(in_blocks, in_block_stride), outb=(out_blocks, out_block_stride))
+
+    def _execute_guru2(self, h, ptr_in, ptr_out, scale):
+        import ctypes
+        cdt = np.complex128 if h['precision'] == 8 else np.complex64
+        isz = np.dtype(cdt).itemsize
+        n1, c_i, c_o = h['cols']
+        n2 = h['n2']
+        npl, p_i, p_o = h['planes']
+
+        def offsets(which):
+            es, ps = (c_i, p_i) if which == 0 else (c_o, p_o)
+            nb, bs = h['inb'] if which == 0 else h['outb']
+            e = np.arange(n1)
+            per = n1 // nb
+            line = (e // per) * bs + (e % per) * es if nb > 1 else e * es
+            return np.arange(npl)[:, None, None] * ps + line[None, :, None] + np.arange(n2)[None, None, :]
+        oi, oo = offsets(0), offsets(1)
+        fin = np.frombuffer((ctypes.c_char * ((int(oi.max()) + 1) * isz)).from_address(ptr_in), dtype=cdt)
+        fout = np.frombuffer((ctypes.c_char * ((int(oo.max()) + 1) * isz)).from_address(ptr_out), dtype=cdt)
+        a = fin[oi]
+        r = np.fft.fft2(a, axes=(1, 2)) if h['kind'] == -1 else np.fft.ifft2(a, axes=(1, 2)) * (n1 * n2)
+        fout[oo] = (r * scale).astype(cdt)
+
     def plan_set_tiles(self, h, side, tile, tile_stride):
         """gfft_plan_set_tiles: the transformed axis (plans along a contiguous axis) or the adjacent
         columns (strided plans) of one side are tile-major."""
@@ -109,6 +145,8 @@ class HostEngine:
 
     def execute_ptr(self, h, ptr_in, ptr_out, scale, stream=None):
         import ctypes
+        if h.get('guru2'):
+            return self._execute_guru2(h, ptr_in, ptr_out, scale)
         n, es_in, es_out = h['dim']
         cdt = np.complex128 if h['precision'] == 8 else np.complex64
         isz = np.dtype(cdt).itemsize
@@ -161,7 +199,7 @@ class HostEngine:
         return 'host checker plan %r' % (h,)
 
     def plan_cost(self, h):
-        return 0.0, 0.0, 0
+        return 0.0, 0.0, (1 if h.get('guru2') else 0)
 
     def pack(self, tarray, tpacked, shape, axis, nparts, itemsize):
         a = _np(tarray).reshape(shape)
