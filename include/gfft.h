@@ -188,10 +188,13 @@ int gfft_plan_create_guru_padded(gfft_plan *plan, int precision, int kind, const
  *   rows    the contiguous transformed axis (is = os = 1)
  *   cols    the strided transformed axis: n, is / os = distance between consecutive rows of a plane
  *   planes  the batch: n planes, is / os = distance between consecutive planes
- *   cols_first = 0: [rows, then cols] -- the forward order: input planes natural, `out_blocks` equal blocks of the
- *     cols axis start `out_block_stride` elements apart on the output side (the send buffer of an all-to-all that
- *     scatters that axis); = 1: [cols, then rows] -- the backward order, `in_blocks` / `in_block_stride` describe
- *     the input side (the receive buffer).  The side of the row pass takes no blocks (GFFT_ERR_UNSUPPORTED).
+ *   cols_first = 1: [cols, then rows] -- strided reads, whole rows written: the faster order in both directions
+ *     (measured, tools/stage_probe.py slab); 0: [rows, then cols].
+ *   in_blocks / in_block_stride, out_blocks / out_block_stride: the cols axis stored as that many equal blocks whose
+ *     starts lie that many elements apart (1 = contiguous) -- the receive buffer of the all-to-all that gathered that
+ *     axis on the input side (backward direction), the send buffer of the one that scatters it on the output side
+ *     (forward).  The strided pass adds the block jump to its step; the row pass places every row by its block.
+ *     At most one side takes blocks.
  * kind: GFFT_C2C_FORWARD / _BACKWARD; gfft_execute's d_in / d_out are the addresses of element 0 and must not
  * overlap unless both sides have the same natural layout; the input is preserved otherwise.  Where the pair has
  * no fused kernels (lengths other than 512 / 1024 in fp64, 1024 in fp32; too few planes for a hand-off ring) the

@@ -1653,6 +1653,98 @@ namespace gfft {
 int pow2_grid_cap() { return opts().grid_cap > 0 ? opts().grid_cap : 4096; }
 }  // namespace gfft
 
+// Batched 2-D complex transform plane by plane: the passes of gfft_plan_create_guru2 (see there), pushed onto pl->passes
+// -- one fused launch where a pair exists, else (unless fused_only) the two stand-alone passes [first: IN -> OUT, second:
+// in place on OUT].
+static int build_pair2d(gfft_plan_s *pl, const gfft_iodim *cols, int64_t n2, const gfft_iodim *planes, bool inverse, int cols_first,
+                        int in_blocks, int64_t in_block_stride, int out_blocks, int64_t out_block_stride, bool fused_only, bool *fused_out) {
+  const int precision = pl->precision;
+  const int64_t esz = 2 * (int64_t)precision;
+  const int64_t n1 = cols->n, np = planes->n;
+  auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+  // one side of the array pair as the two passes see it: the strided pass steps es along the axis and jumps between
+  // blocks; the row pass places row r = (block m, row i of the block) by its batch strides
+  struct Side { int nb; int64_t per, es, bstride, plane; };
+  const Side si{in_blocks, n1 / in_blocks, cols->is, in_blocks > 1 ? in_block_stride : (n1 / in_blocks) * cols->is, planes->is};
+  const Side so{out_blocks, n1 / out_blocks, cols->os, out_blocks > 1 ? out_block_stride : (n1 / out_blocks) * cols->os, planes->os};
+
+  auto base = [&](int64_t n, bool strided) {
+    Pass p;
+    p.regk = true;
+    p.cols = strided;
+    p.logical_first = true;
+    p.d.n = (int)n;
+    p.d.mode = MODE_C2C;
+    p.d.conj_in = p.d.conj_out = inverse ? 1 : 0;
+    p.d.mid = 1;
+    p.d.inner = 1;
+    p.d.in_is = p.d.out_is = 1;
+    p.d.in_es = p.d.out_es = 1;
+    p.d.scale = 1.0;
+    return p;
+  };
+  auto cols_in = [&](Pass &p, const Side &s) {
+    p.d.in_os = s.plane;  p.d.in_es = s.es;
+    if (s.nb > 1) { p.d.in_lgp = lg2(s.nb);  p.d.in_jump = s.bstride - s.per * s.es; }
+    p.blocks[0] = s.nb;  p.bstride[0] = s.nb > 1 ? s.bstride : 0;
+  };
+  auto cols_out = [&](Pass &p, const Side &s) {
+    p.d.out_os = s.plane;  p.d.out_es = s.es;
+    if (s.nb > 1) { p.d.out_lgp = lg2(s.nb);  p.d.out_jump = s.bstride - s.per * s.es; }
+    p.blocks[1] = s.nb;  p.bstride[1] = s.nb > 1 ? s.bstride : 0;
+  };
+  // the stand-alone forms: the first pass carries the data across (IN -> OUT), the second runs in place on OUT
+  Pass pr = base(n2, false), pc = base(n1, true);
+  pc.d.batch = np * n2;
+  pc.d.inner = n2;
+  pr.d.batch = np * n1;
+  const Side &rs = (si.nb > 1 && !cols_first) ? si : so;        // the blocks the row pass walks its rows by
+  pr.d.mid = rs.nb;  pr.d.inner = rs.per;
+  if (!cols_first) {
+    pr.d.in_os = si.plane;   pr.d.in_ms = si.nb > 1 ? si.bstride : rs.per * si.es;  pr.d.in_is = si.es;
+    pr.d.out_os = so.plane;  pr.d.out_ms = so.nb > 1 ? so.bstride : rs.per * so.es;  pr.d.out_is = so.es;
+    pr.src = BUF_IN;  pr.dst = BUF_OUT;
+    cols_in(pc, so);  cols_out(pc, so);
+    pc.src = BUF_OUT;  pc.dst = BUF_OUT;
+  } else {
+    cols_in(pc, si);  cols_out(pc, so);
+    pc.src = BUF_IN;  pc.dst = BUF_OUT;
+    pr.d.in_os = pr.d.out_os = so.plane;
+    pr.d.in_ms = pr.d.out_ms = so.bstride;
+    pr.d.in_is = pr.d.out_is = so.es;
+    pr.src = BUF_OUT;  pr.dst = BUF_OUT;
+  }
+  int rc = get_twiddles(n2, precision, &pr.d.tw);
+  if (!rc) rc = get_twiddles(n1, precision, &pc.d.tw);
+  if (rc) return rc;
+  // ... and as ONE persistent launch, plane by plane through the Infinity Cache: slot[row of the plane][P]
+  bool fused = false;
+  if (np < ((int64_t)1 << 30)) {
+    int64_t P = n2;                                       // slot rows pitched off the power of two
+    if ((P * esz) % 2048 == 0) P += 256 / esz;
+    PassDesc dA, dB;
+    Pass f;
+    if (!cols_first) {
+      dA = pr.d;  dB = pc.d;
+      dA.batch = n1;  dA.in_os = 0;  dA.out_os = 0;  dA.out_ms = rs.per * P;  dA.out_is = P;
+      dB.batch = n2;  dB.in_os = 0;  dB.out_os = 0;  dB.in_es = P;  dB.in_lgp = 0;  dB.in_jump = 0;
+      fused = make_fused2(pl, so.nb > 1 ? FUSED_PLANES_2D_B : FUSED_PLANES_2D, pr, pc, dA, dB, (int)np, si.plane * esz, so.plane * esz, n1 * P * esz, &f);
+    } else {
+      dA = pc.d;  dB = pr.d;
+      dA.batch = n2;  dA.in_os = 0;  dA.out_os = 0;  dA.out_es = P;  dA.out_lgp = 0;  dA.out_jump = 0;
+      dB.batch = n1;  dB.in_os = 0;  dB.out_os = 0;  dB.in_ms = rs.per * P;  dB.in_is = P;
+      fused = make_fused2(pl, si.nb > 1 ? FUSED_PLANES_CR_B : FUSED_COLS_ROWS, pc, pr, dA, dB, (int)np, si.plane * esz, so.plane * esz, n1 * P * esz, &f);
+    }
+    if (fused) pl->passes.push_back(f);
+  }
+  if (!fused && !fused_only) {
+    if (!cols_first) { pl->passes.push_back(pr); pl->passes.push_back(pc); }
+    else { pl->passes.push_back(pc); pl->passes.push_back(pr); }
+  }
+  *fused_out = fused;
+  return GFFT_OK;
+}
+
 extern "C" {
 
 const char *gfft_strerror(int status) {
@@ -1795,24 +1887,20 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
     for (int i = naxes - 1; i >= 0 && !rc; --i)
       rc = line(ax[i], MODE_C2C, inv, pl->sizes_in, pl->sizes_in, i == naxes - 1 ? BUF_IN : BUF_OUT, BUF_OUT);
     // Batched 2-D transforms over the last two axes of a 3-D array -- the leading stage of a slab-decomposed
-    // PFFT with collapse=True, or fftn(axes=(1, 2)) --: [rows] -> [columns] plane by plane in one fused launch
-    // (FUSED_PLANES_2D: the [rows -> strided] kernels on planes whose rows are CONTIGUOUS, the case that pays;
-    // in the 3-D schedule the same pair would read rows scattered and stays off, plan_fused3)
+    // PFFT with collapse=True, or fftn(axes=(1, 2)) --: plane by plane in one fused launch, [strided along axis 1 ->
+    // rows along axis 2] in both directions (build_pair2d: strided reads, whole rows written -- round 6; the [rows ->
+    // strided] order of rounds 4-5 stores 256-byte pieces: (512,1024,1024) complex128 5.57 against 4.79 ms,
+    // profiles/r06_stage_probe_slab.txt)
     if (!rc && ndims == 3 && naxes == 2 && ax[0] == 1 && ax[1] == 2 && pl->passes.size() == 2) {
       const Pass &pr = pl->passes[0], &pc = pl->passes[1];
-      const int64_t n0 = sizes_in[0], n1 = sizes_in[1], n2 = sizes_in[2], esz = 2 * (int64_t)precision;
+      const int64_t n0 = sizes_in[0], n1 = sizes_in[1], n2 = sizes_in[2];
       if (pr.kind == PK_FFT && pc.kind == PK_FFT && pr.regk && pc.regk && !pr.cols && pc.cols && !pr.d.tw_hi && !pc.d.tw_hi &&
-          n0 < ((int64_t)1 << 30)) {
-        int64_t P = n2;                                   // slot rows pitched off the power of two
-        if ((P * esz) % 2048 == 0) P += 256 / esz;
-        PassDesc dA = pr.d, dB = pc.d;
-        dA.batch = n1; dA.out_os = P;
-        dB.batch = n2; dB.in_os = 0; dB.out_os = 0; dB.in_es = P;
-        Pass f;
-        if (make_fused2(pl, FUSED_PLANES_2D, pr, pc, dA, dB, (int)n0, n1 * n2 * esz, n1 * n2 * esz, n1 * P * esz, &f)) {
-          pl->passes.clear();
-          pl->passes.push_back(f);
-        }
+          is_pow2(n1) && is_pow2(n2) && n0 < ((int64_t)1 << 30)) {
+        const std::vector<Pass> two = pl->passes;
+        pl->passes.clear();
+        const gfft_iodim c{n1, n2, n2}, p{n0, n1 * n2, n1 * n2};
+        bool fused = false;
+        if (build_pair2d(pl, &c, n2, &p, inv, 1, 1, 0, 1, 0, true, &fused) != GFFT_OK || !fused) pl->passes = two;
       }
     }
   } else if (kind == GFFT_R2C) {
@@ -2351,26 +2439,17 @@ int gfft_plan_create_guru2(gfft_plan *plan, int precision, int kind, const gfft_
   if (n1 < 1 || n2 < 1 || np < 1) return fail(GFFT_ERR_INVALID, "bad length");
   if (rows->is != 1 || rows->os != 1) return fail(GFFT_ERR_UNSUPPORTED, "the row axis must be contiguous on both sides");
   if (in_blocks < 1 || out_blocks < 1) return fail(GFFT_ERR_INVALID, "bad block count");
-  // the row pass sits on the side whose rows lie whole; the strided pass carries the blocks
-  if (cols_first ? out_blocks != 1 : in_blocks != 1)
-    return fail(GFFT_ERR_UNSUPPORTED, "blocks belong to the side of the strided pass (input when it runs first, output otherwise)");
+  if (in_blocks > 1 && out_blocks > 1) return fail(GFFT_ERR_UNSUPPORTED, "blocks on one side only");
   int rc = check_device();
   if (rc) return rc;
   if (!regk_ok(n1, precision) || !regk_ok(n2, precision) || mixv_supported((int)n1))
     return fail(GFFT_ERR_UNSUPPORTED, "no single-pass register kernel for one of the lengths");
-  const int nb_ = cols_first ? in_blocks : out_blocks;
-  const int64_t bstride = cols_first ? in_block_stride : out_block_stride;
-  {
+  for (int nb_ : {in_blocks, out_blocks}) {
     const int max_blocks = is_pow2(n1) ? (n1 >= 32 ? 8 : 4) : 4;           // whole thread slots per block (gfft_plan_set_split)
     if ((nb_ & (nb_ - 1)) || nb_ > max_blocks || n1 % nb_) return fail(GFFT_ERR_UNSUPPORTED, "block count not supported for this length");
   }
   if ((double)np * (double)n1 >= 2147483648.0 || (double)np * (double)n2 >= 2147483648.0) return fail(GFFT_ERR_UNSUPPORTED, "batch exceeds 2^31");
-  const bool inverse = kind == GFFT_C2C_BACKWARD;
   const int64_t esz = 2 * (int64_t)precision;
-  int lg = 0;
-  while ((1 << lg) < nb_) ++lg;
-  const int64_t per = n1 / nb_;
-
   gfft_plan_s *pl = new gfft_plan_s;
   pl->ndims = 0;
   pl->kind = kind;
@@ -2379,75 +2458,9 @@ int gfft_plan_create_guru2(gfft_plan *plan, int precision, int kind, const gfft_
   pl->variant_cols = opts().variant_cols;
   pl->mixv_variant = opts().mixv_variant;
   pl->xcd_swizzle = opts().xcd_swizzle;
-  auto base = [&](int64_t n, bool strided) {
-    Pass p;
-    p.regk = true;
-    p.cols = strided;
-    p.logical_first = true;
-    p.d.n = (int)n;
-    p.d.mode = MODE_C2C;
-    p.d.conj_in = p.d.conj_out = inverse ? 1 : 0;
-    p.d.mid = 1;
-    p.d.inner = 1;
-    p.d.in_is = p.d.out_is = 1;
-    p.d.in_es = p.d.out_es = 1;
-    p.d.scale = 1.0;
-    return p;
-  };
-  // the stand-alone forms: the first pass carries the data across (IN -> OUT), the second runs in place on OUT
-  Pass pr = base(n2, false), pc = base(n1, true);
-  pc.d.batch = np * n2;
-  pc.d.inner = n2;
-  pr.d.batch = np * n1;
-  if (!cols_first) {
-    // rows: row (plane o, block m, row i of the block) from its natural place to its place in the blocked output
-    pr.d.mid = nb_;  pr.d.inner = per;
-    pr.d.in_os = planes->is;   pr.d.in_ms = per * cols->is;  pr.d.in_is = cols->is;
-    pr.d.out_os = planes->os;  pr.d.out_ms = nb_ > 1 ? bstride : per * cols->os;  pr.d.out_is = cols->os;
-    pr.src = BUF_IN;  pr.dst = BUF_OUT;
-    pc.d.in_os = pc.d.out_os = planes->os;
-    pc.d.in_es = pc.d.out_es = cols->os;
-    if (nb_ > 1) { pc.d.in_lgp = pc.d.out_lgp = lg;  pc.d.in_jump = pc.d.out_jump = bstride - per * cols->os; }
-    pc.blocks[0] = pc.blocks[1] = nb_;  pc.bstride[0] = pc.bstride[1] = nb_ > 1 ? bstride : 0;
-    pc.src = BUF_OUT;  pc.dst = BUF_OUT;
-  } else {
-    pc.d.in_os = planes->is;   pc.d.in_es = cols->is;
-    pc.d.out_os = planes->os;  pc.d.out_es = cols->os;
-    if (nb_ > 1) { pc.d.in_lgp = lg;  pc.d.in_jump = bstride - per * cols->is; }
-    pc.blocks[0] = nb_;  pc.bstride[0] = nb_ > 1 ? bstride : 0;
-    pc.src = BUF_IN;  pc.dst = BUF_OUT;
-    pr.d.inner = n1;
-    pr.d.in_os = pr.d.out_os = planes->os;
-    pr.d.in_is = pr.d.out_is = cols->os;
-    pr.src = BUF_OUT;  pr.dst = BUF_OUT;
-  }
-  rc = get_twiddles(n2, precision, &pr.d.tw);
-  if (!rc) rc = get_twiddles(n1, precision, &pc.d.tw);
-  if (rc) { delete pl; return rc; }
-  // ... and as ONE persistent launch, plane by plane through the Infinity Cache
   bool fused = false;
-  if (np < ((int64_t)1 << 30)) {
-    int64_t P = n2;                                       // slot rows pitched off the power of two
-    if ((P * esz) % 2048 == 0) P += 256 / esz;
-    PassDesc dA, dB;
-    Pass f;
-    if (!cols_first) {
-      dA = pr.d;  dB = pc.d;
-      dA.batch = n1;  dA.mid = 1;  dA.inner = 1;  dA.in_os = cols->is;  dA.in_ms = 0;  dA.in_is = 0;  dA.out_os = P;  dA.out_ms = 0;  dA.out_is = 0;
-      dB.batch = n2;  dB.in_os = 0;  dB.out_os = 0;  dB.in_es = P;  dB.in_lgp = 0;  dB.in_jump = 0;
-      fused = make_fused2(pl, nb_ > 1 ? FUSED_PLANES_2D_B : FUSED_PLANES_2D, pr, pc, dA, dB, (int)np, planes->is * esz, planes->os * esz, n1 * P * esz, &f);
-    } else {
-      dA = pc.d;  dB = pr.d;
-      dA.batch = n2;  dA.in_os = 0;  dA.out_os = 0;  dA.out_es = P;
-      dB.batch = n1;  dB.inner = 1;  dB.in_os = P;  dB.in_is = 0;  dB.out_os = cols->os;  dB.out_is = 0;
-      fused = make_fused2(pl, nb_ > 1 ? FUSED_PLANES_CR_B : FUSED_COLS_ROWS, pc, pr, dA, dB, (int)np, planes->is * esz, planes->os * esz, n1 * P * esz, &f);
-    }
-    if (fused) pl->passes.push_back(f);
-  }
-  if (!fused) {
-    if (!cols_first) { pl->passes.push_back(pr); pl->passes.push_back(pc); }
-    else { pl->passes.push_back(pc); pl->passes.push_back(pr); }
-  }
+  rc = build_pair2d(pl, cols, n2, planes, kind == GFFT_C2C_BACKWARD, cols_first, in_blocks, in_block_stride, out_blocks, out_block_stride, false, &fused);
+  if (rc) { delete pl; return rc; }
   pl->passes.back().carries_scale = true;
   const double elems = (double)np * (double)n1 * (double)n2;
   pl->flops = 5.0 * elems * std::log2((double)n1 * (double)n2);
@@ -2456,7 +2469,6 @@ int gfft_plan_create_guru2(gfft_plan *plan, int precision, int kind, const gfft_
   ++g_live_plans;
   return GFFT_OK;
 }
-
 
 /* Tile-major layouts of exchange buffers (see include/gfft.h). */
 int gfft_plan_set_tiles(gfft_plan pl, int side, int tile, int64_t tile_stride) {

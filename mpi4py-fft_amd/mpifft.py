@@ -500,9 +500,10 @@ class PFFT:
     def _fuse_pairs(self):
         """Consecutive stages joined by a single-rank redistribution -- the reference builds a whole-array self-Alltoallw
         there (mpifft.py:324-331, pencil.py:168-183), `_chain` lets them share one buffer -- as ONE launch per direction:
-        [rows along axis 2 -> strided along axis 1] forward, the plane handed over inside the Infinity Cache and the
-        strided pass storing straight into the send buffer of the NEXT redistribution where `_fuse_packs` made that
-        stage's output a packed one; [strided from the receive buffer -> rows] backward (gfft_plan_create_guru2).  Slab
+        [strided along axis 1 -> rows along axis 2], the plane handed over inside the Infinity Cache: forward the rows
+        are stored straight into the send buffer of the NEXT redistribution where `_fuse_packs` made that stage's
+        output a packed one, backward the strided pass reads the receive buffer (gfft_plan_create_guru2; a 2-D
+        transform may take its axes in either order, and strided reads + whole rows written is the faster one).  Slab
         grids -- (2,1,1), (8,1,1) -- are where this applies: their first two stages are local.  The stage objects,
         `len(self.xfftn) == len(self.axes)` and the stage arrays stay; the shared middle buffer is simply not touched.
         Taken only where libgfft runs the pair as one launch (else the two stage plans are the same work).
@@ -532,7 +533,7 @@ class PFFT:
             nb = N1 // p
             plane_out, bstride = (nb * N2, N0 * nb * N2) if p > 1 else (N1 * N2, 0)
             prec = _lib.precision_of(U.dtype)
-            hf = eng.plan_create_guru2(prec, -1, (N1, N2, N2), (N2, 1, 1), (N0, N1 * N2, plane_out), False, 1, 0, p, bstride)
+            hf = eng.plan_create_guru2(prec, -1, (N1, N2, N2), (N2, 1, 1), (N0, N1 * N2, plane_out), True, 1, 0, p, bstride)
             hb = None if hf is None else eng.plan_create_guru2(prec, +1, (N1, N2, N2), (N2, 1, 1), (N0, plane_out, N1 * N2),
                                                                True, p, bstride, 1, 0)
             if hf is None or hb is None or eng.plan_cost(hf)[2] != 1 or eng.plan_cost(hb)[2] != 1:

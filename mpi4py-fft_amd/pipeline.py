@@ -269,8 +269,10 @@ class _PairStage:
     axis 1, joined in the reference by a self-Alltoallw (mpifft.py:324-331) -- as ONE launch per chunk of planes
     (gfft_plan_create_guru2: the plane is handed from the first pass to the second inside the Infinity Cache).  The
     chunks cut array axis 0, the axis the redistribution gathers; the buffer side is [chunk][peer][plane][E] with the
-    planes E elements apart (_pitch), which the strided pass addresses itself: forward natural -> buffer, backward
-    buffer -> natural.  The stage on the far side transforms axis 0 and takes the chunks all at once (_FarStage)."""
+    planes E elements apart (_pitch), which the pair addresses itself: forward natural -> buffer, backward buffer ->
+    natural, both as [strided pass, then rows] -- strided reads, whole rows written (the forward pair the other way round,
+    its strided pass storing 256-byte pieces into the buffer: 5.5 against 4.8 ms at (512,1024,1024) complex128,
+    profiles/r06_stage_probe_slab.txt).  The stage on the far side transforms axis 0 and takes the chunks all at once (_FarStage)."""
     def __init__(self, shape, p, K, E, forward, precision):
         N0, N1, N2 = (int(v) for v in shape)
         N0c = N0 // K
@@ -280,7 +282,7 @@ class _PairStage:
         if not hasattr(eng, 'plan_create_guru2'):
             return
         if forward:
-            h = eng.plan_create_guru2(precision, -1, (N1, N2, N2), (N2, 1, 1), (N0c, N1 * N2, E), False, 1, 0, p, N0c * E)
+            h = eng.plan_create_guru2(precision, -1, (N1, N2, N2), (N2, 1, 1), (N0c, N1 * N2, E), True, 1, 0, p, N0c * E)
         else:
             h = eng.plan_create_guru2(precision, +1, (N1, N2, N2), (N2, 1, 1), (N0c, E, N1 * N2), True, p, N0c * E, 1, 0)
         if h is None:

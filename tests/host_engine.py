@@ -94,11 +94,11 @@ class HostEngine:
         n1, n2 = int(cols[0]), int(rows[0])
         if n1 & (n1 - 1) or n2 & (n2 - 1) or n1 < 16 or n2 < 16 or tuple(rows[1:]) != (1, 1):
             return None
-        if (out_blocks if cols_first else in_blocks) != 1:
+        if in_blocks > 1 and out_blocks > 1:
             return None
-        nb = in_blocks if cols_first else out_blocks
-        if nb & (nb - 1) or nb > 8 or n1 % nb:
-            return None
+        for nb in (in_blocks, out_blocks):
+            if nb & (nb - 1) or nb > 8 or n1 % nb:
+                return None
         return dict(guru2=True, precision=precision, kind=kind, cols=tuple(int(x) for x in cols), n2=n2,
                     planes=tuple(int(x) for x in planes), inb=(in_blocks, in_block_stride), outb=(out_blocks, out_block_stride))
 

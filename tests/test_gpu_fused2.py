@@ -19,7 +19,7 @@ def _opts(**kw):
 @pytest.fixture(autouse=True)
 def _restore():
     yield
-    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=126, fuse2_wait_ms=2000, fuse2_f32=1, wtile=1)
+    _opts(fuse2=1, fuse2_ring=0, fuse2_lag=0, fuse2_kinds=510, fuse2_wait_ms=2000, fuse2_f32=1, wtile=1)
 
 
 def _plans(shape, axes, fuse, ring=8, lag=4, kinds=15, dt='D'):
@@ -151,7 +151,7 @@ def test_shapes_without_a_paying_pair_keep_the_unfused_plans():
 @pytest.mark.parametrize('dt', ['D', 'F'])
 def test_fused_batched_2d_transform(dt):
     """fftn over the last two axes of a 3-D array (the leading stage of a slab-decomposed PFFT with
-    collapse=True): [rows] -> [columns] plane by plane in one launch."""
+    collapse=True): [columns] -> [rows] plane by plane in one launch (strided reads, whole rows written: round 6)."""
     from mpi4py_fft_amd import _lib
     shape = (24, 1024, 1024)
     rng = np.random.default_rng(8)
@@ -168,7 +168,7 @@ def test_fused_batched_2d_transform(dt):
         if shape[0] < 2 * ring:
             continue
         a1, f1, b1 = _plans(shape, (1, 2), 1, ring, lag, dt=dt)
-        assert 'fused pair (2-D planes' in _lib.engine().plan_describe(f1._plan)
+        assert 'fused pair (strided -> rows)' in _lib.engine().plan_describe(f1._plan)
         a1[...] = x
         for rep in range(3):
             got = np.asarray(f1.execute_scaled(a1, f1.output_array, 1.0))
@@ -480,7 +480,7 @@ def test_fused_batched_2d_transform_at_n_512():
     x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
     ref = np.fft.fftn(x, axes=(1, 2))
     a, f, b = _plans(shape, (1, 2), 1, 0, 0, 126)
-    assert 'fused pair (2-D planes: rows -> strided)' in _lib.engine().plan_describe(f._plan)
+    assert 'fused pair (strided -> rows)' in _lib.engine().plan_describe(f._plan)
     a[...] = x
     got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
     assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max()
@@ -526,7 +526,7 @@ def test_recovery_of_the_real_pairs_and_the_2d_pair():
     shape = (24, 1024, 1024)
     x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
     a, f, b = _plans(shape, (1, 2), 1, 0, 0, 126)
-    assert 'fused pair (2-D planes' in _lib.engine().plan_describe(f._plan)
+    assert 'fused pair (strided -> rows)' in _lib.engine().plan_describe(f._plan)
     a[...] = x
     _opts(fuse2_wait_ms=0)
     f.execute_scaled(a, f.output_array, 1.0)

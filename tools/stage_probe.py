@@ -3,7 +3,8 @@
 GPUs, timed on one GPU -- the stage plans exactly as pipeline.Pipeline builds them, on the line-aligned
 exchange buffers (pipeline._Aligned) and on the C-order ones of round 2.
 
-  python tools/stage_probe.py [c4|c5|c5odd|all]     (c5odd = a rank of the 513-wide grid column)
+  python tools/stage_probe.py [slab|c4|c5|c5odd|all]     (c5odd = a rank of the 513-wide grid column; slab = C3, C4 on 2 ranks
+  and C4 on the (8,1,1) grid: the two local stages as two launches against one fused launch, round 6)
 """
 import os, sys
 from types import SimpleNamespace as NS
@@ -74,6 +75,65 @@ def run_case(name, prec, real0, sh0, nh, sh1, sh2, p0, K0, widths, p1, K1):
     torch.cuda.empty_cache()
 
 
+def run_slab(name, prec, N0, N1, N2, p, Ks=(1, 2, 4)):
+    """The per-rank stages of a complex transform on a SLAB grid (first redistribution local): the two local stages as
+    two stand-alone plans on the shared buffer (round 5: rows natural, then strided into the packed send buffer), as
+    one fused launch (gfft_plan_create_guru2) whole and per chunk of planes, and the far stage on pitched slabs."""
+    isz = 2 * prec
+    eng = _lib.engine()
+    cdt = torch.complex64 if prec == 4 else torch.complex128
+    M0, N1b = p * N0, N1 // p
+    E = P._pitch(N1b * N2, isz)
+    nel = N0 * N1 * N2
+    a = torch.randn(nel, dtype=cdt, device='cuda')
+    mid = torch.empty(nel, dtype=cdt, device='cuda')
+    b = torch.empty(max(p * N0 * E, M0 * E), dtype=cdt, device='cuda')
+    c = torch.empty(nel, dtype=cdt, device='cuda')
+    alg2, alg1 = 4 * nel * isz, 2 * nel * isz
+
+    def line(tag, t, alg, extra=''):
+        print('%-12s %-34s %8.3f ms  %7.1f GB/s  %4.1f %%  %s' % (name, tag, t, alg / t / 1e6, alg / t / 1e6 / 80, extra), flush=True)
+    # two stand-alone launches: rows natural -> natural, strided natural -> packed [block][plane][rows of the block][cols]
+    for kind, tag in ((-1, 'fwd'), (+1, 'bwd')):
+        hr = eng.plan_create_guru(prec, kind, (N2, 1, 1), [(N0 * N1, N2, N2)], 1, 0, 1, 0)
+        if kind < 0:
+            hc = eng.plan_create_guru(prec, kind, (N1, N2, N2), [(N0, N1 * N2, N1b * N2), (N2, 1, 1)], 1, 0, p, N0 * N1b * N2)
+            t = timeit(lambda: (eng.execute_ptr(hr, a.data_ptr(), mid.data_ptr(), 1.0), eng.execute_ptr(hc, mid.data_ptr(), b.data_ptr(), 1.0)))
+        else:
+            hc = eng.plan_create_guru(prec, kind, (N1, N2, N2), [(N0, N1b * N2, N1 * N2), (N2, 1, 1)], p, N0 * N1b * N2, 1, 0)
+            t = timeit(lambda: (eng.execute_ptr(hc, b.data_ptr(), mid.data_ptr(), 1.0), eng.execute_ptr(hr, mid.data_ptr(), a.data_ptr(), 1.0)))
+        line('two launches %s' % tag, t, alg2)
+        eng.plan_destroy(hr)
+        eng.plan_destroy(hc)
+    for K in Ks:
+        if N0 % K:
+            continue
+        for fwd in (True, False):
+            st = P._PairStage((N0, N1, N2), p, K, E, fwd, prec)
+            if st.plan is None:
+                continue
+            pin, pout = (a, b) if fwd else (b, c)
+            t = timeit(lambda: [st.execute(eng, q, pin.data_ptr(), pout.data_ptr(), 1.0) for q in range(K)])
+            line('pair K=%d %s (%d launch%s per chunk)' % (K, 'fwd' if fwd else 'bwd', st.launches, '' if st.launches == 1 else 'es'), t, alg2)
+            st.destroy()
+    # (the forward pair the other way round: rows first, the strided pass storing into the blocks)
+    h = eng.plan_create_guru2(prec, -1, (N1, N2, N2), (N2, 1, 1), (N0, N1 * N2, E), False, 1, 0, p, N0 * E)
+    if h is not None:
+        line('pair K=1 fwd [rows -> strided] (%d)' % eng.plan_cost(h)[2], timeit(lambda: eng.execute_ptr(h, a.data_ptr(), b.data_ptr(), 1.0)), alg2)
+        eng.plan_destroy(h)
+    # the far stage: axis 0 over slabs E apart <-> the natural output
+    x = torch.randn(M0 * E, dtype=cdt, device='cuda')
+    y = torch.empty(M0 * N1b * N2, dtype=cdt, device='cuda')
+    for kind, tag in ((-1, 'fwd'), (+1, 'bwd')):
+        si, so = (E, N1b * N2) if kind < 0 else (N1b * N2, E)
+        h = eng.plan_create_guru(prec, kind, (M0, si, so), [(N1b, N2, N2), (N2, 1, 1)], 1, 0, 1, 0)
+        pin, pout = (x, y) if kind < 0 else (y, x)
+        line('far stage (axis 0) %s' % tag, timeit(lambda: eng.execute_ptr(h, pin.data_ptr(), pout.data_ptr(), 1.0)), alg1)
+        eng.plan_destroy(h)
+    del a, b, c, mid, x, y
+    torch.cuda.empty_cache()
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     print(torch.cuda.get_device_name(0))
@@ -83,6 +143,13 @@ def main():
         for K0 in (1, 2):
             run_case('C5@8e K0=%d' % K0, 4, True, (512, 1024, 2048), 1025, (512, 2048, 512), (2048, 512, 512), 2, K0, [513, 512], 4, 1)
         return
+    if what in ('slab', 'all'):
+        run_slab('C3 (2,1,1)', 8, 256, 512, 512, 2)
+        run_slab('C4@2', 8, 512, 1024, 1024, 2)
+        run_slab('C4 (8,1,1)', 8, 128, 1024, 1024, 8)
+        run_slab('c64 (8,1,1)', 4, 128, 1024, 1024, 8)
+        if what == 'slab':
+            return
     if what in ('c4', 'all'):
         run_case('C4@8', 8, False, (256, 512, 1024), 1024, (256, 1024, 512), (1024, 256, 512), 2, 4, None, 4, 4)
     if what in ('c5', 'all'):
