@@ -652,6 +652,9 @@ def run(args, guard, state):
         out_t = f.forward().tensor
         sync()
         rep['forward_rel_err'] = selftest.forward_gate(f, world, u0, out_t)
+        # (a warning field, not a gate: the contract is 2e-10; fp64 rounding over n^3 points allows 4 eps log2(n^3) ~ 2.7e-14 --
+        # a plan between the two has lost digits somewhere and is worth a look; tests/cases.py rounding_tol)
+        rep['forward_rel_err_rounding_ok'] = bool(rep['forward_rel_err'] <= 4 * 2.0 ** -52 * 3 * np.log2(n))
         if not rep['forward_rel_err'] <= 2e-10:
             return rep, 'forward differs from the DFT by definition: rel err %.3e > 2e-10' % rep['forward_rel_err']
         prints = world.allgather_obj(selftest.fingerprint(out_t))
@@ -663,6 +666,7 @@ def run(args, guard, state):
         rep['_print'] = prints
         f.forward.input_array.tensor.copy_(u0)
         rep['round_trip_rel_err'] = round_trip_error(f, u0)
+        rep['round_trip_rel_err_rounding_ok'] = bool(rep['round_trip_rel_err'] <= 4 * 2.0 ** -52 * 3 * np.log2(n))
         if not rep['round_trip_rel_err'] <= 1e-10:
             return rep, 'round-trip rel err %.3e exceeds 1e-10' % rep['round_trip_rel_err']
         rep['gate_seconds'] = round(time.perf_counter() - t0, 3)
@@ -689,8 +693,12 @@ def run(args, guard, state):
     if hip:
         plans = list(fft._fused_plans) if fft._fused_plans else \
             [x.fwd for x in fft.xfftn] + [x.bck for x in fft.xfftn]
-    for p in plans:
-        for name, nbytes, ms, launches in p.profile():
+    profiles = [p.profile() for p in plans]
+    if hip:       # (slab grids: the two local stages run as one guru2 plan per direction, PFFT._fuse_pairs)
+        eng = _lib.engine()
+        profiles += [eng.plan_profile(h, eng.plan_cost(h)[2]) for h in getattr(fft, '_pair_plans', [])]
+    for prof in profiles:
+        for name, nbytes, ms, launches in prof:
             if launches:
                 k = kern.setdefault(name, dict(bytes=nbytes, ms=0.0, launches=0))
                 k['ms'] += ms
@@ -841,24 +849,54 @@ def run(args, guard, state):
         guard.phase = name
         test_hook(guard, rank)
 
+    XGMI_LINK_GBS = 153.0                    # per link and direction (BASELINE.md section 3; 7 links per GPU)
+    s_local = u0.numel() * 16                # bytes of one rank's local array
+
     def stages(tr):
+        """[[label, ms]] of one synchronised, stage-by-stage execution (max over ranks).  Serial stages carry their
+        SURVEY 8d fraction -- one read + one write of the local array per transformed axis, / time / 8 TB/s --, exchanges
+        their outgoing rate per GPU and `xgmi_frac` = that rate / (153 GB/s x (p - 1) links): what a point-to-point
+        fabric can give an all-to-all inside a sub-communicator of p ranks."""
         st = tr.stage_times()
         allst = world.allgather_obj([b for _, b in st])
         out_ = []
         for i in range(len(st)):
             label, ms = st[i][0], max(r[i] for r in allst) * 1e3
-            mb = re.search(r'([0-9.]+) MB out', label)
+            mb = re.search(r'p=(\d+) ([0-9.]+) MB out', label)
             if mb and ms > 0:        # per-GPU outgoing wire rate of this exchange
-                label += ' = %.1f GB/s per GPU' % (float(mb.group(1)) / ms)
+                rate, p = float(mb.group(2)) / ms, int(mb.group(1))
+                label += ' = %.1f GB/s per GPU, xgmi_frac %.3f' % (rate, rate / (XGMI_LINK_GBS * max(1, p - 1)))
+            ax = re.match(r'fft axes=\(([^)]*)\)', label)
+            if ax and ms > 0:
+                naxes = len([a for a in ax.group(1).split(',') if a.strip()])
+                label += ' = %.3f of 8 TB/s' % (2.0 * s_local * naxes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
             out_.append([label, round(ms, 3)])
         return out_
+
+    def split_ms(st):
+        """(compute, wire) milliseconds of a stage breakdown: serial transforms against everything a redistribution
+        costs (pack, exchange, unpack)"""
+        comp = sum(ms for label, ms in st if label.startswith('fft'))
+        return comp, sum(ms for label, ms in st if not label.startswith('fft'))
 
     try:
         # where a step spends its time, stage by stage (synchronised, max over ranks)
         phase('stage breakdown')
         st = {'forward': stages(fft.forward), 'backward': stages(fft.backward)}
+        cf, wf = split_ms(st['forward'])
+        cb, wb = split_ms(st['backward'])
+        staged_split = dict(compute_ms=round(cf + cb, 3), wire_ms=round(wf + wb, 3))
+
+        def overlap(step_ms):
+            """How much of the shorter of (compute, wire) a plan hides behind the longer one: (compute + wire - step) /
+            min(compute, wire), both taken from the stage-by-stage run of the headline plan -- 0 = strictly sequential,
+            1 = the step costs what the longer of the two costs."""
+            c, w = staged_split['compute_ms'], staged_split['wire_ms']
+            eff = (c + w - step_ms) / min(c, w) if min(c, w) > 0 else None
+            return dict(staged_split, step_ms=round(step_ms, 3), overlap_eff=None if eff is None else round(eff, 3))
         if rank == 0:
             out['stages_ms'] = st
+            out['overlap'] = overlap(out['ms_per_step'])
 
         # Alternatives to the plain route, each the product's own plan of the same transform, each
         # checked by the round trip and timed with the same K steps; the headline becomes the
@@ -912,6 +950,7 @@ def run(args, guard, state):
                 el2 = timed_steps(world, sync, tuned_step, args.steps)
                 info['ms_per_step'] = round(el2 / args.steps * 1e3, 3)
                 info['value'] = round(flops / (el2 / args.steps) / 1e9, 1)
+                info['overlap'] = overlap(info['ms_per_step'])
                 if rank == 0 and el2 < best['elapsed']:
                     if 'plain_route' not in out:
                         out['plain_route'] = {'ms_per_step': out['ms_per_step'], 'value': out['value'],
@@ -921,6 +960,7 @@ def run(args, guard, state):
                     out.update(headline(tuned, el2, gate2))
                     out.update(keep)
                     out['config']['plan'] = label
+                    out['overlap'] = info['overlap']
                     if tuned.pipeline is not None:
                         out['config']['pipeline'] = info['pipeline']
                 best['elapsed'] = min(best['elapsed'], el2)

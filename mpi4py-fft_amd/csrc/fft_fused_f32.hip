@@ -25,9 +25,9 @@ struct Fused1024F32 {
   typedef PassCfg<float, 1024, 16, 16, false, false, 1 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> RowsToRing;
   typedef PassCfg<float, 1024, 32, 32, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> ColsFromRing;
   typedef PassCfg<float, 1024, 32, 32, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirst;
-  // the strided side of the slab pairs: the array side is an all-to-all buffer of equal blocks (FLAGS 32768, FUSED_PLANES_2D_B / _CR_B)
+  // the strided side of the slab pairs: the array side is an all-to-all buffer of equal blocks (FLAGS 32768 input / 65536 output, FUSED_PLANES_2D_B / _CR_B)
   typedef PassCfg<float, 1024, 32, 32, true, true, 1 | 8 | 2048 | 8192 | 32768, MODE_C2C, false, 16, 16, 4> ColsToRingB;
-  typedef PassCfg<float, 1024, 32, 32, true, true, 2 | 8 | 4096 | 8192 | 32768, MODE_C2C, false, 16, 16, 4> ColsFromRingB;
+  typedef PassCfg<float, 1024, 32, 32, true, true, 2 | 8 | 4096 | 8192 | 65536, MODE_C2C, false, 16, 16, 4> ColsFromRingB;
 };
 
 bool fused2_supported_f32(int kind, int n_a, int n_b) {

@@ -66,9 +66,9 @@ struct Fused1024R32 {
   typedef PassCfg<double, 1024, 32, 16, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 32, 32> FourStepFirst;
   typedef PassCfg<double, 1024, 32, 16, true, true, 1 | 2048 | 8192, MODE_C2C, true, 32, 32> FourStepFirstNat;
   typedef PassCfg<double, 1024, 32, 16, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 32, 32> RowsFromRingT;
-  // the strided side of the slab pairs: the array side is an all-to-all buffer of equal blocks (FLAGS 32768, FUSED_PLANES_2D_B / _CR_B)
+  // the strided side of the slab pairs: the array side is an all-to-all buffer of equal blocks (FLAGS 32768 input / 65536 output, FUSED_PLANES_2D_B / _CR_B)
   typedef PassCfg<double, 1024, 32, 16, true, true, 1 | 8 | 2048 | 8192 | 32768, MODE_C2C, false, 32, 32> ColsToRingB;
-  typedef PassCfg<double, 1024, 32, 16, true, true, 2 | 8 | 4096 | 8192 | 32768, MODE_C2C, false, 32, 32> ColsFromRingB;
+  typedef PassCfg<double, 1024, 32, 16, true, true, 2 | 8 | 4096 | 8192 | 65536, MODE_C2C, false, 32, 32> ColsFromRingB;
 };
 
 // n = 512: 32 values per thread, radices 32 x 16, 256-thread workgroups on 16 lines -- 128 KiB tiles, TWO workgroups per CU
@@ -83,7 +83,7 @@ struct Fused512R32 {
   typedef PassCfg<double, 512, 32, 16, true, true, 1 | 2048 | 8192, MODE_C2C, true, 32, 16> FourStepFirstNat;
   typedef PassCfg<double, 512, 32, 16, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 32, 16> RowsFromRingT;
   typedef PassCfg<double, 512, 32, 16, true, true, 1 | 8 | 2048 | 8192 | 32768, MODE_C2C, false, 32, 16> ColsToRingB;
-  typedef PassCfg<double, 512, 32, 16, true, true, 2 | 8 | 4096 | 8192 | 32768, MODE_C2C, false, 32, 16> ColsFromRingB;
+  typedef PassCfg<double, 512, 32, 16, true, true, 2 | 8 | 4096 | 8192 | 65536, MODE_C2C, false, 32, 16> ColsFromRingB;
 };
 
 // variant: 1 = the default, 32 values per thread / one exchange (Fused1024R32); 3 = 16 values per thread / two exchanges

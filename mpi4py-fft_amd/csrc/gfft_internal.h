@@ -180,7 +180,7 @@ enum FusedKind { FUSED_ROWS_COLS = 0, FUSED_COLS_ROWS = 1, FUSED_FOURSTEP = 2, F
                  FUSED_R2C_PLANES = 5, FUSED_COLS_C2R = 6,
                  // the two LOCAL stages of a slab-decomposed transform, plane by plane, with the all-to-all buffer addressed by
                  // the pair itself (gfft_plan_create_guru2): [rows -> strided, output in blocks] forward, [strided, input in
-                 // blocks -> rows] backward -- the kernels of 3 / 1 with the block jump of the transformed axis kept (FLAGS 32768)
+                 // blocks -> rows] backward -- the kernels of 3 / 1 with the block jump of the transformed axis kept (FLAGS 65536 / 32768)
                  FUSED_PLANES_2D_B = 7, FUSED_PLANES_CR_B = 8 };
 // variant: 1 = the default kernels (32 values per thread, one exchange, one 512-thread workgroup per CU); 3 = the round-3
 // kernels (16 values per thread, two exchanges, 1024 threads); 2 / 4 = (make VARIANTS=1) 8 lines per tile, two workgroups per CU

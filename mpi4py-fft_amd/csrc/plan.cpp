@@ -89,6 +89,10 @@ struct Options {
   int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
   int64_t fused3_min_bytes = 32 << 20;
+  // TEST HOOK (tests/test_gpu_rounding_guard.py): twiddle tables uploaded while debug_tw_exp > 0 carry ONE wrong entry --
+  // the real part of entry debug_tw_index (mod n) is off by 10^-debug_tw_exp -- under their own cache key, so that plans made
+  // before / after are untouched.  What the rounding-level guards of the test suite must catch; never set by the product.
+  int debug_tw_index = 1, debug_tw_exp = 0;
   Options() {
     if (const char *s = getenv("GFFT_GRID_CAP")) grid_cap = atoi(s);
     if (const char *s = getenv("GFFT_VARIANT_ROWS")) variant_rows = atoi(s);
@@ -116,12 +120,12 @@ Options &opts() {
 // (per device: the key's precision slot also carries the ordinal of the device the table lives on)
 int dev_prec(int precision) { return precision + (current_device() << 8); }
 std::mutex g_tw_mutex;
-std::map<std::pair<int64_t, int>, void *> g_tw_cache;       // (n, precision) -> W_n^k, k<n
+std::map<std::tuple<int64_t, int, int>, void *> g_tw_cache;       // (n, precision + device, test-hook signature) -> W_n^k, k<n
 struct BigTw { void *hi, *lo; int L; };
 std::map<std::pair<int64_t, int>, BigTw> g_bigtw_cache;     // (big_n, precision)
 
 // exp(-2 pi i k / n) for k in [k0, k0 + count*step) step `step`, in long double, stored as `precision`
-int upload_twiddles(int64_t n, int64_t step, int64_t count, int precision, void **out) {
+int upload_twiddles(int64_t n, int64_t step, int64_t count, int precision, void **out, int64_t wrong_index = -1, double wrong_by = 0) {
   const long double w = -2.0L * 3.14159265358979323846264338327950288L / (long double)n;
   std::vector<unsigned char> host((size_t)count * 2 * precision);
   for (int64_t j = 0; j < count; ++j) {
@@ -137,6 +141,7 @@ int upload_twiddles(int64_t n, int64_t step, int64_t count, int precision, void 
       else if (4 * k == 3 * n) { c = 0; s = 1; }
       else if (k == 0) { c = 1; s = 0; }
     }
+    if (j == wrong_index) c += (long double)wrong_by;          // (test hook, Options::debug_tw_exp)
     if (precision == 8) {
       double *p = reinterpret_cast<double *>(host.data()) + 2 * j;
       p[0] = (double)c;
@@ -156,11 +161,13 @@ int upload_twiddles(int64_t n, int64_t step, int64_t count, int precision, void 
 
 int get_twiddles(int64_t n, int precision, const void **out) {
   std::lock_guard<std::mutex> lock(g_tw_mutex);
-  auto key = std::make_pair(n, dev_prec(precision));
+  const int e = opts().debug_tw_exp;
+  const int64_t wrong = e > 0 ? ((int64_t)opts().debug_tw_index % n + n) % n : -1;
+  auto key = std::make_tuple(n, dev_prec(precision), e > 0 ? (int)(wrong * 64 + (e & 63)) + 1 : 0);
   auto it = g_tw_cache.find(key);
   if (it == g_tw_cache.end()) {
     void *d = nullptr;
-    int rc = upload_twiddles(n, 1, n, precision, &d);
+    int rc = upload_twiddles(n, 1, n, precision, &d, wrong, e > 0 ? std::pow(10.0, -e) : 0.0);
     if (rc) return rc;
     it = g_tw_cache.emplace(key, d).first;
   }
@@ -1817,6 +1824,8 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "debug_tile_stride")) opts().debug_tile_stride = value;
   else if (!strcmp(key, "ws_skew_kib")) opts().ws_skew_kib = value < 0 ? 0 : value;
   else if (!strcmp(key, "profile")) opts().profile = value;
+  else if (!strcmp(key, "debug_tw_index")) opts().debug_tw_index = value;
+  else if (!strcmp(key, "debug_tw_exp")) opts().debug_tw_exp = value;
   else if (!strcmp(key, "xcd_swizzle")) opts().xcd_swizzle = value;
   else if (!strcmp(key, "fused3_min_mib")) opts().fused3_min_bytes = (int64_t)value << 20;
   else return fail(GFFT_ERR_INVALID, std::string("unknown option ") + key);

@@ -53,7 +53,15 @@ def test_bench_self_launch_two_ranks_gloo():
     assert [e['ranks'] for e in out['config']['exchange']] == [2]
     assert out['config']['exchange'][0]['route'] == 'direct'
     labels = [l for l, _ in out['stages_ms']['forward']]
-    assert sum('exchange' in l for l in labels) == 1 and sum(l.startswith('fft') for l in labels) == 3
+    # (slab grid: the two local stages run as one launch, then the exchange, then the far stage)
+    assert sum('exchange' in l for l in labels) == 1 and sum(l.startswith('fft') for l in labels) == 2
+    assert 'one launch' in labels[0] and 'of 8 TB/s' in labels[0]
+    # the self-explaining keys of a multi-GPU run: per-exchange fabric fraction, compute / wire split, overlap
+    assert all('xgmi_frac' in l for l in labels if 'exchange' in l)
+    ov = out['overlap']
+    assert ov['compute_ms'] > 0 and ov['wire_ms'] > 0 and ov['step_ms'] > 0 and ov['overlap_eff'] is not None
+    assert out['config']['gates']['forward_rel_err_rounding_ok'] is True
+    assert all('overlap' in a for a in out.get('alternatives', []) if 'ms_per_step' in a)
 
 
 def test_bench_self_launch_four_ranks_measures_routes_and_slab():

@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 from tests import cases
 from oracle import pfft_oracle as O
 
-FP32_FWD_TOL = 2e-4     # forward vs oracle: max|d| <= tol * max|ref|   (cases.tol_for)
+FP32_FWD_TOL = 2e-4     # forward vs oracle: max|d| <= tol * max|ref|   (cases.tol_for): the contract ...
 FP32_RT_TOL = 1e-4      # round trip ||bwd(fwd(u)) - u|| / ||u||
+FP32_LINE_GUARD = cases.rounding_tol('f', 2048)          # ... and what a 2048-point fp32 line may lose to rounding (5.2e-6)
 
 
 @pytest.mark.parametrize('P', [1, 4, 8])
@@ -159,7 +160,7 @@ def test_c5_local_piece_r2c_rows_2048_full_size():
         x = u0[i, j].cpu().numpy()
         got = uh.tensor[i, j].cpu().numpy()
         ref = dft(x, -2, 1025, 'D') / 2048
-        assert np.abs(got - ref).max() <= FP32_FWD_TOL * np.abs(ref).max(), (i, j, np.abs(got - ref).max() / np.abs(ref).max())
+        assert np.abs(got - ref).max() <= min(FP32_FWD_TOL, FP32_LINE_GUARD) * np.abs(ref).max(), (i, j, np.abs(got - ref).max() / np.abs(ref).max())
     assert torch.equal(u.tensor, u0)           # the input is preserved
     f.backward()
     d = sum(float(((u.tensor[i:i + 64] - u0[i:i + 64]).to(torch.float64) ** 2).sum().item()) for i in range(0, 512, 64))
@@ -193,7 +194,7 @@ def test_c5_local_piece_c2c_strided_2048_full_size(shape, axis):
         x = u0[sl].cpu().numpy()
         got = uh.tensor[sl].cpu().numpy()
         ref = dft(x, -1, 2048, 'D') / 2048
-        assert np.abs(got - ref).max() <= FP32_FWD_TOL * np.abs(ref).max(), (sl, np.abs(got - ref).max() / np.abs(ref).max())
+        assert np.abs(got - ref).max() <= min(FP32_FWD_TOL, FP32_LINE_GUARD) * np.abs(ref).max(), (sl, np.abs(got - ref).max() / np.abs(ref).max())
     f.backward()
     d = sum(float((torch.view_as_real(u.tensor[i:i + 64] - u0[i:i + 64]).to(torch.float64) ** 2).sum().item())
             for i in range(0, shape[0], 64))

@@ -7,6 +7,8 @@ raced (a tile read before its plane was complete, a slot overwritten too early) 
 import numpy as np
 import pytest
 
+from tests import cases
+
 pytestmark = pytest.mark.gpu
 
 
@@ -48,7 +50,7 @@ def test_fused_3d_schedule_matches_the_unfused_one(shape, dt, wtile):
     want = np.asarray(f0.execute_scaled(a0, f0.output_array, 1.0)).copy()
     wantb = np.asarray(b0.execute_scaled(f0.output_array, b0.output_array, 1.0 / x.size)).copy()
     ref = np.fft.fftn(x.astype('D'))
-    assert np.abs(want - ref).max() <= (2e-10 if dt == 'D' else 2e-4) * np.abs(ref).max()
+    assert np.abs(want - ref).max() <= cases.tol_for(dt, ref.size) * np.abs(ref).max()
     for f in (f0, b0):
         f.destroy()
     # kinds 15: both directions run axis 1, then the fused pair [axis 0 -> rows]; kinds 1: only the mirror pair
@@ -90,7 +92,7 @@ def test_fused_3d_pair_on_unequal_width_stage_lengths(n):
     a0[...] = x
     want = np.asarray(f0.execute_scaled(a0, f0.output_array, 1.0)).copy()
     ref = np.fft.fftn(x)
-    assert np.abs(want - ref).max() <= 2e-10 * np.abs(ref).max()
+    assert np.abs(want - ref).max() <= cases.tol_for('D', ref.size) * np.abs(ref).max()
     f0.destroy()
     b0.destroy()
     for ring, lag in ((8, 4), (12, 6), (5, 2)):
@@ -120,7 +122,7 @@ def test_fused_four_step_matches_the_two_launch_form(shape, dt):
     a0[...] = x
     want = np.asarray(f0.execute_scaled(a0, f0.output_array, 1.0)).copy()
     ref = np.fft.fft(x[:2].astype('D'), axis=1)
-    assert np.abs(want[:2] - ref).max() <= (2e-10 if dt == 'D' else 2e-4) * np.abs(ref).max()
+    assert np.abs(want[:2] - ref).max() <= cases.tol_for(dt, ref.size) * np.abs(ref).max()
     f0.destroy()
     b0.destroy()
     # kinds 15: [strided + transposing store] -> [strided]; 31: [strided] -> [rows + transposing store] (the default)
@@ -161,7 +163,7 @@ def test_fused_batched_2d_transform(dt):
     a0[...] = x
     want = np.asarray(f0.execute_scaled(a0, f0.output_array, 1.0)).copy()
     ref = np.fft.fftn(x[:3].astype('D'), axes=(1, 2))
-    assert np.abs(want[:3] - ref).max() <= (2e-10 if dt == 'D' else 2e-4) * np.abs(ref).max()
+    assert np.abs(want[:3] - ref).max() <= cases.tol_for(dt, ref.size) * np.abs(ref).max()
     f0.destroy()
     b0.destroy()
     for ring, lag in ((8, 4), (4, 2), (12, 6)):
@@ -246,7 +248,7 @@ def test_a_fused_launch_that_gives_up_a_wait_is_an_error_and_the_plan_recovers(s
     assert ('tile-major workspace' in _lib.engine().plan_describe(f._plan)) == (shape == (1024, 64, 1024))
     a[...] = x
     good = np.asarray(f.execute_scaled(a, f.output_array, 1.0)).copy()       # the healthy launch first
-    assert np.abs(good - ref).max() <= 2e-10 * np.abs(ref).max()
+    assert np.abs(good - ref).max() <= cases.tol_for('D', ref.size) * np.abs(ref).max()
     _opts(fuse2_wait_ms=0)                         # every wait gives up at once
     f.execute_scaled(a, f.output_array, 1.0)       # enqueues; the launch voids itself on the device
     torch.cuda.synchronize()
@@ -258,7 +260,7 @@ def test_a_fused_launch_that_gives_up_a_wait_is_an_error_and_the_plan_recovers(s
     assert 'fused pair' not in desc and 'two stand-alone passes' in desc, desc
     for rep in range(2):
         got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
-        assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max()
+        assert np.abs(got - ref).max() <= cases.tol_for('D', ref.size) * np.abs(ref).max()
     # the process, the context and the other plans are alive: the backward plan still runs fused
     assert 'fused pair' in _lib.engine().plan_describe(b._plan)
     back = np.asarray(b.execute_scaled(f.output_array, b.output_array, 1.0 / np.prod([shape[i] for i in axes])))
@@ -330,7 +332,7 @@ def test_the_round3_kernel_set_is_still_selectable_and_agrees():
         assert 'fused pair (strided -> rows)' in _lib.engine().plan_describe(f._plan)
         a[...] = x
         got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
-        assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max()
+        assert np.abs(got - ref).max() <= cases.tol_for('D', ref.size) * np.abs(ref).max()
         back = np.asarray(b.execute_scaled(f.output_array, b.output_array, 1.0 / x.size))
         assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
         outs.append(got.copy())
@@ -366,7 +368,7 @@ def test_fused_pairs_of_real_transforms(shape):
         a[...] = x
         for rep in range(3):
             got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
-            assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max(), (fuse, rep)
+            assert np.abs(got - ref).max() <= cases.tol_for('D', ref.size) * np.abs(ref).max(), (fuse, rep)
             if rep == 0:
                 first = got.copy()
             assert np.array_equal(got, first), ('forward not reproducible', fuse, rep)
@@ -400,12 +402,12 @@ def test_fused_pair_of_the_complex64_schedule(shape):
         a[...] = x
         for rep in range(3):
             got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
-            assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()
+            assert np.abs(got - ref).max() <= cases.tol_for('F', ref.size) * np.abs(ref).max()
             if rep == 0:
                 first = got.copy()
             assert np.array_equal(got, first)
         back = np.asarray(b.execute_scaled(f.output_array, b.output_array, 1.0 / x.size))
-        assert np.abs(back - x).max() <= 1e-4 * np.abs(x).max()
+        assert np.abs(back - x).max() <= 2 * cases.tol_for('F', x.size) * np.abs(x).max()
         res[fuse] = first
         f.destroy()
         b.destroy()
@@ -428,7 +430,7 @@ def test_fused_pair_at_n_512_and_where_it_stays_off():
         a[...] = x
         for rep in range(3):
             got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
-            assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max()
+            assert np.abs(got - ref).max() <= cases.tol_for('D', ref.size) * np.abs(ref).max()
             if rep == 0:
                 first = got.copy()
             assert np.array_equal(got, first)
@@ -459,11 +461,11 @@ def test_fused_pairs_of_real_fp32_transforms(shape):
             assert ('fused pair (strided -> c2r rows)' in db) == (shape[0] == 1024), db
         a[...] = x
         got = np.asarray(f.execute_scaled(a, f.output_array, 1.0)).copy()
-        assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max()
+        assert np.abs(got - ref).max() <= cases.tol_for('F', ref.size) * np.abs(ref).max()
         assert np.array_equal(np.asarray(f.execute_scaled(a, f.output_array, 1.0)), got)
         c[...] = ref.astype('F')
         back = np.asarray(b.execute_scaled(c, b.output_array, 1.0 / x.size)).copy()
-        assert np.abs(back - x).max() <= 1e-4 * np.abs(x).max()
+        assert np.abs(back - x).max() <= 2 * cases.tol_for('F', x.size) * np.abs(x).max()
         res[fuse] = (got, back)
         f.destroy()
         b.destroy()
@@ -483,7 +485,7 @@ def test_fused_batched_2d_transform_at_n_512():
     assert 'fused pair (strided -> rows)' in _lib.engine().plan_describe(f._plan)
     a[...] = x
     got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
-    assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max()
+    assert np.abs(got - ref).max() <= cases.tol_for('D', ref.size) * np.abs(ref).max()
     back = np.asarray(b.execute_scaled(f.output_array, b.output_array, 1.0 / (512 * 512)))
     assert np.abs(back - x).max() <= 1e-12 * np.abs(x).max()
     f.destroy()
@@ -521,7 +523,7 @@ def test_recovery_of_the_real_pairs_and_the_2d_pair():
         if not forward:
             a[...] = ref                      # (multi-axis c2r preserves its input; refreshed all the same)
         got = np.asarray(p.execute_scaled(a, p.output_array, scale))
-        assert np.abs(got - want).max() <= 2e-10 * np.abs(want).max()
+        assert np.abs(got - want).max() <= cases.tol_for('D', want.size) * np.abs(want).max()
         p.destroy()
     shape = (24, 1024, 1024)
     x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
@@ -536,6 +538,6 @@ def test_recovery_of_the_real_pairs_and_the_2d_pair():
         _lib.check_async()
     got = np.asarray(f.execute_scaled(a, f.output_array, 1.0))
     ref = np.fft.fftn(x, axes=(1, 2))
-    assert np.abs(got - ref).max() <= 2e-10 * np.abs(ref).max()
+    assert np.abs(got - ref).max() <= cases.tol_for('D', ref.size) * np.abs(ref).max()
     f.destroy()
     b.destroy()

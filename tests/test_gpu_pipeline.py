@@ -115,7 +115,7 @@ def test_pipelined_transform_is_bit_identical_to_the_staged_one(P, shape, kw, dt
             assert all(e['layout'] == 'aligned' for e in info), info      # (pipeline._Aligned)
         assert np.array_equal(a, b) and np.array_equal(a, c), (P, shape, kw, r)
         assert np.array_equal(ab, bb)
-        tol = cases.tol_for(dt)
+        tol = cases.tol_for(dt, G.size)
         assert np.abs(a - want[r]).max() <= tol * np.abs(want[r]).max()
         assert np.allclose(bn * G.size, bb, rtol=1e-5 if dt == 'F' else 1e-12, atol=0)
     # the golden fixture of the reference itself through the pipelined path
@@ -286,7 +286,7 @@ def test_pipelined_r2c_transform(P, shape, dt, exchange, monkeypatch):
             assert any(e['route'] == 'relay' for e in info), info
         assert np.array_equal(a, b) and np.array_equal(a, c), (P, shape, dt, r)
         assert np.array_equal(ab, bb) and np.array_equal(ab, bc)
-        assert np.abs(a - want[r]).max() <= cases.tol_for(dt) * np.abs(want[r]).max()
+        assert np.abs(a - want[r]).max() <= cases.tol_for(dt, G.size) * np.abs(want[r]).max()
 
 
 @pytest.mark.parametrize('P,shape,pad', [
@@ -348,7 +348,7 @@ def test_pipelined_padded_transform(P, shape, pad, dt, monkeypatch):
         # whose multiply-adds the compiler may contract differently -- last-bit agreement)
         eps = 1e-13 if dt in 'dD' else 1e-5
         assert np.abs(k - a).max() <= eps * np.abs(a).max() and np.abs(kb - ab).max() <= eps * np.abs(ab).max()
-        assert np.abs(a - want[r]).max() <= cases.tol_for(dt) * np.abs(want[r]).max()
+        assert np.abs(a - want[r]).max() <= cases.tol_for(dt, G.size) * np.abs(want[r]).max()
 
 
 @pytest.mark.parametrize('P,shape,kw', [
@@ -400,7 +400,7 @@ def test_pipelined_collapsed_transform(P, shape, kw, dt, monkeypatch):
             assert len(axes) == 2 and tuple(axes[1]) == (1, 2), axes
         assert np.array_equal(a, b) and np.array_equal(a, c) and np.array_equal(a, b2), (P, shape, kw, dt, r)
         assert np.array_equal(ab, bb) and np.array_equal(ab, bc)
-        assert np.abs(a - want[r]).max() <= cases.tol_for(dt) * np.abs(want[r]).max()
+        assert np.abs(a - want[r]).max() <= cases.tol_for(dt, G.size) * np.abs(want[r]).max()
 
 
 def test_late_messages_are_waited_for():

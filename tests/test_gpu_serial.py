@@ -30,9 +30,15 @@ def _check(shape, axes, dt, seed=0):
     rt = np.linalg.norm(A2 - A) / np.linalg.norm(A)
     assert A2.shape == A.shape and A2.dtype == A.dtype
     assert rt <= (1e-10 if dt in 'dD' else 1e-4), (shape, axes, dt, 'round trip', rt)
-    # tighter than the contract: fp64 should be at rounding level
+    # tighter than the contract: both precisions at rounding level (tests/cases.py rounding_tol)
     if dt in 'dD':
         assert err < 1e-13 and rt < 1e-13, (shape, axes, err, rt)
+    from tests import cases
+    npts = int(np.prod([shape[a] for a in (axes if np.ndim(axes) else [axes])])) if axes is not None else int(np.prod(shape))
+    cases._note('fwd', dt, npts, err)
+    cases._note('rt', dt, npts, rt)
+    guard = cases.rounding_tol(dt, npts)
+    assert err <= guard and rt <= guard, (shape, axes, dt, 'ROUNDING-LEVEL guard', err, rt, guard)
     fft.destroy()
 
 
