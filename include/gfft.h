@@ -73,13 +73,14 @@ int gfft_device_name(int device, char *buf, size_t len);
 /* tunables consulted when a plan is created: "grid_cap", "variant_rows", "variant_cols",
  * "force_generic", "fused3", "profile" (also readable from the environment as GFFT_<UPPERCASE NAME>);
  * "fuse2" (1: pass pairs as one persistent launch through the Infinity Cache where a pair exists and pays,
- * 0: stand-alone passes; 3: the round-3 kernel set, for A/B), with "fuse2_ring" / "fuse2_lag" (slots of the hand-off ring /
+ * 0: stand-alone passes), with "fuse2_ring" / "fuse2_lag" (slots of the hand-off ring /
  * planes the producer runs ahead; 0 = auto: about 96 MiB of lead and twice that of ring -- 12 / 6 planes of 16 MiB, 24 / 12 of
  * 8 MiB, 48 / 24 of 4 MiB --, launches with too few planes for that stay unfused), "fuse2_kinds" (bit mask of pair kinds:
  * 2 strided->rows, 4 / 16 four-step, 8 batched 2-D, 32 r2c rows->strided, 64 strided->c2r rows), "fuse2_f32" (1: complex64
  * pairs, 2: real fp32 pairs too), "fuse2_n512" (the n = 512 pairs), "fuse2_wait_ms" (wall-clock limit of a wait inside a fused
- * launch before the launch voids itself, gfft_async_error below; default 2000) and the A/B switches "fuse2_wlayout",
- * "fuse2_group", "fuse2_defer" (DESIGN.md sections 4.7, 4.8); GFFT_FUSE2_DEBUG=1 prints a fused launch's counters */
+ * launch before the launch voids itself, gfft_async_error below; default 2000); GFFT_FUSE2_DEBUG=1 prints a fused
+ * launch's counters.  ("debug_tw_index" / "debug_tw_exp": TEST HOOK -- twiddle tables uploaded while debug_tw_exp > 0
+ * carry one entry off by 10^-debug_tw_exp: what the rounding-level guards of tests/ must catch.) */
 int gfft_set_option(const char *key, int value);
 
 /* ---- serial multi-axis transform plan ------------------------------------------------
@@ -102,12 +103,6 @@ int gfft_plan_create_r2r(gfft_plan *plan, int ndims, const int64_t *sizes, int n
  * on it when it reads a caller's array in place (Transform.__call__). */
 int gfft_execute(gfft_plan plan, const void *d_in, void *d_out, double scale, void *stream);
 int gfft_plan_destroy(gfft_plan plan);
-/* Where inside the shared per-stream workspace this plan's regions start (KiB; < 0: the library default).  Results do not depend
- * on it; the time of the strided passes does, by a few per cent, through how the workspace and the caller's arrays share the memory
- * channels -- FFTW_MEASURE territory (the reference plans with FFTW_MEASURE by default, libfft.py:52): with GFFT_TUNE=measure the
- * Python host times a few offsets on the planned arrays when it builds a large one-rank plan (mpifft.PFFT._tune_placement; off by
- * default: over three boxes the effect did not stand out from process-to-process placement, profiles/r05_tune_ab.txt). */
-int gfft_plan_set_ws_skew(gfft_plan plan, int kib);
 int gfft_scratch_release(void);           /* frees the shared per-stream workspaces, pinned ones included */
 /* Errors of launches that have already returned GFFT_OK (execution is asynchronous): a fused pass-pair launch
  * whose workgroups waited longer than option "fuse2_wait_ms" (default 2000) for one another -- a device shared

@@ -87,7 +87,6 @@ def _declare(lib):
         'gfft_probe_copy': (c.c_int, [vp, vp, c.c_size_t, vp]),
         'gfft_async_error': (c.c_int, []),
         'gfft_plan_status': (c.c_int, [vp]),
-        'gfft_plan_set_ws_skew': (c.c_int, [vp, c.c_int]),
         'gfft_rccl_load': (c.c_int, [c.c_char_p]),
         'gfft_rccl_info': (c.c_int, [c.c_char_p, c.c_size_t]),
         'gfft_exchange_last_error': (c.c_char_p, []),
@@ -234,9 +233,6 @@ class HipEngine:
         """gfft_execute on raw device addresses (element 0 of the plan's input / output)."""
         check(lib().gfft_execute(h, ctypes.c_void_p(ptr_in), ctypes.c_void_p(ptr_out), float(scale),
                                  current_stream() if stream is None else stream))
-
-    def plan_set_ws_skew(self, h, kib):
-        check(lib().gfft_plan_set_ws_skew(h, int(kib)))
 
     def plan_status(self, h):
         """gfft_plan_status: raises if a launch of THIS plan voided itself since anybody last looked (call after a sync)."""

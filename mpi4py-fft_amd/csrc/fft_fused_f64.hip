@@ -12,17 +12,6 @@ namespace gfft {
 //                                  real   N     R   T   COLS   SPLIT FLAGS                 MODE      BIGTW  radices
 // (FLAGS 1 / 2: the streams that are NOT the hand-off -- A's loads, B's stores -- are non-temporal, so that
 // they do not push the ring out of the Infinity Cache: 1024^3 per step 37.35 -> 36.26 ms, clean A/B)
-template <> struct FusedCfgs<double, 1024> {
-  typedef PassCfg<double, 1024, 16, 16, false, true, 1 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> RowsToRing;
-  typedef PassCfg<double, 1024, 16, 16, false, true, 2 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> RowsFromRing;
-  typedef PassCfg<double, 1024, 16, 16, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 16, 16, 4> ColsToRing;
-  typedef PassCfg<double, 1024, 16, 16, true, true, 2 | 8 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> ColsFromRing;
-  typedef PassCfg<double, 1024, 16, 16, true, true, 1 | 32 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirst;
-  // the four-step pair the other way round: the first pass stores its columns where they are (twiddled), the
-  // second one reads the intermediate as ROWS -- exchanges inside the wave, no barriers -- and transposes on store
-  typedef PassCfg<double, 1024, 16, 16, true, true, 1 | 2048 | 8192, MODE_C2C, true, 16, 16, 4> FourStepFirstNat;
-  typedef PassCfg<double, 1024, 16, 16, false, true, 2 | 32 | 4096 | 8192, MODE_C2C, false, 16, 16, 4> RowsFromRingT;
-};
 // Measured and NOT kept (tools/ab_option_probe.py fuse2 0,1 <dtype> <n>, fwd + bwd per step): fp64 n = 512
 // (512^3: 5.03 ms unfused, 7.01 fused; four-step 2^18: 0.90 -> 1.32 ms) -- a 128 KiB tile is over in ~10 us, so
 // the per-ticket costs (ticket, counters, write-through acknowledgements) weigh twice as much --, and fp32
@@ -86,9 +75,9 @@ struct Fused512R32 {
   typedef PassCfg<double, 512, 32, 16, true, true, 2 | 8 | 4096 | 8192 | 65536, MODE_C2C, false, 32, 16> ColsFromRingB;
 };
 
-// variant: 1 = the default, 32 values per thread / one exchange (Fused1024R32); 3 = 16 values per thread / two exchanges
-// on 1024 threads (FusedCfgs: the round-3 kernels, kept for A/B: 1024^3 per step 33.4 -> 32.6 ms, C2 0.707 -> 0.677 ms
-// with variant 1, tools/ab_combo_probe.py, profiles/r04_ab_fuse2_variants.txt); 2 / 4 = (make VARIANTS=1) 8 lines per tile,
+// variant: 1 = the default, 32 values per thread / one exchange (Fused1024R32; the round-3 kernels -- 16 values per thread / two
+// exchanges on 1024 threads -- were kept as variant 3 for A/B until round 6: 1024^3 per step 33.4 -> 32.6 ms, C2 0.707 -> 0.677 ms
+// with variant 1, profiles/r04_ab_fuse2_variants.txt); 2 / 4 = (make VARIANTS=1) 8 lines per tile,
 // two workgroups per CU, with 16 / 32 values per thread: 40.6 / 39.7 ms per step, a quarter SLOWER -- what bounds the fused
 // launch is the traffic its CUs can move across the L2 boundary, and 128-byte pieces move less of it
 // Round 5: the 3-D schedule's pair [strided n -> rows n] on two of the unequal-width stage lengths (fft_mixv_f64.hip): 32 values per
@@ -120,7 +109,7 @@ bool fused2_supported_f64(int kind, int variant, int n_a, int n_b) {
   // (... and the batched 2-D kind, [rows -> strided] on contiguous planes: (256,512,512) axes (1,2) 0.78 -> 0.69 ms, (512,512,512) 1.57 -> 1.34 ms)
   if (variant == 1 && n_a == 512) return g_fuse2_n512 != 0 && (kind == FUSED_COLS_ROWS || kind == FUSED_PLANES_2D || kind == FUSED_PLANES_2D_B || kind == FUSED_PLANES_CR_B);
   if (kind == FUSED_PLANES_2D_B || kind == FUSED_PLANES_CR_B) return variant == 1 && n_a == 1024;
-  return (variant == 1 || variant == 3) && n_a == 1024;
+  return variant == 1 && n_a == 1024;
 }
 int g_fuse2_n512 = 1;
 
@@ -140,7 +129,6 @@ int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &
     const int k = kind == FUSED_PLANES_2D_B ? FUSED_PLANES_2D : FUSED_COLS_ROWS;
     return dA.n == 512 ? fused2_tiles_kind<Fused512R32>(k, dA, dB, tiles_a, tiles_b) : fused2_tiles_kind<Fused1024R32>(k, dA, dB, tiles_a, tiles_b);
   }
-  if (variant == 3) return fused2_tiles_kind<FusedCfgs<double, 1024>>(kind, dA, dB, tiles_a, tiles_b);
   if (dA.n == 512) return fused2_tiles_kind<Fused512R32>(kind, dA, dB, tiles_a, tiles_b);
   return fused2_tiles_kind<Fused1024R32>(kind, dA, dB, tiles_a, tiles_b);
 }
@@ -160,7 +148,6 @@ hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const Pa
   if (kind == FUSED_PLANES_CR_B)
     return dA.n == 512 ? launch_fused2<Fused512R32::ColsToRingB, Fused512R32::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s)
                        : launch_fused2<Fused1024R32::ColsToRingB, Fused1024R32::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s);
-  if (variant == 3) return launch_fused2_kind<FusedCfgs<double, 1024>>(kind, dA, dB, dev_descs, f, in, ring, out, s);
   if (dA.n == 512) return launch_fused2_kind<Fused512R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);
   return launch_fused2_kind<Fused1024R32>(kind, dA, dB, dev_descs, f, in, ring, out, s);
 }

@@ -69,24 +69,16 @@ struct Options {
   int xcd_swizzle = -1;      // XCD-contiguous tile order in the pow2 kernels: 0 off, 1 on, -1 auto
   int profile = 0;           // record HIP events around every pass (bench.py roofline leg)
   int fused3 = 1;            // reorder + padded-pitch workspace for 3-D all-axes plans
-  int real_half = 1;         // contiguous real lines as half-length complex transforms (fft_real_*.hip)
   int debug_flat = 0;        // gfft_debug_pass: tiles over the flattened (mid, inner) index
   int flat_out = 1;          // forward r2c 3-D plans: far-axis last pass with flattened tiles
   int mixv_variant = 0;      // A/B: alternative kernels of the unequal-width lengths (tools/gen_mixv_tables.py)
   int mixv = 1;              // one-pass kernels for 3 x 5 x 2^k lengths (fft_mixv_*.hip); 0: the two-pass plans of rounds 1-4 (A/B)
   int wtile = 1;             // tile-major workspace under the complex 3-D pair schedule (plan_fused3; A/B)
-  int pitch129 = 1;          // 3-D schedules: avoid workspace pitches of 129 x 2^k entries (plan_fused3)
-  int pitch_extra = 0;       // A/B: lines (128 B) added to the workspace pitch
-  int ws_plane_skew = 0;     // 3-D schedules: elements added to the FAR stride of the workspace (planes a little more than n * pitch apart)
   int fuse2 = 1;             // pass pairs in one persistent launch, handed over through the Infinity Cache (fft_fused_f64.hip)
   int fuse2_ring = 0, fuse2_lag = 0;   // slots of the hand-off ring / planes the producer runs ahead; 0 = auto (make_fused2)
-  int fuse2_group = 1;       // tiles per ticket
-  int fuse2_defer = 0;       // settle an A tile's counter behind the next tile's loads (A/B)
-  int fuse2_wlayout = 1;     // workspace W[i0][k1][c] under the fused [axis 0 -> rows] pair (0: W[k1][i0][c], A/B)
   int fuse2_kinds = 510;     // which pairs (bit = FusedKind): measured per kind, see make_fused2
   int fuse2_f32 = 1;         // 1: complex64 pairs (fft_fused_f32.hip); 2: the real fp32 pairs too (fft_fused_real_f32.hip: measured level, off)
   int fuse2_wait_ms = 2000;  // wall-clock limit of one wait inside a fused launch before the launch is voided (0: at once -- test hook)
-  int ws_skew_kib = 0;       // developer probe: start the workspace regions this many KiB into their buffer
   int debug_tile_lg = 0, debug_tile_side = 0, debug_tile_stride = 0;   // gfft_debug_pass: tile-major lines (rows passes)
   int64_t fused3_min_bytes = 32 << 20;
   // TEST HOOK (tests/test_gpu_rounding_guard.py): twiddle tables uploaded while debug_tw_exp > 0 carry ONE wrong entry --
@@ -99,15 +91,11 @@ struct Options {
     if (const char *s = getenv("GFFT_VARIANT_COLS")) variant_cols = atoi(s);
     if (const char *s = getenv("GFFT_FORCE_GENERIC")) force_generic = atoi(s);
     if (const char *s = getenv("GFFT_FUSED3")) fused3 = atoi(s);
-    if (const char *s = getenv("GFFT_REAL_HALF")) real_half = atoi(s);
     if (const char *s = getenv("GFFT_XCD_SWIZZLE")) xcd_swizzle = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2")) fuse2 = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_RING")) fuse2_ring = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_LAG")) fuse2_lag = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_KINDS")) fuse2_kinds = atoi(s);
-    if (const char *s = getenv("GFFT_FUSE2_WLAYOUT")) fuse2_wlayout = atoi(s);
-    if (const char *s = getenv("GFFT_FUSE2_GROUP")) fuse2_group = atoi(s);
-    if (const char *s = getenv("GFFT_FUSE2_DEFER")) fuse2_defer = atoi(s);
     if (const char *s = getenv("GFFT_FUSE2_WAIT_MS")) fuse2_wait_ms = atoi(s);
   }
 };
@@ -285,8 +273,8 @@ bool real_half_mixv_ok(int64_t m) { return !opts().force_generic && opts().mixv 
 // kernels.  `n_axis`: transformed length of a complex axis, or the COMPLEX length (half) of a packed-real row.
 bool fused_pad_ok(int64_t n_axis) {
 #ifdef GFFT_VARIANTS
-  (void)n_axis;
-  return true;
+  // (a `make VARIANTS=1` library instantiates the 5^c 2^k adapters; the unequal-width lengths not divisible by 3 have none in ANY build)
+  return !(n_axis <= 4096 && mixv_supported((int)n_axis) && n_axis % 3 != 0);
 #else
   // (the unequal-width stage kernels carry the adapters on lengths divisible by 3: what the 3/2-rule makes of 5 x 2^k, 7 x 2^k ...)
   return !(n_axis <= 4096 && (mix5_supported((int)n_axis) || (mixv_supported((int)n_axis) && n_axis % 3 != 0)));
@@ -414,7 +402,6 @@ struct gfft_plan_s {
   double flops = 0, bytes = 0;
   int variant_rows = 0, variant_cols = 0, xcd_swizzle = 0;
   bool fused3 = false;
-  int ws_skew_kib = -1;                        // >= 0: this plan's workspace starts that many KiB into the shared buffer (gfft_plan_set_ws_skew)
   int mixv_variant = 0;                        // option mixv_variant at plan time (fft_mixv_*.hip: measured alternatives)
   int64_t ws_pitch = 0;                        // plan_fused3: entries between consecutive rows of the workspace
   int ws_tile = 0;                             // ... or: columns of a tile of its tile-major layout
@@ -426,22 +413,24 @@ struct gfft_plan_s {
   int device = 0;                               // the device the plan's tables and descriptors live on
   std::atomic<bool> fused_off{false};           // a fused launch gave up a wait: the pairs run as stand-alone passes from now on
   std::atomic<bool> voided{false};              // ... and nobody has been told yet (poll_async_error)
+  int async_slot = -1;                          // this plan's word of the host-visible table (async_errors; -1: none taken yet)
   gfft_plan_s();
   ~gfft_plan_s();
 };
 
 // ---- fused launches that gave up a wait (fft_pow2_impl.h fused_give_up) --------------------------------
-// The kernel writes the plan's id into a slot of a small table of pinned host words (slot = id mod 64, so that two plans
-// voiding before anybody looks are both recorded); the library scans the table on entry to gfft_execute, in
+// The kernel writes the plan's id into the plan's OWN word of a small table of pinned host words (taken at the plan's first
+// fused launch, given back when the plan is destroyed: two live plans never share one); the library scans the table on entry to gfft_execute, in
 // gfft_plan_status() and in gfft_async_error().  A plan named there switches its pairs to stand-alone passes and carries
 // the error until it is reported ONCE: by that plan's own next gfft_execute (which enqueues nothing), by
 // gfft_plan_status(plan), or by gfft_async_error() -- whichever looks first.  Other plans are not refused: the results of
 // the voided plan's last execution are invalid, everything else is untouched.
 namespace {
 struct AsyncErrors {
-  static constexpr int SLOTS = 64;
+  static constexpr int SLOTS = 256;
   std::mutex m;
   unsigned *flag = nullptr;                    // SLOTS pinned, device-visible words
+  gfft_plan_s *owner[SLOTS] = {};              // the live plan each word belongs to (a plan takes one at its first fused launch)
   std::map<unsigned, gfft_plan_s *> live;
   std::vector<unsigned> orphans;               // ids of voided plans destroyed before anybody looked
   unsigned next_id = 1;
@@ -463,9 +452,9 @@ AsyncErrors &async_errors() {
 void collect_async_errors(AsyncErrors &a) {
   if (!a.flag) return;
   for (int i = 0; i < AsyncErrors::SLOTS; ++i) {
-    const unsigned id = __atomic_load_n(a.flag + i, __ATOMIC_ACQUIRE);
+    // (one exchange, not load-then-store: a word written between the two would be lost)
+    const unsigned id = __atomic_exchange_n(a.flag + i, 0u, __ATOMIC_ACQ_REL);
     if (!id) continue;
-    __atomic_store_n(a.flag + i, 0u, __ATOMIC_RELEASE);
     auto it = a.live.find(id);
     if (it == a.live.end()) { a.orphans.push_back(id); continue; }
     gfft_plan_s *pl = it->second;
@@ -514,6 +503,11 @@ gfft_plan_s::~gfft_plan_s() {
   {
     AsyncErrors &a = async_errors();
     std::lock_guard<std::mutex> lock(a.m);
+    if (a.flag && async_slot >= 0) {
+      // (a launch of this plan may have voided itself since the last look: its word goes with the slot)
+      if (__atomic_exchange_n(a.flag + async_slot, 0u, __ATOMIC_ACQ_REL) == id) voided = true;
+      a.owner[async_slot] = nullptr;
+    }
     if (voided.exchange(false)) a.orphans.push_back(id);      // destroyed before anybody looked: still reported, by gfft_async_error
     a.live.erase(id);
   }
@@ -584,7 +578,11 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   int ring = 0, lag = 0;
   if (!fused2_ring(pl->precision, dA.n, dB.n, slot_bytes, planes, &ring, &lag)) return false;
   if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1)) return false;
-  const int variant = (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1;
+#ifdef GFFT_VARIANTS      // (make VARIANTS=1: the 8-lines-per-tile kernel sets, option fuse2 = 2 / 4 -- measured a quarter slower, fft_fused_f64.hip)
+  const int variant = (opts().fuse2 == 2 || opts().fuse2 == 4) ? opts().fuse2 : 1;
+#else
+  const int variant = 1;
+#endif
   // (complex64 pairs are on by default since round 4 -- option fuse2_f32 = 1, profiles/r04_ab_fuse2_f32.txt; the real fp32
   // pairs measured level with their stand-alone passes and need fuse2_f32 = 2)
   const bool real_kind = kind == FUSED_R2C_PLANES || kind == FUSED_COLS_C2R;
@@ -611,8 +609,8 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   f.fused.tiles_b = tb;
   f.fused.ring = ring;
   f.fused.lag = lag;
-  f.fused.defer = opts().fuse2_defer;     // 0: at the end of the tile; 1: behind the next tile's loads; 2: behind the next ticket's poll
-  f.fused.group = (opts().fuse2_group >= 1 && ta % opts().fuse2_group == 0 && tb % opts().fuse2_group == 0) ? opts().fuse2_group : 1;
+  f.fused.defer = 0;      // an A tile's counter is settled at the end of the tile (1 / 2: behind the next tile's loads / the next ticket's poll -- measured, not kept)
+  f.fused.group = 1;      // one tile per ticket (groups of 2 / 4 measured level to slower, profiles/r03_ab_fuse2_group.txt)
   f.fused.a_in_plane = a_in_plane;
   f.fused.b_out_plane = b_out_plane;
   f.fused.slot_bytes = (int64_t)align256((size_t)slot_bytes);
@@ -676,7 +674,7 @@ PassDesc natural_desc(const Line &L) {
 // Real lines along a contiguous axis, even length: the packed-real form (MODE_R2C_H / MODE_C2R_H).
 bool real_half_ok(const Line &L, int prec) {
   (void)prec;
-  return opts().real_half && !opts().force_generic && (L.mode == MODE_R2C || L.mode == MODE_C2R) &&
+  return !opts().force_generic && (L.mode == MODE_R2C || L.mode == MODE_C2R) &&
          L.inner == 1 && L.n % 2 == 0 && L.n / 2 <= 4096 &&
          (real_half_supported((int)(L.n / 2)) || real_half_mix_supported((int)(L.n / 2)) || real_half_mixv_ok(L.n / 2)) && L.outer < ((int64_t)1 << 31);
 }
@@ -1252,7 +1250,7 @@ bool fused3_applicable(const gfft_plan_s *pl) {
   const std::vector<int64_t> &full = (pl->kind == GFFT_C2R) ? pl->sizes_out : pl->sizes_in;
   for (int i = 0; i < 3; ++i)
     if (!regk_ok(full[i], pl->precision) && !(pl->trunc.empty() && ((!real || i < 2) ? regk_c2c_ok(full[i], pl->precision, MODE_C2C)
-                                                                                       : (opts().real_half && full[i] % 2 == 0 && real_half_mixv_ok(full[i] / 2))))) return false;
+                                                                                       : (full[i] % 2 == 0 && real_half_mixv_ok(full[i] / 2))))) return false;
   const int64_t bytes = full[0] * full[1] * full[2] * (real ? 1 : 2) * pl->precision;
   return bytes >= opts().fused3_min_bytes;
 }
@@ -1287,11 +1285,10 @@ int plan_fused3(gfft_plan_s *pl) {
   // (1024,1024,2048) r2c f64 [1025-wide rows, P = 1032] 11.6 -> 7.2 ms; (512,1024,2048) c128 [P = 2064] 14.0 -> 6.4 ms;
   // (2048,512,2048) r2c f64 18.0 -> 7.8 ms; (1024,1024,4096) r2c f32 [2049-wide, P = 2064] 14.0 -> 8.5 ms; pitches of
   // 17 / 33 / 65 / 257 x 2^k entries (every other BASELINE-sized shape) are level with or without a skew.
-  if (opts().pitch129) {
+  {
     auto odd = [](int64_t x) { while (x && !(x & 1)) x >>= 1; return x; };
     while (odd(P) == 129 || (P * esz) % 2048 == 0) P += seg;
   }
-  if (opts().pitch_extra > 0) P += (int64_t)opts().pitch_extra * seg;        // (A/B: tools/ab_combo_probe.py pitch_extra=...)
   need(pl, BUF_WS, (size_t)(n0 * n1 * P * esz));
   pl->ws_pitch = P;
   // columns the in-workspace passes run over: nc rounded up to whole 128-byte lines (the padding
@@ -1356,7 +1353,7 @@ int plan_fused3(gfft_plan_s *pl) {
     if (wtile && in_ws) { p.d.in_os = TWc; p.d.in_tlg = wt_lg; p.d.in_tS = wtS; }          // (o = k1: one row of a tile; the line itself tile-major)
     if (wtile && out_ws) { p.d.out_os = TWc; p.d.out_tlg = wt_lg; p.d.out_tS = wtS; }
     p.src = src; p.dst = dst;
-    if (mode != MODE_C2C && opts().real_half && n2 % 2 == 0 &&
+    if (mode != MODE_C2C && n2 % 2 == 0 &&
         (real_half_supported((int)(n2 / 2)) || real_half_mix_supported((int)(n2 / 2)) || real_half_mixv_ok(n2 / 2))) {
       // packed-real form: complex length n2/2, the real side (the user's natural array) in pairs
       p.d.n = (int)(n2 / 2);
@@ -1429,7 +1426,7 @@ int plan_fused3(gfft_plan_s *pl) {
   int ring_probe = 0, lag_probe = 0;
   const bool pair_cols_rows = !real && !tr && !flat_out && Pu == nc && opts().fuse2 && fused2_arch_ok() &&
                               ((opts().fuse2_kinds >> FUSED_COLS_ROWS) & 1) && fused2_ring(prec, (int)n0, (int)n2, n0 * P * esz, (int)n1, &ring_probe, &lag_probe) &&
-                              (prec == GFFT_F64 ? fused2_supported_f64(FUSED_COLS_ROWS, (opts().fuse2 >= 2 && opts().fuse2 <= 4) ? opts().fuse2 : 1, (int)n0, (int)n2)
+                              (prec == GFFT_F64 ? fused2_supported_f64(FUSED_COLS_ROWS, 1, (int)n0, (int)n2)
                                                 : (opts().fuse2_f32 && fused2_supported_f32(FUSED_COLS_ROWS, (int)n0, (int)n2)));
   // Real transforms: forward [r2c rows -> axis 1] on the contiguous planes i0 of the flat_out schedule (FUSED_R2C_PLANES),
   // backward [axis 0 -> c2r rows] on the planes i1 (FUSED_COLS_C2R), as the complex schedule runs its last two passes
@@ -1439,16 +1436,16 @@ int plan_fused3(gfft_plan_s *pl) {
     // profiles/r04_real_pairs_f32.txt -- so they need option fuse2_f32 = 2)
     return prec == GFFT_F64 ? fused2_real_supported_f64(kind, na, nb) : (opts().fuse2_f32 >= 2 && fused2_real_supported_f32(kind, na, nb));
   };
-  const bool pair_real = real && !tr && opts().fuse2 && fused2_arch_ok() && n2 % 2 == 0 && opts().real_half &&
+  const bool pair_real = real && !tr && opts().fuse2 && fused2_arch_ok() && n2 % 2 == 0 &&
                          (inverse ? (((opts().fuse2_kinds >> FUSED_COLS_C2R) & 1) && real_ok(FUSED_COLS_C2R, (int)n0, (int)(n2 / 2)) &&
                                      fused2_ring(prec, (int)n0, (int)(n2 / 2), n0 * P * esz, (int)n1, &ring_probe, &lag_probe))
                                   : (((opts().fuse2_kinds >> FUSED_R2C_PLANES) & 1) && flat_out && real_ok(FUSED_R2C_PLANES, (int)(n2 / 2), (int)n1) &&
                                      fused2_ring(prec, (int)(n2 / 2), (int)n1, n1 * P * esz, (int)n0, &ring_probe, &lag_probe)));
-  if (pair_real && inverse && opts().fuse2_wlayout) { w_i0 = n1 * P; w_i1 = P; }     // (as under the complex pair, below)
+  if (pair_real && inverse) { w_i0 = n1 * P; w_i1 = P; }     // (as under the complex pair, below)
   const bool cols_first = !inverse && pair_cols_rows;
   // ... and the workspace then is W[i0][k1][c]: the stand-alone axis-1 pass stores on NEAR strides (stores are
   // what far strides hurt), the fused pair's axis-0 tiles read the far (pitched) ones
-  if (pair_cols_rows && opts().fuse2_wlayout) { w_i0 = n1 * P; w_i1 = P; }
+  if (pair_cols_rows) { w_i0 = n1 * P; w_i1 = P; }
   // Tile-major workspace under that schedule (option wtile): the stand-alone axis-1 pass then WRITES every tile of 256-byte segments
   // as one contiguous 256 KiB run -- measured on the pass alone, same buffers (tools/tile_major_probe.py): 6.48 -> 5.84 ms at 1024^3
   // complex128, reading such a buffer is level -- and the pair's strided tiles read W[i0][tile][k1][.] one 256-byte row per plane.
@@ -1461,19 +1458,12 @@ int plan_fused3(gfft_plan_s *pl) {
   // profiles/r05_ab_wtile.txt part 4; they keep W[i1][i0][c].)
   // The stand-alone forms of a voided pair read the rows tile-major: their thread layout has to advance by whole tiles.
   const bool wtile_rows = pow2_rows_nt(n2, prec) > 0 && pow2_rows_nt(n2, prec) % (int)(256 / esz) == 0 && is_pow2(n0);
-  if (pair_cols_rows && opts().fuse2_wlayout && opts().wtile && wtile_rows && (wtile_len || opts().wtile >= 2) && Pu % (256 / esz) == 0) {
+  if (pair_cols_rows && opts().wtile && wtile_rows && (wtile_len || opts().wtile >= 2) && Pu % (256 / esz) == 0) {
     wtile = true;
     TWc = 256 / esz;
     pl->ws_tile = (int)TWc;
     while (((int64_t)1 << wt_lg) < TWc) ++wt_lg;
     wtS = n1 * TWc;          // (rows of padding after every tile -- 1, 3, 8 -- measured level: profiles/r05_ab_wtile.txt)
-  }
-  if (opts().ws_plane_skew > 0) {
-    // (A/B, tools/skew_sweep.py: consecutive planes of the workspace a few lines further apart than rows * pitch, so that
-    // the rows a far-axis tile walks differ in their LOW address bits too)
-    const int64_t sk = opts().ws_plane_skew;
-    (w_i0 > w_i1 ? w_i0 : w_i1) += sk;
-    need(pl, BUF_WS, (size_t)((n0 * n1 * P + (n0 > n1 ? n0 : n1) * sk) * esz));
   }
   std::vector<Pass> seq;
   if (flat_out) {
@@ -1798,14 +1788,10 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "force_generic")) opts().force_generic = value;
   else if (!strcmp(key, "copy_nt")) gfft::g_copy_nt = value;
   else if (!strcmp(key, "fused3")) opts().fused3 = value;
-  else if (!strcmp(key, "real_half")) opts().real_half = value;
   else if (!strcmp(key, "fuse2")) opts().fuse2 = value;
   else if (!strcmp(key, "fuse2_ring")) opts().fuse2_ring = value;
   else if (!strcmp(key, "fuse2_lag")) opts().fuse2_lag = value;
   else if (!strcmp(key, "fuse2_kinds")) opts().fuse2_kinds = value;
-  else if (!strcmp(key, "fuse2_wlayout")) opts().fuse2_wlayout = value;
-  else if (!strcmp(key, "fuse2_group")) opts().fuse2_group = value;
-  else if (!strcmp(key, "fuse2_defer")) opts().fuse2_defer = value;
   else if (!strcmp(key, "fuse2_wait_ms")) opts().fuse2_wait_ms = value;
   else if (!strcmp(key, "fuse2_f32")) opts().fuse2_f32 = value;
   else if (!strcmp(key, "fuse2_n512")) gfft::g_fuse2_n512 = value;
@@ -1813,16 +1799,12 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "fuse2_mixv")) gfft::g_fuse2_mixv = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
-  else if (!strcmp(key, "ws_plane_skew")) opts().ws_plane_skew = value;
-  else if (!strcmp(key, "pitch129")) opts().pitch129 = value;
   else if (!strcmp(key, "wtile")) opts().wtile = value;
   else if (!strcmp(key, "mixv")) opts().mixv = value;
   else if (!strcmp(key, "mixv_variant")) opts().mixv_variant = value;
-  else if (!strcmp(key, "pitch_extra")) opts().pitch_extra = value;
   else if (!strcmp(key, "debug_tile_lg")) opts().debug_tile_lg = value;
   else if (!strcmp(key, "debug_tile_side")) opts().debug_tile_side = value;
   else if (!strcmp(key, "debug_tile_stride")) opts().debug_tile_stride = value;
-  else if (!strcmp(key, "ws_skew_kib")) opts().ws_skew_kib = value < 0 ? 0 : value;
   else if (!strcmp(key, "profile")) opts().profile = value;
   else if (!strcmp(key, "debug_tw_index")) opts().debug_tw_index = value;
   else if (!strcmp(key, "debug_tw_exp")) opts().debug_tw_exp = value;
@@ -1962,7 +1944,7 @@ int gfft_plan_create_padded(gfft_plan *plan, const int64_t *padded, const int64_
     if (!one_pass || (kept[i] < (real_axis ? padded[i] / 2 + 1 : padded[i]) && !fused_pad_ok(real_axis ? padded[i] / 2 : padded[i])))
       return fail(GFFT_ERR_UNSUPPORTED, "padded length without a single-pass kernel");
   }
-  if (real && !(opts().real_half && padded[2] % 2 == 0 &&
+  if (real && !(padded[2] % 2 == 0 &&
                 (real_half_supported((int)(padded[2] / 2)) || real_half_mix_supported((int)(padded[2] / 2)) || real_half_mixv_ok(padded[2] / 2))))
     return fail(GFFT_ERR_UNSUPPORTED, "real axis without a packed-real row kernel");
   const int64_t bytes = padded[0] * padded[1] * padded[2] * (real ? 1 : 2) * precision;
@@ -2050,6 +2032,24 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
   if (current_device() != pl->device) return fail(GFFT_ERR_INVALID, "the plan was made on another device than the calling thread's current one");
   if ((pl->kind == GFFT_R2C || pl->kind == GFFT_C2R) && d_in == d_out)
     return fail(GFFT_ERR_INVALID, "in-place real transforms are not supported");
+  if (!pl->fused_off && pl->async_slot < 0) {
+    bool any = false;
+    for (const Pass &q : pl->passes) any = any || q.kind == PK_FUSED2;
+    if (any) {
+      // this plan's own word of the host-visible table: two live plans never share one (ids 64 apart used to), so a
+      // voided launch is always attributed; with every word taken the pairs run as their stand-alone passes instead
+      AsyncErrors &ae = async_errors();
+      std::lock_guard<std::mutex> lock(ae.m);
+      if (ae.word())
+        for (int i = 0; i < AsyncErrors::SLOTS && pl->async_slot < 0; ++i)
+          if (!ae.owner[i]) { ae.owner[i] = pl; pl->async_slot = i; }
+      if (pl->async_slot < 0) {
+        pl->fused_off = true;
+        for (const Pass &q : pl->passes)
+          if (q.kind == PK_FUSED2 && q.alt_buf >= 0 && q.alt_bytes > pl->region_bytes[q.alt_buf]) pl->region_bytes[q.alt_buf] = q.alt_bytes;
+      }
+    }
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   // scratch regions: carved from the stream's shared buffer (scratch_pool)
   size_t off[BUF_COUNT] = {0, 0, 0, 0, 0, 0, 0}, total = 0;
@@ -2059,12 +2059,8 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
   }
   void *scratch = nullptr;
   if (total) {
-    // (the plan's own offset, gfft_plan_set_ws_skew -- chosen by measurement at planning, mpifft.PFFT._tune_placement -- else the
-    // developer option, tools/skew_sweep.py)
-    const size_t skew = (size_t)(pl->ws_skew_kib >= 0 ? pl->ws_skew_kib : opts().ws_skew_kib) << 10;
-    int rc = scratch_pool().get(s, total + skew, &scratch);
+    int rc = scratch_pool().get(s, total, &scratch);
     if (rc) return rc;
-    scratch = static_cast<char *>(scratch) + skew;
   }
   void *bufs[BUF_COUNT] = {const_cast<void *>(d_in), d_out, nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int b = BUF_WS; b < BUF_COUNT; ++b)
@@ -2107,8 +2103,7 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
       f.ctr = reinterpret_cast<unsigned *>(ring + (size_t)f.ring * (size_t)f.slot_bytes);
       {
         AsyncErrors &ae = async_errors();
-        if (!ae.flag) { std::lock_guard<std::mutex> lock(ae.m); (void)ae.word(); }
-        f.host_flag = ae.flag ? ae.flag + (pl->id % AsyncErrors::SLOTS) : nullptr;
+        f.host_flag = (ae.flag && pl->async_slot >= 0) ? ae.flag + pl->async_slot : nullptr;
         const int ms = opts().fuse2_wait_ms;
         f.wait_ticks = ms <= 0 ? 0u : (ms > 40000 ? 4000000000u : (unsigned)ms * 100000u);      // 100 MHz ticks
       }
@@ -2572,15 +2567,9 @@ int gfft_plan_set_split_slabs(gfft_plan pl, int side, int nblocks, int64_t rows_
 /* free the shared scratch buffers (they are otherwise kept for the life of the process) */
 int gfft_scratch_release(void) { return scratch_pool().release(true); }
 
-/* Did a fused launch give up a wait since the last look?  GFFT_OK, or GFFT_ERR_HIP once per event with the plan
- * named in gfft_last_error().  Does not synchronise: call it after the stream (or device) has been synchronised to
- * learn whether the results that synchronisation waited for are valid. */
-int gfft_plan_set_ws_skew(gfft_plan pl, int kib) {
-  if (!pl) return fail(GFFT_ERR_INVALID, "null plan");
-  if (kib > (1 << 20)) return fail(GFFT_ERR_INVALID, "workspace offset beyond 1 GiB");
-  pl->ws_skew_kib = kib < 0 ? -1 : kib;
-  return GFFT_OK;
-}
+/* Did a fused launch of ANY plan give up a wait since the last look?  GFFT_OK, or GFFT_ERR_VOIDED once per event with the plan
+ * named in gfft_last_error().  Does not synchronise: call it after the stream (or device) has been synchronised to learn
+ * whether the results that synchronisation waited for are valid (include/gfft.h). */
 int gfft_async_error(void) { return poll_async_error(nullptr); }
 int gfft_plan_status(gfft_plan pl) {
   if (!pl) return fail(GFFT_ERR_INVALID, "null plan");

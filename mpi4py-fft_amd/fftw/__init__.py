@@ -187,13 +187,6 @@ class FFT:
             return copy_out
         return tout
 
-    def set_ws_skew(self, kib):
-        """Offset (KiB) of this plan's regions inside libgfft's shared workspace; results do not depend on it (gfft.h)."""
-        if hasattr(self._eng, 'plan_set_ws_skew'):
-            self._eng.plan_set_ws_skew(self._plan, kib)
-            return True
-        return False
-
     def status(self):
         """After synchronising: raise RuntimeError if a launch of this plan voided itself on the device (a fused pass
         pair that waited too long for another workgroup, include/gfft.h gfft_plan_status); the plan's last results are

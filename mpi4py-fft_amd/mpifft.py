@@ -610,50 +610,8 @@ class PFFT:
         forward, backward = self._fused_callables(fwd, bck, U, V)
         return (forward if 'fwd' in which else None), (backward if 'bwd' in which else None)
 
-    # GFFT_TUNE=measure: offsets of the workspace against the planned arrays (KiB) that are timed when a large one-rank plan is
-    # built.  The strided pass of a 1024^3 plan moves by +-5 % over them on some boxes, the two directions preferring different
-    # ones (tools/skew_sweep.py).  OFF by default: measured over three boxes (profiles/r05_tune_ab.txt) neither the
-    # offsets nor merely executing the plans at planning time moved the step reliably -- fresh processes differ by the same +-1.5 %
-    # through physical placement alone.
-    TUNE_SKEWS = (0, 64, 256, 1088)
-    TUNE_MIN_BYTES = 1 << 30
-
-    def _tune_placement(self, fwd, bck, U, V):
-        """GFFT_TUNE=measure: time each direction's plan on the planned arrays at a few workspace offsets and keep the fastest
-        (as FFTW_MEASURE, the reference's default flag -- libfft.py:52 --, this overwrites the planned arrays); GFFT_TUNE=warm:
-        execute each direction once, so that the workspace is allocated with the plan.  Results never depend on either."""
-        import torch
-        mode = os.environ.get('GFFT_TUNE', '0')
-        if mode in ('0', '') or not torch.cuda.is_available() or U.nbytes < self.TUNE_MIN_BYTES:
-            return None
-        if mode not in ('measure', 'warm'):
-            return None
-        if mode == 'warm' or not (hasattr(fwd, 'set_ws_skew') and fwd.set_ws_skew(0) and bck.set_ws_skew(0)):
-            fwd.execute_scaled(U, V, 1.0)
-            bck.execute_scaled(V, U, 1.0)
-            return None
-        chosen = []
-        for plan, a, b in ((fwd, U, V), (bck, V, U)):
-            best = None
-            for kib in self.TUNE_SKEWS:
-                plan.set_ws_skew(kib)
-                plan.execute_scaled(a, b, 1.0)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(4):
-                    plan.execute_scaled(a, b, 1.0)
-                e1.record()
-                e1.synchronize()
-                ms = e0.elapsed_time(e1) / 4
-                if best is None or ms < 0.98 * best[0]:
-                    best = (ms, kib)
-            plan.set_ws_skew(best[1])
-            chosen.append(best[1])
-        return tuple(chosen)
-
     def _fused_callables(self, fwd, bck, U, V):
         self._fused_plans = (fwd, bck)
-        self.ws_skews = self._tune_placement(fwd, bck, U, V)
         M = fwd.get_normalization()
 
         def forward(src=None, dst=None, **kw):
@@ -684,7 +642,15 @@ class PFFT:
             except _lib.GfftError as e:
                 mine.append(str(e))
         parent = next((c.relay_parent for c in self.subcomm if getattr(c, 'relay_parent', None) is not None), None)
-        everyone = [mine] if parent is None else parent.allgather_obj(mine)
+        if parent is not None:
+            everyone = parent.allgather_obj(mine)
+        else:
+            # no communicator of the whole grid at hand (a user's own Subcomm): gather along one grid axis after the other --
+            # after the last one every rank holds every rank's list (and all raise, or none does)
+            everyone = [mine]
+            for c in self.subcomm:
+                if c.Get_size() > 1:
+                    everyone = [m for part in c.allgather_obj(everyone) for m in part]
         bad = ['rank %d: %s' % (r, m) for r, ms in enumerate(everyone) for m in ms]
         if bad:
             raise _lib.GfftError('; '.join(bad[:4]))

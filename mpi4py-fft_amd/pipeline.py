@@ -1019,11 +1019,17 @@ class Pipeline:
                 me = comm.Get_rank()
                 mytag = int(getattr(comm, '_ranks', list(range(p)))[me]) + 1
                 sb, rb = _bytes(send_t), _bytes(recv_t)
+                # whether this transfer can be checked is a RANK-LOCAL finding (buffer aliasing, message sizes); the skip is a
+                # collective decision -- a rank that skipped alone would leave its peers waiting in the gathers and exchanges below
+                why = None
                 if send_t.data_ptr() == recv_t.data_ptr():
-                    failures.append('transfer %d: send and receive buffer are one array (not checkable)' % ti)
-                    continue
-                if sb.numel() % 8 or rb.numel() % 8 or any(n % 8 for n in list(snd['sizes']) + list(rcv['sizes'])):
-                    failures.append('transfer %d: message sizes are not whole 64-bit words (not checkable)' % ti)
+                    why = 'send and receive buffer are one array'
+                elif sb.numel() % 8 or rb.numel() % 8 or any(n % 8 for n in list(snd['sizes']) + list(rcv['sizes'])):
+                    why = 'message sizes are not whole 64-bit words'
+                whys = comm.allgather_obj(why)
+                if any(w is not None for w in whys):
+                    failures.append('transfer %d: %s on rank(s) %s of its communicator (not checkable)' % (
+                        ti, next(w for w in whys if w is not None), [r for r, w in enumerate(whys) if w is not None]))
                     continue
                 sw, rw = sb.view(torch.int64), rb.view(torch.int64)
                 sw.copy_(torch.arange(sw.numel(), dtype=torch.int64, device=sw.device) + (mytag << 44))

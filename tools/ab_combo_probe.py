@@ -2,9 +2,8 @@
 """Developer probe: clean A/B of COMBINATIONS of libgfft planning options inside a cubic complex128 PFFT -- one plan
 set per combination, all run alternately on the SAME caller arrays (placement moves the step time by several per
 cent), 5 rounds x 10 steps; then the per-pass times of each.
-usage: ab_combo_probe.py [-n 1024 | -n 1024x1024x2048] [-d D] "fuse2=1" "fuse2=3,fuse2_defer=2" ...   (the first one is the baseline)"""
+usage: ab_combo_probe.py [-n 1024 | -n 1024x1024x2048] [-d D] "fuse2=1" "fuse2=0,wtile=0" ...   (the first one is the baseline)"""
 import os, sys
-os.environ.setdefault('GFFT_TUNE', '0')       # (A/B of planning options: no per-plan placement tuning on top)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mpi4py_fft_amd import PFFT, comm, _lib

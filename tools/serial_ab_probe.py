@@ -3,7 +3,6 @@
 combination, all on the same arrays, alternating; results checked against the first combination's.
 usage: serial_ab_probe.py 128x1048576 F 1  "fuse2_f32=0" "fuse2_f32=1" ...     (shape, dtype, axes comma separated)"""
 import os, sys
-os.environ.setdefault('GFFT_TUNE', '0')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
