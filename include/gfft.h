@@ -183,8 +183,8 @@ int gfft_plan_create_guru_padded(gfft_plan *plan, int precision, int kind, const
  *   rows    the contiguous transformed axis (is = os = 1)
  *   cols    the strided transformed axis: n, is / os = distance between consecutive rows of a plane
  *   planes  the batch: n planes, is / os = distance between consecutive planes
- *   cols_first = 1: [cols, then rows] -- strided reads, whole rows written: the faster order in both directions
- *     (measured, tools/stage_probe.py slab); 0: [rows, then cols].
+ *   cols_first = 1: [cols, then rows] -- strided reads, whole rows written: the order the host uses in both directions
+ *     (level with the other one in complex128, 9 % ahead in complex64: tools/stage_probe.py slab); 0: [rows, then cols].
  *   in_blocks / in_block_stride, out_blocks / out_block_stride: the cols axis stored as that many equal blocks whose
  *     starts lie that many elements apart (1 = contiguous) -- the receive buffer of the all-to-all that gathered that
  *     axis on the input side (backward direction), the send buffer of the one that scatters it on the output side

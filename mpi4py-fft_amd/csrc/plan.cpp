@@ -1879,9 +1879,8 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
       rc = line(ax[i], MODE_C2C, inv, pl->sizes_in, pl->sizes_in, i == naxes - 1 ? BUF_IN : BUF_OUT, BUF_OUT);
     // Batched 2-D transforms over the last two axes of a 3-D array -- the leading stage of a slab-decomposed
     // PFFT with collapse=True, or fftn(axes=(1, 2)) --: plane by plane in one fused launch, [strided along axis 1 ->
-    // rows along axis 2] in both directions (build_pair2d: strided reads, whole rows written -- round 6; the [rows ->
-    // strided] order of rounds 4-5 stores 256-byte pieces: (512,1024,1024) complex128 5.57 against 4.79 ms,
-    // profiles/r06_stage_probe_slab.txt)
+    // rows along axis 2] in both directions (build_pair2d: strided reads, whole rows written -- round 6; against the
+    // [rows -> strided] order of rounds 4-5: level in complex128, 9 % ahead in complex64, profiles/r06_stage_probe_slab.txt)
     if (!rc && ndims == 3 && naxes == 2 && ax[0] == 1 && ax[1] == 2 && pl->passes.size() == 2) {
       const Pass &pr = pl->passes[0], &pc = pl->passes[1];
       const int64_t n0 = sizes_in[0], n1 = sizes_in[1], n2 = sizes_in[2];

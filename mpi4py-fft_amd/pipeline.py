@@ -270,9 +270,10 @@ class _PairStage:
     (gfft_plan_create_guru2: the plane is handed from the first pass to the second inside the Infinity Cache).  The
     chunks cut array axis 0, the axis the redistribution gathers; the buffer side is [chunk][peer][plane][E] with the
     planes E elements apart (_pitch), which the pair addresses itself: forward natural -> buffer, backward buffer ->
-    natural, both as [strided pass, then rows] -- strided reads, whole rows written (the forward pair the other way round,
-    its strided pass storing 256-byte pieces into the buffer: 5.5 against 4.8 ms at (512,1024,1024) complex128,
-    profiles/r06_stage_probe_slab.txt).  The stage on the far side transforms axis 0 and takes the chunks all at once (_FarStage)."""
+    natural, both as [strided pass, then rows] -- strided reads, whole rows written.  (The forward pair the other way
+    round, its strided pass storing into the blocks, is level in complex128 -- 4.73 against 4.78 ms at (512,1024,1024) --
+    and 9 % behind in complex64, profiles/r06_stage_probe_slab.txt; it measured 5.5 ms while the compiler serialised its
+    ring loads, which tools/scan_serial_loads.py found.)  The stage on the far side transforms axis 0 and takes the chunks all at once (_FarStage)."""
     def __init__(self, shape, p, K, E, forward, precision):
         N0, N1, N2 = (int(v) for v in shape)
         N0c = N0 // K
