@@ -68,7 +68,6 @@ def test_one_wrong_twiddle_entry_fails_the_guards(dt, exponent, wrong_twiddle):
             ef, eb = cases.impulse_errors(n, dt, strided)
             unit = cases.EPS[dt] * np.log2(n)
             assert ef > IMPULSE_FACTOR * unit and ef >= 0.9 * delta, (n, dt, strided, ef)          # caught, at full size
-            assert ef <= cases.CONTRACT['fwd'][dt] and eb <= cases.CONTRACT['rt'][dt]              # ... which the contract tolerance lets through
     # a whole transform on random data: what the shared checker sees
     from mpi4py_fft_amd import PFFT, newDistArray, comm
     from oracle import pfft_oracle as O

@@ -41,10 +41,12 @@ def run_case(name, prec, real0, sh0, nh, sh1, sh2, p0, K0, widths, p1, K1):
     b = torch.empty_like(a)
     alg = [np.prod(sh0) * (prec if real0 else isz) + np.prod(sh0[:2]) * nh * isz, 2 * np.prod(sh1) * isz, 2 * np.prod(sh2) * isz]
 
+    only_dir, only_stage = os.environ.get('STAGE_PROBE_DIR'), os.environ.get('STAGE_PROBE_STAGE')     # profiling runs: one direction / stage per process
+
     def report(layout, fwd, bwd):
         for i in range(3):
             for tag, st in (('fwd', fwd[i]), ('bwd', bwd[i])):
-                if st is None:
+                if st is None or (only_dir and tag != only_dir) or (only_stage and str(i) != only_stage):
                     continue
                 t = timeit(lambda: [st.execute(eng, c, a.data_ptr(), b.data_ptr(), 1.0) for c in range(st.nchunks)])
                 print('%-16s %-9s stage %d %s  %d step(s) %8.3f ms  %7.1f GB/s  %4.1f %%' % (
