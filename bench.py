@@ -11,7 +11,7 @@ as it is.  Rank 0 prints ONE JSON line.
 1-D line => 1.6106e11 per 1024^3 transform, fwd + bwd per step), inputs resident in HBM before the
 timed region, barrier + device sync on both sides, max over ranks.  `roofline` is for the dominant
 kernel: algorithmic bytes per launch (one read + one write of the local array per axis pass the
-launch performs -- the fused launch of DESIGN.md section 4.7 performs two) / its mean launch
+launch performs -- the fused launch of DESIGN_HISTORY.md section 4.7 performs two) / its mean launch
 duration from HIP events recorded on the launch stream inside the timed region; that launch hands
 its intermediate over inside the Infinity Cache, which is how `achieved` can exceed the same-run
 streaming-copy ceiling (`hbm_copy_ceiling`).  `cpu_baseline`

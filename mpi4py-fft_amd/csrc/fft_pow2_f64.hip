@@ -3,7 +3,7 @@
 // Plan table (R = elements per thread, T = columns per workgroup, radices per stage).
 // Defaults at N = 1024: rows R = 16 / T = 4 (111 VGPRs), strided R = 16 / T = 16 = 256-byte
 // segments (107 VGPRs, 1024 threads); the `variant` argument selects the measured alternatives
-// (DESIGN.md section 4.1 has the A/B numbers that picked the defaults).
+// (DESIGN_HISTORY.md section 4.1 has the A/B numbers that picked the defaults).
 #include "fft_pow2_impl.h"
 
 namespace gfft {

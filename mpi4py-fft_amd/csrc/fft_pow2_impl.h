@@ -1150,7 +1150,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 // ---- two dependent passes in ONE persistent launch, handed over through the Infinity Cache -----------
 // Two passes A -> B over an array far larger than the 256 MiB Infinity Cache normally cost 4 array-sized
 // HBM transfers (A reads, A writes, B reads, B writes), and running them slab by slab as separate launches
-// loses in launch tails what the cache gives back.  Here both run inside one launch of
+// loses in launch tails what the cache gives back (DESIGN_HISTORY.md section 6).  Here both run inside one launch of
 // one workgroup per CU.  The work is cut into PLANES -- a plane is a set of A tiles whose output is exactly
 // the input of a set of B tiles (an i1-plane of a 3-D array for [rows along axis 2] -> [columns along axis
 // 0]; one signal of a four-step transform) -- and A writes plane p into slot p % ring of a small ring buffer
