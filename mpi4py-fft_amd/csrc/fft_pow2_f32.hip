@@ -136,6 +136,7 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
           // (4.50 with non-temporal streams), axis 0 4.8-4.9 -> 6.44 / 4.93 ms (profiles/r04_variant_cols_f32_r64.txt)
           case 5: return P32F(1024, 64, 32, true, true, 2, 8, 64, 16);
           case 6: return P32F(1024, 64, 32, true, true, 2, 8 | 3, 64, 16);     // ... with non-temporal loads and stores
+          case 10: return P32F(1024, 32, 32, true, true, 1, 8 | 4, 16, 16, 4);    // R6: the ACCESS PATTERN ALONE of the default tile (tools/strided_bound_probe_f32.py)
 #endif
 #ifdef GFFT_VARIANTS
           // A/B: two radix-32 stages = ONE exchange instead of two (LDS cycles and barriers halved), but the
@@ -152,6 +153,7 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
           // (512,2048,513) axis 1 2.53 -> 2.80 ms (3.81 with non-temporal streams), (2048,512,513) axis 0 2.38 -> 2.65 / 2.36 ms
           case 5: return P32F(2048, 64, 16, true, true, 2, 8, 64, 32);
           case 6: return P32F(2048, 64, 16, true, true, 2, 8 | 3, 64, 32);
+          case 10: return P32F(2048, 32, 16, true, true, 1, 8 | 4, 16, 16, 8);    // R6: access pattern alone
 #endif
 #ifdef GFFT_VARIANTS
           case 1: return P32(2048, 16, 8, true, true, 4, 16, 16, 8);

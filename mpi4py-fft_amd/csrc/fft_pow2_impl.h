@@ -1045,6 +1045,36 @@ __device__ __forceinline__ int64_t uneven_offset(const PassDesc &d, unsigned row
   return d.ub_rows * (int64_t)start + (int64_t)row * width + ee;
 }
 
+// The same for the entries e = tl + q * NT_ a thread holds (q a compile-time slot index, NT_ threads per row): the block of
+// the GROUP's first entry q * NT_ comes from scalar compares -- both sides are uniform --, and since no block is narrower than
+// a group (PassDesc::ub_minw >= NT_, checked by the caller) at most ONE boundary falls inside it: one per-lane compare and
+// selects between the two blocks' uniform quantities replace the chain of seven compare-and-select steps per entry, which
+// cost the packed-real rows of config C5 a quarter of their time (stage 0 of a rank: 1.74 ms natural, 2.21 ms into the
+// exchange buffer; profiles/r05_stage_probe.txt).
+template <int NT_>
+__device__ __forceinline__ int64_t uneven_offset_group(const PassDesc &d, unsigned row, unsigned slab, unsigned srow, int tl, int q) {
+  const int e0 = q * NT_;
+  int b = 0;
+#pragma unroll
+  for (int bb = 1; bb < 8; ++bb)
+    if (bb < d.ub_p && e0 >= d.ub_start[bb]) b = bb;
+  const int s_lo = d.ub_start[b], s_hi = d.ub_start[b + 1], s_top = d.ub_start[b + 2 > 8 ? 8 : b + 2];
+  const int e = e0 + tl;
+  const bool up = e >= s_hi;                    // (the last block ends at N + 1 > e: never)
+  const int start = up ? s_hi : s_lo;
+  const int ee = e - start;
+  if (d.ub_n1 > 0) {
+    const int lg = d.ub_tlg, n1 = (int)d.ub_n1;
+    const int w_lo = s_hi - s_lo, w_hi = s_top - s_hi;
+    const int bw_lo = (w_lo >> lg) << lg, bw_hi = (w_hi >> lg) << lg;
+    const int s0_lo = (int)d.ub_base[b] + (int)slab * (n1 * w_lo), s0_hi = (int)d.ub_base[b + 1 > 7 ? 7 : b + 1] + (int)slab * (n1 * w_hi);
+    const int s0 = up ? s0_hi : s0_lo, bw = up ? bw_hi : bw_lo, lw = up ? w_hi - bw_hi : w_lo - bw_lo;
+    return ee < bw ? s0 + (int)srow * bw + ee : s0 + n1 * bw + (int)srow * lw + (ee - bw);
+  }
+  const int width = up ? s_top - s_hi : s_hi - s_lo;
+  return d.ub_rows * (int64_t)start + (int64_t)row * width + ee;
+}
+
 template <int T, bool COLS, bool BIGTW>
 __device__ __host__ __forceinline__ unsigned pow2_ntiles(const PassDesc &d) {
   const unsigned batch = (unsigned)d.batch, inner = (unsigned)d.inner, mid = (unsigned)d.mid;

@@ -70,6 +70,7 @@ struct PassDesc {
   // rows in the buffer) lives at  ub_rows * start_b + o * w_b + (e - start_b):  the layout gfft_pack
   // produces for the cut axis being the last one.  0 = not in use.
   int ub_p;
+  int ub_minw;            // width of the narrowest block (the kernels' group addressing needs it >= their threads per row)
   int ub_start[9];
   int64_t ub_rows;
   int64_t in_os, in_ms, in_is, in_es;

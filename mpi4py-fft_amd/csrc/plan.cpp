@@ -2286,6 +2286,7 @@ int gfft_plan_set_split(gfft_plan pl, int side, int nblocks) {
     p.d.ub_p = nblocks;
     for (int b = 0; b <= nblocks; ++b) p.d.ub_start[b] = b * q + (b < r ? b : r);
     for (int b = nblocks + 1; b < 9; ++b) p.d.ub_start[b] = nh;
+    p.d.ub_minw = q;
     p.d.ub_rows = p.d.batch;
     return GFFT_OK;
   }

@@ -53,12 +53,13 @@ def wrong_twiddle():
     _lib.set_option('debug_tw_index', 1)
 
 
-@pytest.mark.parametrize('dt,exponent', [('D', 9), ('F', 5)])
+@pytest.mark.parametrize('dt,exponent', [('D', 9), ('D', 11), ('F', 5)])
 def test_one_wrong_twiddle_entry_fails_the_guards(dt, exponent, wrong_twiddle):
     """Plans made while the hook is armed read tables whose entry 1 (w^1: every plan's last stage reads it) is off by
     10^-exponent in its real part.  The impulse family must name it in both precisions, in both mappings, at every
-    length; the random-data guards must name it in fp64 (1e-9 against ~1e-13), and the CONTRACT tolerances must let all
-    of it through -- which is why they cannot be the only check."""
+    length; the random-data guards must name it in fp64 (1e-9 and 1e-11 against ~1e-14).  The CONTRACT tolerances let the
+    fp64 entry off by 1e-11 and the fp32 one off by 1e-5 through (on 64^3 the 1e-9 one comes out at 1.3e-9, which they
+    catch) -- which is why they cannot be the only check."""
     delta = 10.0 ** -exponent
     shape = (64, 64, 64)
     cases.check_pfft_vs_oracle(1, shape, dt)                      # sane before ...
@@ -79,10 +80,11 @@ def test_one_wrong_twiddle_entry_fails_the_guards(dt, exponent, wrong_twiddle):
     ref = O.OPFFT(1, shape, dtype=dt).forward([G])[0]
     err = float(np.abs(uh - ref).max() / np.abs(ref).max())
     fft.destroy()
-    assert err <= cases.CONTRACT['fwd'][dt], err                  # the contract tolerance passes the broken table
+    if exponent != 9:
+        assert err <= cases.CONTRACT['fwd'][dt], err              # the contract tolerance passes the broken table
     if dt == 'D':
         assert err > cases.rounding_tol(dt, G.size), (err, cases.rounding_tol(dt, G.size))
-        with pytest.raises(AssertionError, match='ROUNDING-LEVEL'):
+        with pytest.raises(AssertionError, match='ROUNDING-LEVEL' if exponent != 9 else None):
             cases.check_pfft_vs_oracle(1, shape, dt)
     else:
         # fp32: one entry off by 1e-5 is diluted to ~1 / (3.5 sqrt(radix)) of itself on random data -- level with fp32
@@ -93,11 +95,11 @@ def test_one_wrong_twiddle_entry_fails_the_guards(dt, exponent, wrong_twiddle):
 
 
 def test_lost_digits_in_a_distributed_plan_fail_the_guards(wrong_twiddle):
-    """The same on 4 thread-ranks (pencil grid, packed exchange buffers): a distributed fp64 plan that lost four digits
+    """The same on 4 thread-ranks (pencil grid, packed exchange buffers): a distributed fp64 plan that lost three digits
     passes the 2e-10 contract and fails the shared checker."""
     shape = (64, 32, 64)
     cases.check_pfft_vs_oracle(4, shape, 'D')
-    wrong_twiddle(1, 9)
+    wrong_twiddle(1, 11)
     with pytest.raises(AssertionError, match='ROUNDING-LEVEL'):
         cases.check_pfft_vs_oracle(4, shape, 'D')
     wrong_twiddle(1, 0)
