@@ -231,6 +231,12 @@ bool mix5_supported(int n);
 hipError_t launch_mix5_f64(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
 hipError_t launch_mix5_f32(const PassDesc &d, bool cols, const void *in, void *out, hipStream_t s);
 
+// both passes of small 2-D planes in one launch, the plane in LDS (fft_plane2d.hip): dA = rows of one plane -> LDS, dB = columns LDS -> out
+bool plane2d_supported(int n, int precision);
+int plane2d_pitch(int n);
+hipError_t launch_plane2d(const PassDesc &dA, const PassDesc &dB, int precision, int planes, int64_t in_plane, int64_t out_plane,
+                          const void *in, void *out, hipStream_t s);
+
 hipError_t launch_pack(const void *src, void *dst, int64_t outer, int64_t naxis, int64_t inner,
                        int nparts, int itemsize, bool unpack, hipStream_t s);
 hipError_t launch_trunc(const void *src, void *dst, int64_t outer, int64_t npad,

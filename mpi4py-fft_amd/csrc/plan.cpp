@@ -74,6 +74,7 @@ struct Options {
   int mixv_variant = 0;      // A/B: alternative kernels of the unequal-width lengths (tools/gen_mixv_tables.py)
   int mixv = 1;              // one-pass kernels for 3 x 5 x 2^k lengths (fft_mixv_*.hip); 0: the two-pass plans of rounds 1-4 (A/B)
   int wtile = 1;             // tile-major workspace under the complex 3-D pair schedule (plan_fused3; A/B)
+  int plane2d = 1;           // planes of 32^2 / 64^2 points: both passes in one launch, the plane in LDS (fft_plane2d.hip; 0: two passes, A/B)
   int fuse2 = 1;             // pass pairs in one persistent launch, handed over through the Infinity Cache (fft_fused_f64.hip)
   int fuse2_ring = 0, fuse2_lag = 0;   // slots of the hand-off ring / planes the producer runs ahead; 0 = auto (make_fused2)
   int fuse2_kinds = 510;     // which pairs (bit = FusedKind): measured per kind, see make_fused2
@@ -194,7 +195,7 @@ int get_bigtw(int64_t big_n, int precision, BigTw *out) {
 //   FS2  the intermediate of the outer level of a three-pass axis (lengths beyond 2^24, plan_long)
 enum Buf { BUF_IN = 0, BUF_OUT = 1, BUF_WS = 2, BUF_FS = 3, BUF_AUX = 4, BUF_RING = 5, BUF_FS2 = 6, BUF_COUNT = 7 };
 
-enum PassKind { PK_FFT = 0, PK_EMBED, PK_MULB, PK_EXTRACT, PK_FUSED2 };
+enum PassKind { PK_FFT = 0, PK_EMBED, PK_MULB, PK_EXTRACT, PK_FUSED2, PK_PLANE2D };    // PK_PLANE2D: both passes of small planes on chip (fft_plane2d.hip)
 
 struct Pass {
   PassKind kind = PK_FFT;
@@ -1788,6 +1789,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "force_generic")) opts().force_generic = value;
   else if (!strcmp(key, "copy_nt")) gfft::g_copy_nt = value;
   else if (!strcmp(key, "fused3")) opts().fused3 = value;
+  else if (!strcmp(key, "plane2d")) opts().plane2d = value;
   else if (!strcmp(key, "fuse2")) opts().fuse2 = value;
   else if (!strcmp(key, "fuse2_ring")) opts().fuse2_ring = value;
   else if (!strcmp(key, "fuse2_lag")) opts().fuse2_lag = value;
@@ -1891,6 +1893,29 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
         const gfft_iodim c{n1, n2, n2}, p{n0, n1 * n2, n1 * n2};
         bool fused = false;
         if (build_pair2d(pl, &c, n2, &p, inv, 1, 1, 0, 1, 0, true, &fused) != GFFT_OK || !fused) pl->passes = two;
+      }
+    }
+    // Planes of 32 x 32 / 64 x 64 points -- config C1's 64^3, small images --: rows and columns of a plane in ONE launch with the
+    // plane held in LDS (fft_plane2d.hip): such arrays live in the caches and a pass costs its dependent memory round trip, not
+    // its bytes (64^3 complex128: three passes of ~5 us each, tools/c1_probe.py); this removes one of them.
+    if (!rc && ndims == 3 && naxes >= 2 && ax[naxes - 2] == 1 && ax[naxes - 1] == 2 && (naxes == 2 || (naxes == 3 && ax[0] == 0)) &&
+        sizes_in[1] == sizes_in[2] && plane2d_supported((int)sizes_in[1], precision) && pl->passes.size() == (size_t)naxes && opts().plane2d) {
+      const Pass &pr = pl->passes[0], &pc = pl->passes[1];
+      if (pr.kind == PK_FFT && pc.kind == PK_FFT && pr.regk && pc.regk && !pr.cols && pc.cols && sizes_in[0] < ((int64_t)1 << 30)) {
+        const int64_t n = sizes_in[1], P = plane2d_pitch((int)n), esz = 2 * (int64_t)precision;
+        Pass f = pr;
+        f.kind = PK_PLANE2D;
+        f.d = pr.d;                                          // rows of ONE plane: natural rows -> the plane in LDS, rows P entries apart
+        f.d.batch = n;  f.d.mid = 1;  f.d.inner = 1;  f.d.in_os = n;  f.d.in_is = 0;  f.d.out_os = P;  f.d.out_is = 0;
+        f.d2 = pc.d;                                         // columns of one plane: LDS -> natural rows
+        f.d2.batch = n;  f.d2.mid = 1;  f.d2.inner = n;  f.d2.in_os = 0;  f.d2.out_os = 0;  f.d2.in_es = P;  f.d2.in_is = 1;
+        f.fused.planes = (int)sizes_in[0];
+        f.fused.a_in_plane = n * n * esz;
+        f.fused.b_out_plane = n * n * esz;
+        f.src = BUF_IN;  f.dst = BUF_OUT;
+        f.bytes2 = 4.0 * (double)sizes_in[0] * (double)n * (double)n * (double)esz;
+        pl->passes.erase(pl->passes.begin(), pl->passes.begin() + 2);
+        pl->passes.insert(pl->passes.begin(), f);
       }
     }
   } else if (kind == GFFT_R2C) {
@@ -2082,6 +2107,13 @@ int gfft_execute(gfft_plan pl, const void *d_in, void *d_out, double scale, void
   }
   for (const Pass &p : pl->passes) {
     PassDesc d = p.d;
+    if (p.kind == PK_PLANE2D) {
+      PassDesc d2 = p.d2;
+      d2.scale = p.carries_scale ? scale : 1.0;
+      HIP_TRY(launch_plane2d(d, d2, pl->precision, p.fused.planes, p.fused.a_in_plane, p.fused.b_out_plane, bufs[p.src], bufs[p.dst], s));
+      HIP_TRY(mark());
+      continue;
+    }
     if (p.kind == PK_FUSED2 && pl->fused_off) {
       // the pair as its two stand-alone passes (a fused launch of this plan gave up a wait, poll_async_error)
       for (int k = 0; k < 2; ++k) {
@@ -2178,6 +2210,11 @@ int gfft_plan_pass_info(gfft_plan pl, int i, char *buf, size_t len, double *byte
     snprintf(buf, len, "%s n=%dx%d", fk[p.fused_kind], p.d.n, p.d2.n);
     if (bytes) *bytes = p.bytes2 > 1 ? p.bytes2 : (double)p.fused.planes * 2.0 * pl->precision *
                         ((double)p.d.batch * 2.0 * p.d.n + (double)p.d2.batch * 2.0 * p.d2.n);
+    return GFFT_OK;
+  }
+  if (p.kind == PK_PLANE2D) {
+    snprintf(buf, len, "planes in LDS rows+cols n=%dx%d", p.d.n, p.d2.n);
+    if (bytes) *bytes = p.bytes2;
     return GFFT_OK;
   }
   if (p.kind != PK_FFT) {
@@ -2607,6 +2644,12 @@ int gfft_plan_describe(gfft_plan pl, char *buf, size_t len) {
       snprintf(line, sizeof line, "  fused pair (%s) n=%d then n=%d: %d planes, %d + %d tiles per plane, ring of %d slots x %lld KiB, one persistent launch%s  %s -> %s\n",
                fk[p.fused_kind], p.d.n, p.d2.n, p.fused.planes, p.fused.tiles_a, p.fused.tiles_b, p.fused.ring,
                (long long)(p.fused.slot_bytes >> 10), p.carries_scale ? " [scale]" : "", bufn[p.src], bufn[p.dst]);
+      s += line;
+      continue;
+    }
+    if (p.kind == PK_PLANE2D) {
+      snprintf(line, sizeof line, "  planes on chip: rows n=%d then columns n=%d of %d planes held in LDS, one launch%s  %s -> %s\n", p.d.n, p.d2.n,
+               p.fused.planes, p.carries_scale ? " [scale]" : "", bufn[p.src], bufn[p.dst]);
       s += line;
       continue;
     }
