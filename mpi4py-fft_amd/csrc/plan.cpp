@@ -1618,6 +1618,12 @@ hipError_t run_pass(const gfft_plan_s *pl, const Pass &p, const PassDesc &d0, co
   // (256,512,1024) c128 rows 0.803 (4096) -> 0.782 ms (16384), (512,1024,2048) f32 r2c rows 1.854 ->
   // 1.803 ms; strided stand-alone passes are level or lose (far axis 1.001 -> 1.037 ms) and keep 4096
   if (!d.grid_cap && p.regk && !p.cols && !pl->fused3 && opts().grid_cap <= 0) d.grid_cap = 16384;
+  // ... and of strided passes that READ on a far power-of-two stride (the caller's natural array along its outermost axis: the far
+  // stage of every backward distributed transform): more, shorter walks -- (1024,256,512) complex128 natural -> natural 0.895 ->
+  // 0.849 ms, natural -> pitched 0.903 -> 0.857 ms; pitched inputs and near axes are level or lose (tools/bwd_probe.py,
+  // profiles/r06_bwd_probe.txt)
+  if (!d.grid_cap && p.regk && p.cols && !pl->fused3 && opts().grid_cap <= 0 && d.mid == 1 && !d.flat && !d.in_lgp &&
+      d.in_es >= ((int64_t)1 << 16) && (d.in_es & (d.in_es - 1)) == 0) d.grid_cap = 16384;
   d.swizzle = pl->xcd_swizzle >= 0 ? pl->xcd_swizzle : (p.cols && !d.flat && ((d.out_es * esz_out) % 128 != 0) ? 1 : 0);
   if ((d.mode == MODE_R2C_H || d.mode == MODE_C2R_H) && real_half_supported(d.n))
     return pl->precision == 8 ? launch_real_half_f64(d, pl->variant_rows, in, out, s)

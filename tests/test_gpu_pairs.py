@@ -167,3 +167,61 @@ def test_slab_grid_runs_its_local_stages_as_one_launch(P, shape, dt, small_ring,
         assert np.linalg.norm(ra - G[sl]) <= tol * np.linalg.norm(G[sl])
         assert np.linalg.norm(r0 - G[sl]) <= tol * np.linalg.norm(G[sl])
         assert np.allclose(rn * nelem, rb, rtol=1e-5 if dt == 'F' else 1e-12, atol=0)
+
+
+def test_a_voided_slab_pair_falls_back_to_its_two_passes(small_ring):
+    """A guru2 launch that gives up a wait (fuse2_wait_ms = 0: every wait gives up at once) is reported once as GFFT_ERR_VOIDED and the
+    plan runs [strided IN -> OUT, rows in place on OUT] from then on -- with the blocks of the all-to-all buffer on either side."""
+    import torch
+    from mpi4py_fft_amd import _lib
+    eng = _lib.engine()
+    n, planes, blocks = 1024, 16, 4
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((planes, n, n)) + 1j * rng.standard_normal((planes, n, n))).astype('D')
+    nb = n // blocks
+    E = nb * n + 16
+    bstride = planes * E
+    want = np.fft.fft2(x, axes=(1, 2))
+    a = torch.from_numpy(x).cuda()
+    buf = torch.zeros(blocks * bstride, dtype=torch.complex128, device='cuda')
+    back = torch.zeros((planes, n, n), dtype=torch.complex128, device='cuda')
+    hf = eng.plan_create_guru2(8, -1, (n, n, n), (n, 1, 1), (planes, n * n, E), True, 1, 0, blocks, bstride)
+    hb = eng.plan_create_guru2(8, +1, (n, n, n), (n, 1, 1), (planes, E, n * n), True, blocks, bstride, 1, 0)
+    try:
+        for h, src, dst in ((hf, a, buf), (hb, buf, back)):
+            assert eng.plan_cost(h)[2] == 1
+            _lib.set_option('fuse2_wait_ms', 0)
+            eng.execute_ptr(h, src.data_ptr(), dst.data_ptr(), 1.0)
+            torch.cuda.synchronize()
+            _lib.set_option('fuse2_wait_ms', 2000)
+            with pytest.raises(RuntimeError, match='gave up'):
+                eng.plan_status(h)
+            assert 'two stand-alone passes' in eng.plan_describe(h)
+            eng.execute_ptr(h, src.data_ptr(), dst.data_ptr(), 1.0 if h is hf else 1.0 / (n * n))       # ... and right
+            torch.cuda.synchronize()
+            _lib.check_async()
+        got = buf.cpu().numpy().reshape(blocks, planes, E)
+        for j in range(blocks):
+            blk = got[j, :, :nb * n].reshape(planes, nb, n)
+            assert np.abs(blk - want[:, j * nb:(j + 1) * nb]).max() <= _rounding('D', n * n) * np.abs(want).max()
+        assert np.linalg.norm(back.cpu().numpy() - x) <= _rounding('D', n * n) * np.linalg.norm(x)
+    finally:
+        _lib.set_option('fuse2_wait_ms', 2000)
+        eng.plan_destroy(hf)
+        eng.plan_destroy(hb)
+
+
+def test_pairs_without_packed_exchange_buffers(small_ring, monkeypatch):
+    """fuse_pack=False: the pair writes / reads the natural stage array and the Transfer packs with its own kernels."""
+    from mpi4py_fft_amd import PFFT
+    shape, P = (32, 512, 512), 2
+
+    def body(comm):
+        fft = PFFT(comm, shape, dtype='D', grid=[P, 1, 1], wire='torch', exchange='direct', fuse_pack=False)
+        out = (list(fft.forward._pairs), [(t.packedA, t.packedB) for t in fft.transfer])
+        fft.destroy()
+        return out
+    for pairs, packed in cases.run_ranks(P, body):
+        assert pairs == [0] and packed == [(False, False), (False, False)]
+    monkeypatch.setenv('GFFT_FUSE_PACK', '0')
+    cases.check_pfft_vs_oracle(P, shape, 'D', grid=[P, 1, 1])
