@@ -137,7 +137,9 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
           case 5: return P32F(1024, 64, 32, true, true, 2, 8, 64, 16);
           case 6: return P32F(1024, 64, 32, true, true, 2, 8 | 3, 64, 16);     // ... with non-temporal loads and stores
           case 10: return P32F(1024, 32, 32, true, true, 1, 8 | 4, 16, 16, 4);    // R6: the ACCESS PATTERN ALONE of the default tile (tools/strided_bound_probe_f32.py)
-          case 11: return P32F(1024, 32, 32, true, true, 1, 8 | 131072, 16, 16, 4);   // R6: touches of the next tile behind the loads (fft_pow2_body.inc)
+          // (R6, measured and NOT kept: touches of the NEXT tile's lines issued behind this tile's loads -- one dword per element into a VGPR nobody reads --
+          // so that HBM works during the exchange phase: near strides +8 ... +10 % SLOWER, far strides +-1 %: the touches cross the L2 boundary too,
+          // which is what the launch is short of; profiles/r06_touch_probe.txt)
 #endif
 #ifdef GFFT_VARIANTS
           // A/B: two radix-32 stages = ONE exchange instead of two (LDS cycles and barriers halved), but the
@@ -155,7 +157,6 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
           case 5: return P32F(2048, 64, 16, true, true, 2, 8, 64, 32);
           case 6: return P32F(2048, 64, 16, true, true, 2, 8 | 3, 64, 32);
           case 10: return P32F(2048, 32, 16, true, true, 1, 8 | 4, 16, 16, 8);    // R6: access pattern alone
-          case 11: return P32F(2048, 32, 16, true, true, 1, 8 | 131072, 16, 16, 8);
 #endif
 #ifdef GFFT_VARIANTS
           case 1: return P32(2048, 16, 8, true, true, 4, 16, 16, 8);

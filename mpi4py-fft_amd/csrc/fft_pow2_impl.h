@@ -1148,9 +1148,7 @@ __device__ __forceinline__ void pow2_body(const PassDesc &d, const void *__restr
 #define GFFT_TILE_LOOP for (unsigned k = k_first; k < k_end; k += k_step)
 #define GFFT_TILE_INDEX const unsigned tile = xcd_base + k;
 #define GFFT_AFTER_LOADS after_loads();
-#define GFFT_NEXT_TILE (~0u)
 #include "fft_pow2_body.inc"
-#undef GFFT_NEXT_TILE
 #undef GFFT_TILE_LOOP
 #undef GFFT_TILE_INDEX
 #undef GFFT_AFTER_LOADS
@@ -1172,9 +1170,7 @@ fft_pow2_kernel(PassDesc d, const void *__restrict__ in, void *__restrict__ out)
 #define GFFT_TILE_INDEX const unsigned tile = d.swizzle ? (blockIdx.x % 8) * per_xcd + k : k;
 #define GFFT_AFTER_LOADS
 #define GFFT_SCALE d.scale
-#define GFFT_NEXT_TILE (d.swizzle ? ~0u : k + kstep)
 #include "fft_pow2_body.inc"
-#undef GFFT_NEXT_TILE
 #undef GFFT_TILE_LOOP
 #undef GFFT_TILE_INDEX
 #undef GFFT_AFTER_LOADS

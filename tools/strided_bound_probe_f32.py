@@ -40,7 +40,7 @@ for name, shape, axis in (('C5 stage 1 (512,2048,512) axis 1', (512, 2048, 512),
     tc = timeit(lambda: _lib.check(L.gfft_probe_copy(x.data_ptr(), y.data_ptr(), nbytes, st)))
     row = []
     want = None
-    for v in (0, 10, 11):
+    for v in (0, 10) + ((11,) if os.environ.get('GFFT_PROBE_TOUCH') else ()):       # (11: the touch experiment of round 6, no longer built)
         _lib.set_option('variant_cols', v)
         h = eng.plan_create_guru(4, -1, (n, inner, inner), dims)
         row.append(timeit(lambda: eng.execute_ptr(h, x.data_ptr(), y.data_ptr(), 1.0)))
@@ -50,8 +50,9 @@ for name, shape, axis in (('C5 stage 1 (512,2048,512) axis 1', (512, 2048, 512),
             assert torch.equal(y, want), 'variant 11 differs from the default kernel'
         eng.plan_destroy(h)
     _lib.set_option('variant_cols', 0)
-    print('%-36s kernel %.3f ms (%.0f GB/s)   pattern alone %.3f ms (%.0f GB/s)   copy %.3f ms (%.0f GB/s)   with touches of the next tile %.3f ms (%+.1f %%)' % (
-        name, row[0], 2 * nbytes / row[0] / 1e6, row[1], 2 * nbytes / row[1] / 1e6, tc, 2 * nbytes / tc / 1e6, row[2], 100 * (row[2] / row[0] - 1)), flush=True)
+    extra = '   with touches of the next tile %.3f ms (%+.1f %%)' % (row[2], 100 * (row[2] / row[0] - 1)) if len(row) > 2 else ''
+    print('%-36s kernel %.3f ms (%.0f GB/s)   pattern alone %.3f ms (%.0f GB/s)   copy %.3f ms (%.0f GB/s)%s' % (
+        name, row[0], 2 * nbytes / row[0] / 1e6, row[1], 2 * nbytes / row[1] / 1e6, tc, 2 * nbytes / tc / 1e6, extra), flush=True)
     del want
     del x, y
     torch.cuda.empty_cache()
