@@ -355,6 +355,87 @@ def cpu_baseline(cores, budget_s=None):
         return out
 
 
+def other_configs(_lib, torch):
+    """The other BASELINE configurations as far as ONE GPU can run them, timed in the same process as the headline (HIP events on
+    the launch stream, best of 5 after 2 warm-ups; a few seconds in all) -- so that the driver's own record carries them, not only
+    profiles/.  C1: PFFT 64^3 complex128 forward (the reference's own benchmark size, tests/test_speed.py:15-20).  C2: 64 x 2^20
+    complex128 forward (four-step pair).  C3 / C4 / C5: the per-rank SERIAL stages of the distributed configurations (what one GPU of
+    the grid computes between its exchanges; the exchanges need the grid): C3 on 2 ranks and C4 on the (8,1,1) slab grid as [the two
+    local stages in one fused launch -> far stage], C4 on the (4,2,1) pencil grid as three stand-alone stages, C5's three stages
+    (fp32).  `frac` = SURVEY 8d algorithmic bytes (one read + one write of the local array per transformed axis) / time / 8 TB/s."""
+    from mpi4py_fft_amd import PFFT, comm, fftw, zeros, pipeline as P
+    eng = _lib.engine()
+
+    def best(fn, reps=5, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(reps):
+            s.record(); fn(); e.record(); e.synchronize()
+            ts.append(s.elapsed_time(e))
+        return min(ts)
+
+    def entry(ms, alg_bytes, **kw):
+        return dict(ms=round(ms, 4), frac=round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3), **kw)
+    out = {}
+    # C1
+    f = PFFT(comm.COMM_SELF, (64, 64, 64), dtype='D')
+    ms = best(lambda: [f.forward() for _ in range(50)]) / 50
+    out['C1 PFFT 64^3 c128 forward'] = entry(ms, 6.0 * 64 ** 3 * 16, launches=f._fused_plans[0].cost()[2])
+    f.destroy()
+    # C2
+    a = zeros((64, 1 << 20), 'D')
+    p = fftw.fftn(a, axes=(1,))
+    out['C2 64 x 2^20 c128 forward'] = entry(best(lambda: p.execute_scaled(a, p.output_array, 1.0)), 2.0 * 64 * (1 << 20) * 16,
+                                             launches=p.cost()[2], note='a two-pass transform: 0.50 is its cap')
+    p.destroy()
+    del a
+
+    def slab(tag, prec, N0, N1, N2, pr):
+        isz = 2 * prec
+        cdt = torch.complex128 if prec == 8 else torch.complex64
+        M0, N1b = pr * N0, N1 // pr
+        E = P._pitch(N1b * N2, isz)
+        x = torch.randn(N0 * N1 * N2, dtype=cdt, device='cuda')
+        buf = torch.empty(M0 * E, dtype=cdt, device='cuda')
+        y = torch.empty(M0 * N1b * N2, dtype=cdt, device='cuda')
+        S = N0 * N1 * N2 * isz
+        res = {}
+        for fwd in (True, False):
+            st = P._PairStage((N0, N1, N2), pr, 1, E, fwd, prec)
+            pin, pout = (x, buf) if fwd else (buf, x)
+            res['local pair ' + ('fwd' if fwd else 'bwd')] = entry(best(lambda: st.execute(eng, 0, pin.data_ptr(), pout.data_ptr(), 1.0)), 4.0 * S, launches=st.launches)
+            st.destroy()
+        for kind, name in ((-1, 'fwd'), (+1, 'bwd')):
+            si, so = (E, N1b * N2) if kind < 0 else (N1b * N2, E)
+            h = eng.plan_create_guru(prec, kind, (M0, si, so), [(N1b, N2, N2), (N2, 1, 1)], 1, 0, 1, 0)
+            pin, pout = (buf, y) if kind < 0 else (y, buf)
+            res['far stage ' + name] = entry(best(lambda: eng.execute_ptr(h, pin.data_ptr(), pout.data_ptr(), 1.0)), 2.0 * S)
+            eng.plan_destroy(h)
+        out[tag] = res
+    slab('C3 512^3 c128 on 2 ranks, per rank (256,512,512)', 8, 256, 512, 512, 2)
+    slab('C4 1024^3 c128 on the (8,1,1) grid, per rank (128,1024,1024)', 8, 128, 1024, 1024, 8)
+    torch.cuda.empty_cache()
+
+    def serial(shape, axis, dt):
+        from mpi4py_fft_amd.libfft import FFT
+        f = FFT(shape, axes=(axis,), dtype=dt)
+        tf, tb = best(f.forward), best(f.backward)
+        nin, nout = f.forward.input_array.nbytes, f.forward.output_array.nbytes
+        f.destroy()
+        return dict(fwd=entry(tf, nin + nout), bwd=entry(tb, nin + nout))
+    out['C4 1024^3 c128 on the (4,2,1) grid, per-rank stages'] = {
+        '(256,512,1024) axis 2': serial((256, 512, 1024), 2, 'D'), '(256,1024,512) axis 1': serial((256, 1024, 512), 1, 'D'),
+        '(1024,256,512) axis 0': serial((1024, 256, 512), 0, 'D')}
+    out['C5 2048^3 r2c fp32 on the (4,2,1) grid, per-rank stages'] = {
+        '(512,1024,2048) r2c axis 2': serial((512, 1024, 2048), 2, 'f'), '(512,2048,513) axis 1': serial((512, 2048, 513), 1, 'F'),
+        '(2048,512,513) axis 0': serial((2048, 512, 513), 0, 'F')}
+    torch.cuda.empty_cache()
+    return out
+
+
 def relaunch(args):
     """`python bench.py --gpus N` from a plain shell: one process per GPU under torch.distributed.run.
     The rendezvous is torchrun's own stand-alone one on the loopback address (it binds its store to a
@@ -533,6 +614,7 @@ def main():
     ap.add_argument('--no-slab', action='store_true', help='skip the slab-grid extra at N > 1')
     ap.add_argument('--no-tune', action='store_true', help='skip the measured route choice at N > 1')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--no-configs', action='store_true', help='skip the other BASELINE configurations (one GPU, a few seconds)')
     ap.add_argument('--cpu-budget', type=float, default=None,
                     help='seconds of timed CPU executions for the cpu_baseline leg (default: 300 when the host can hold the 1024^3 sample, else 25)')
     args = ap.parse_args()
@@ -860,6 +942,11 @@ def run(args, guard, state):
                                        'sample': 'failed: %r' % (e,)}
 
     if size == 1:
+        if hip and n == 1024 and not args.no_configs:
+            try:
+                out['other_configs'] = other_configs(_lib, torch)
+            except Exception as e:          # never lose the headline to an extra
+                out['other_configs'] = {'error': repr(e)[:300]}
         print(json.dumps(out), flush=True)
         fft.destroy()
         return
