@@ -453,7 +453,9 @@ AsyncErrors &async_errors() {
 void collect_async_errors(AsyncErrors &a) {
   if (!a.flag) return;
   for (int i = 0; i < AsyncErrors::SLOTS; ++i) {
-    // (one exchange, not load-then-store: a word written between the two would be lost)
+    // (a plain look first -- this runs on entry to every gfft_execute --, then ONE exchange, not load-then-store: a word written
+    // between the two would be lost)
+    if (!__atomic_load_n(a.flag + i, __ATOMIC_RELAXED)) continue;
     const unsigned id = __atomic_exchange_n(a.flag + i, 0u, __ATOMIC_ACQ_REL);
     if (!id) continue;
     auto it = a.live.find(id);
