@@ -273,7 +273,8 @@ class _PairStage:
     natural, both as [strided pass, then rows] -- strided reads, whole rows written.  (The forward pair the other way
     round, its strided pass storing into the blocks, is level in complex128 -- 4.73 against 4.78 ms at (512,1024,1024) --
     and 9 % behind in complex64, profiles/r06_stage_probe_slab.txt; it measured 5.5 ms while the compiler serialised its
-    ring loads, which tools/scan_serial_loads.py found.)  The stage on the far side transforms axis 0 and takes the chunks all at once (_FarStage)."""
+    ring loads, which tools/scan_serial_loads.py found.)  The stage on the far side transforms axis 0 and takes the chunks
+    all at once (_FarStage)."""
     def __init__(self, shape, p, K, E, forward, precision):
         N0, N1, N2 = (int(v) for v in shape)
         N0c = N0 // K
