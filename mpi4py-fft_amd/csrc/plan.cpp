@@ -1906,22 +1906,26 @@ int gfft_plan_create(gfft_plan *plan, int ndims, const int64_t *sizes_in, const 
     // Planes of 32 x 32 / 64 x 64 points -- config C1's 64^3, small images --: rows and columns of a plane in ONE launch with the
     // plane held in LDS (fft_plane2d.hip): such arrays live in the caches and a pass costs its dependent memory round trip, not
     // its bytes (64^3 complex128: three passes of ~5 us each, tools/c1_probe.py); this removes one of them.
-    if (!rc && ndims == 3 && naxes >= 2 && ax[naxes - 2] == 1 && ax[naxes - 1] == 2 && (naxes == 2 || (naxes == 3 && ax[0] == 0)) &&
-        sizes_in[1] == sizes_in[2] && plane2d_supported((int)sizes_in[1], precision) && pl->passes.size() == (size_t)naxes && opts().plane2d) {
+    // (a 2-D array is one plane)
+    const int p0 = ndims - 2;                                // the two in-plane axes: p0, p0 + 1
+    if (!rc && (ndims == 3 || ndims == 2) && naxes >= 2 && ax[naxes - 2] == p0 && ax[naxes - 1] == p0 + 1 &&
+        (naxes == 2 || (ndims == 3 && naxes == 3 && ax[0] == 0)) &&
+        sizes_in[p0] == sizes_in[p0 + 1] && plane2d_supported((int)sizes_in[p0], precision) && pl->passes.size() == (size_t)naxes && opts().plane2d) {
       const Pass &pr = pl->passes[0], &pc = pl->passes[1];
-      if (pr.kind == PK_FFT && pc.kind == PK_FFT && pr.regk && pc.regk && !pr.cols && pc.cols && sizes_in[0] < ((int64_t)1 << 30)) {
-        const int64_t n = sizes_in[1], P = plane2d_pitch((int)n), esz = 2 * (int64_t)precision;
+      const int64_t nplanes = ndims == 3 ? sizes_in[0] : 1;
+      if (pr.kind == PK_FFT && pc.kind == PK_FFT && pr.regk && pc.regk && !pr.cols && pc.cols && nplanes < ((int64_t)1 << 30)) {
+        const int64_t n = sizes_in[p0], P = plane2d_pitch((int)n), esz = 2 * (int64_t)precision;
         Pass f = pr;
         f.kind = PK_PLANE2D;
         f.d = pr.d;                                          // rows of ONE plane: natural rows -> the plane in LDS, rows P entries apart
         f.d.batch = n;  f.d.mid = 1;  f.d.inner = 1;  f.d.in_os = n;  f.d.in_is = 0;  f.d.out_os = P;  f.d.out_is = 0;
         f.d2 = pc.d;                                         // columns of one plane: LDS -> natural rows
         f.d2.batch = n;  f.d2.mid = 1;  f.d2.inner = n;  f.d2.in_os = 0;  f.d2.out_os = 0;  f.d2.in_es = P;  f.d2.in_is = 1;
-        f.fused.planes = (int)sizes_in[0];
+        f.fused.planes = (int)nplanes;
         f.fused.a_in_plane = n * n * esz;
         f.fused.b_out_plane = n * n * esz;
         f.src = BUF_IN;  f.dst = BUF_OUT;
-        f.bytes2 = 4.0 * (double)sizes_in[0] * (double)n * (double)n * (double)esz;
+        f.bytes2 = 4.0 * (double)nplanes * (double)n * (double)n * (double)esz;
         pl->passes.erase(pl->passes.begin(), pl->passes.begin() + 2);
         pl->passes.insert(pl->passes.begin(), f);
       }

@@ -19,7 +19,8 @@ def _plans(shape, axes, dt):
 
 @pytest.mark.parametrize('dt', ['D', 'F'])
 @pytest.mark.parametrize('shape,axes', [((64, 64, 64), (0, 1, 2)), ((32, 32, 32), (0, 1, 2)), ((5, 64, 64), (1, 2)), ((1, 32, 32), (1, 2)),
-                                        ((3000, 32, 32), (1, 2)), ((1100, 64, 64), (1, 2)), ((48, 64, 64), (0, 1, 2)), ((16, 32, 32), (0, 1, 2))])
+                                        ((3000, 32, 32), (1, 2)), ((1100, 64, 64), (1, 2)), ((48, 64, 64), (0, 1, 2)), ((16, 32, 32), (0, 1, 2)),
+                                        ((64, 64), (0, 1)), ((32, 32), (0, 1))])
 def test_planes_on_chip_against_numpy(shape, axes, dt):
     from mpi4py_fft_amd import _lib
     rng = np.random.default_rng(17)
