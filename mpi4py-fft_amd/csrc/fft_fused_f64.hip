@@ -75,6 +75,15 @@ struct Fused512R32 {
   typedef PassCfg<double, 512, 32, 16, true, true, 2 | 8 | 4096 | 8192 | 65536, MODE_C2C, false, 32, 16> ColsFromRingB;
 };
 
+// Unequal pairs (round 6): planes of 512 x 1024 or 1024 x 512 points -- non-cubic grids, e.g. (512,1024,1024) on one rank or as the
+// slabs of a distributed transform.  Both passes share one 512-thread workgroup shape: the n = 1024 side is Fused1024R32's (16 lines
+// per tile), the n = 512 side takes 32 lines per tile (512-byte hand-off segments, the same 256 KiB of values per tile).
+struct Fused512T32 {
+  typedef PassCfg<double, 512, 32, 32, false, true, 2 | 4096 | 8192, MODE_C2C, false, 32, 16> RowsFromRing;
+  typedef PassCfg<double, 512, 32, 32, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 32, 16> ColsToRing;
+  typedef PassCfg<double, 512, 32, 32, true, true, 1 | 8 | 2048 | 8192 | 32768, MODE_C2C, false, 32, 16> ColsToRingB;
+};
+
 // variant: 1 = the default, 32 values per thread / one exchange (Fused1024R32; the round-3 kernels -- 16 values per thread / two
 // exchanges on 1024 threads -- were kept as variant 3 for A/B until round 6: 1024^3 per step 33.4 -> 32.6 ms, C2 0.707 -> 0.677 ms
 // with variant 1, profiles/r04_ab_fuse2_variants.txt); 2 / 4 = (make VARIANTS=1) 8 lines per tile,
@@ -97,9 +106,12 @@ struct Fused896 {
 int g_fuse2_mixv = 1;          // option fuse2_mixv
 
 extern int g_fuse2_n512;
+int g_fuse2_mixed = 1;        // option fuse2_mixed
 bool fused2_supported_f64(int kind, int variant, int n_a, int n_b) {
   (void)kind;
-  if (n_a != n_b) return false;
+  if (n_a != n_b)     // unequal planes: [strided -> rows] only (the 3-D schedule's pair, the slab pair of either direction)
+    return g_fuse2_mixed != 0 && variant == 1 && ((n_a == 512 && n_b == 1024) || (n_a == 1024 && n_b == 512)) &&
+           (kind == FUSED_COLS_ROWS || kind == FUSED_PLANES_CR_B);
   if (n_a == 960 || n_a == 896) return g_fuse2_mixv != 0 && variant == 1 && kind == FUSED_COLS_ROWS;
 #ifdef GFFT_VARIANTS
   if (variant == 2 || variant == 4) return n_a == 1024;
@@ -107,11 +119,17 @@ bool fused2_supported_f64(int kind, int variant, int n_a, int n_b) {
   // (n = 512: measured for the 3-D schedule's pair only -- 512^3 per step 4.82 -> 4.27 ms with 24 planes of 4 MiB ahead,
   // 5.34 ms with 16: profiles/r04_ab_fuse2_n512.txt)
   // (... and the batched 2-D kind, [rows -> strided] on contiguous planes: (256,512,512) axes (1,2) 0.78 -> 0.69 ms, (512,512,512) 1.57 -> 1.34 ms)
+  if (variant == 5) return n_a == 512 && (kind == FUSED_COLS_ROWS || kind == FUSED_PLANES_CR_B);      // the square n = 512 pair on 32 lines per tile (Fused512T32)
   if (variant == 1 && n_a == 512) return g_fuse2_n512 != 0 && (kind == FUSED_COLS_ROWS || kind == FUSED_PLANES_2D || kind == FUSED_PLANES_2D_B || kind == FUSED_PLANES_CR_B);
   if (kind == FUSED_PLANES_2D_B || kind == FUSED_PLANES_CR_B) return variant == 1 && n_a == 1024;
   return variant == 1 && n_a == 1024;
 }
-int g_fuse2_n512 = 1;
+// option fuse2_n512: 0 = no n = 512 pairs, 1 = all of them on Fused512R32 (16 lines per tile, 256 threads, two workgroups per CU), 2 (the default since
+// round 6) = the [strided -> rows] pairs on Fused512T32 instead: 32 lines per tile = 512-byte hand-off segments on 512 threads.  Plans alternating
+// on the same arrays (tools/unequal_pair_probe.py n512, profiles/r06_n512_t32_probe.txt): the slab pair (256,512,512) -- config C3's local stages --
+// 0.683 / 0.702 -> 0.608 / 0.612 ms (0.79 -> 0.88 of 8 TB/s), (512,512,512) over 4 blocks 1.317 / 1.358 -> 1.182 / 1.193 ms; the one-rank 512^3
+// transform level (2.064 / 2.096 -> 2.085 / 2.089 ms).
+int g_fuse2_n512 = 2;
 
 int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &dB, int *tiles_a, int *tiles_b) {
 #ifdef GFFT_VARIANTS
@@ -122,6 +140,11 @@ int fused2_tiles_f64(int kind, int variant, const PassDesc &dA, const PassDesc &
     if (kind != FUSED_COLS_ROWS) return -1;
     *tiles_a = (int)(dA.n == 960 ? Fused960::ColsToRing::ntiles(dA) : Fused896::ColsToRing::ntiles(dA));
     *tiles_b = (int)(dA.n == 960 ? Fused960::RowsFromRing::ntiles(dB) : Fused896::RowsFromRing::ntiles(dB));
+    return 0;
+  }
+  if (dA.n != dB.n || (dA.n == 512 && variant == 5)) {
+    *tiles_a = (int)(dA.n == 512 ? Fused512T32::ColsToRing::ntiles(dA) : Fused1024R32::ColsToRing::ntiles(dA));
+    *tiles_b = (int)(dB.n == 512 ? Fused512T32::RowsFromRing::ntiles(dB) : Fused1024R32::RowsFromRing::ntiles(dB));
     return 0;
   }
   if (kind == FUSED_PLANES_2D_B || kind == FUSED_PLANES_CR_B) {
@@ -142,6 +165,18 @@ hipError_t launch_fused2_f64(int kind, int variant, const PassDesc &dA, const Pa
   if (dA.n == 960 && kind == FUSED_COLS_ROWS) return launch_fused2<Fused960::ColsToRing, Fused960::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s);
   if (dA.n == 896 && kind == FUSED_COLS_ROWS) return launch_fused2<Fused896::ColsToRing, Fused896::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s);
   if (dA.n == 960 || dA.n == 896) return hipErrorInvalidValue;
+  if (dA.n == 512 && dB.n == 512 && variant == 5)
+    return kind == FUSED_PLANES_CR_B ? launch_fused2<Fused512T32::ColsToRingB, Fused512T32::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s)
+                                     : launch_fused2<Fused512T32::ColsToRing, Fused512T32::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s);
+  if (dA.n != dB.n) {
+    if (kind != FUSED_COLS_ROWS && kind != FUSED_PLANES_CR_B) return hipErrorInvalidValue;
+    const bool blk = kind == FUSED_PLANES_CR_B;
+    if (dA.n == 512)
+      return blk ? launch_fused2<Fused512T32::ColsToRingB, Fused1024R32::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s)
+                 : launch_fused2<Fused512T32::ColsToRing, Fused1024R32::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s);
+    return blk ? launch_fused2<Fused1024R32::ColsToRingB, Fused512T32::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s)
+               : launch_fused2<Fused1024R32::ColsToRing, Fused512T32::RowsFromRing>(dA, dB, dev_descs, f, in, ring, out, s);
+  }
   if (kind == FUSED_PLANES_2D_B)
     return dA.n == 512 ? launch_fused2<Fused512R32::RowsToRing, Fused512R32::ColsFromRingB>(dA, dB, dev_descs, f, in, ring, out, s)
                        : launch_fused2<Fused1024R32::RowsToRing, Fused1024R32::ColsFromRingB>(dA, dB, dev_descs, f, in, ring, out, s);

@@ -99,13 +99,30 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
       case 32: return P64F(32, 8, 16, true, 1, 8, 8, 4);
       case 64: return P64F(64, 8, 16, true, 1, 8, 8, 8);
       case 128: return P64F(128, 8, 16, true, 1, 8, 8, 8, 2);
-      case 256: return P64F(256, 8, 16, true, 1, 8, 8, 8, 4);
-      case 512:
+      case 256:
+        // Round 6: 32 values per thread, radices 32 x 8 = ONE exchange, 32 columns = 512-byte segments on 256 threads.  Against the
+        // former default (16; 8 values per thread, radices 8.8.4, 16 columns on 512 threads), plans alternating on the same arrays
+        // (tools/cols_variant_probe.py, profiles/r06_cols_t32_probe.txt): (256,256,256) axis 1 0.105 -> 0.094 ms, axis 0 0.114 -> 0.102 ms,
+        // (1024,256,1024) axis 1 1.704 -> 1.523 ms, (256,1024,1024) axis 0 1.799 -> 1.641 ms.  (64 columns on 512 threads: 1.450 ms on the
+        // third case, slower than the default on the first; the default's radices on 32 columns: slower everywhere.)
+        if (variant == 0 && d.inner % 32 == 0) return P64F(256, 32, 32, true, 2, 8 | 3, 32, 8);
         switch (variant) {
+          default: return P64F(256, 8, 16, true, 1, 8, 8, 8, 4);
+          case 21: return P64F(256, 32, 32, true, 2, 8 | 3, 32, 8);
+        }
+      case 512:
+        // Round 6: on NEAR strides (the line's entries less than 2^16 elements apart: axis 1 of a 3-D array) 32 columns = 512-byte
+        // segments on 512 threads, one workgroup per CU -- the tile shape that the fused pairs of unequal planes showed
+        // (fft_fused_f64.hip Fused512T32): (512,512,512) axis 1 0.831 -> 0.730 ms, (256,512,512) axis 1 0.406 -> 0.387 ms,
+        // (1024,512,1024) axis 1 3.190 -> 2.828 ms.  On FAR strides (axis 0) the same tile LOSES 8 %: (512,512,512) axis 0 0.800 -> 0.865 ms,
+        // (512,256,512) 0.391 -> 0.423 ms -- they keep 16 columns on 256 threads, two workgroups per CU (profiles/r06_cols_t32_probe.txt).
+        if (variant == 0 && d.inner % 32 == 0 && d.in_es < 65536 && d.out_es < 65536) return P64F(512, 32, 32, true, 2, 8 | 3, 32, 16);
+        switch (variant) {
+          case 21: return P64F(512, 32, 32, true, 2, 8 | 3, 32, 16);
           // R4: 32 values per thread, radices 32 x 16 = ONE exchange, 256 threads on 16 columns (two workgroups per CU),
-          // non-temporal loads and stores.  Against the former default (17), same box, tools/variant_cols_probe.py:
-          // (512,512,512) axis 1 0.85-0.88 -> 0.79 ms, axis 0 0.95 -> 0.83 ms; the C3 stage (512,256,512) axis 0 0.47-0.48 ->
-          // 0.40 ms, (256,512,512) axis 1 0.42 -> 0.39-0.41 ms (profiles/r04_variant_cols_r32.txt)
+          // non-temporal loads and stores.  Against the former default (17), same box: (512,512,512) axis 1 0.85-0.88 -> 0.79 ms,
+          // axis 0 0.95 -> 0.83 ms; the C3 stage (512,256,512) axis 0 0.47-0.48 -> 0.40 ms, (256,512,512) axis 1 0.42 ->
+          // 0.39-0.41 ms (profiles/r04_variant_cols_r32.txt)
           default: return P64F(512, 32, 16, true, 2, 8 | 3, 32, 16);
           case 15: return P64F(512, 32, 16, true, 2, 8, 32, 16);         // ... with plain loads and stores
           case 17: return P64F(512, 8, 16, true, 1, 8, 8, 8, 8);         // 8 values per thread, radices 8.8.8, 1024 threads (rounds 1-3; real 3-D schedules)

@@ -582,10 +582,12 @@ bool make_fused2(gfft_plan_s *pl, int kind, const Pass &a, const Pass &b, const 
   if (!fused2_ring(pl->precision, dA.n, dB.n, slot_bytes, planes, &ring, &lag)) return false;
   if (!opts().fuse2 || !((opts().fuse2_kinds >> kind) & 1)) return false;
 #ifdef GFFT_VARIANTS      // (make VARIANTS=1: the 8-lines-per-tile kernel sets, option fuse2 = 2 / 4 -- measured a quarter slower, fft_fused_f64.hip)
-  const int variant = (opts().fuse2 == 2 || opts().fuse2 == 4) ? opts().fuse2 : 1;
+  int variant = (opts().fuse2 == 2 || opts().fuse2 == 4) ? opts().fuse2 : 1;
 #else
-  const int variant = 1;
+  int variant = 1;
 #endif
+  if (variant == 1 && gfft::g_fuse2_n512 == 2 && pl->precision == GFFT_F64 && dA.n == 512 && dB.n == 512 && (kind == FUSED_COLS_ROWS || kind == FUSED_PLANES_CR_B))
+    variant = 5;
   // (complex64 pairs are on by default since round 4 -- option fuse2_f32 = 1, profiles/r04_ab_fuse2_f32.txt; the real fp32
   // pairs measured level with their stand-alone passes and need fuse2_f32 = 2)
   const bool real_kind = kind == FUSED_R2C_PLANES || kind == FUSED_COLS_C2R;
@@ -1580,6 +1582,10 @@ int plan_fused3(gfft_plan_s *pl) {
   // schedules (1024^3 c128 per step 32.85 -> 32.51 ms) and on natural-stride stage arrays, and lose 1.5-3 % here
   // (1024^3 r2c f64 per step 18.76 -> 19.03 / 19.31 ms, profiles/r04_real_pairs.txt)
   if (prec == GFFT_F64 && real && pl->variant_cols == 0) pl->variant_cols = 17;
+  // ... and complex fp64 schedules the round-4 tiles of 16 columns (table variant 16): the 32-column tiles that win 5-12 % on natural-stride
+  // arrays since round 6 (n = 256, n = 512 near strides, fft_pow2_f64.hip) LOSE inside this schedule -- its workspace is laid out in
+  // 16-column tiles and pitched rows --: 512^3 c128 per step 4.159 -> 4.269 ms, 256^3 0.582 -> 0.600 ms (profiles/r06_cols_t32_probe.txt)
+  if (prec == GFFT_F64 && !real && pl->variant_cols == 0) pl->variant_cols = 16;
   // XCD-contiguous tile order for the stand-alone passes of power-of-two schedules (each XCD walks its own eighth of the
   // tiles: neighbouring column chunks of the pitched workspace rows share an L2).  Neutral with the kernels of rounds 1-3
   // (+-0.2 %); with the 512- / 256-thread kernels of round 4, same arrays, plans alternating (profiles/r04_ab_swizzle.txt):
@@ -1807,6 +1813,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "fuse2_n512")) gfft::g_fuse2_n512 = value;
   else if (!strcmp(key, "c2r_2048")) gfft::g_c2r_2048 = value;
   else if (!strcmp(key, "fuse2_mixv")) gfft::g_fuse2_mixv = value;
+  else if (!strcmp(key, "fuse2_mixed")) gfft::g_fuse2_mixed = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "wtile")) opts().wtile = value;

@@ -81,6 +81,85 @@ def test_guru2_plans_against_numpy(dt, n, planes, blocks, pitch, launches, order
     eng.plan_destroy(hb)
 
 
+@pytest.mark.parametrize('n1,n2,planes,blocks,pitch', [(512, 1024, 16, 1, 0), (512, 1024, 20, 4, 32), (1024, 512, 16, 2, 0),
+                                                      (1024, 512, 24, 8, 16)])
+def test_guru2_unequal_planes(n1, n2, planes, blocks, pitch, small_ring):
+    """Planes of n1 x n2 points with n1 != n2 (non-cubic grids): the [strided n1 -> rows n2] pair of either direction as
+    one launch, blocks of the strided axis on the buffer side -- against numpy's fft2 and the round trip."""
+    import torch
+    from mpi4py_fft_amd import _lib
+    eng = _lib.engine()
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((planes, n1, n2)) + 1j * rng.standard_normal((planes, n1, n2))
+    nb = n1 // blocks
+    E = nb * n2 + pitch
+    bstride = planes * E
+    hf = eng.plan_create_guru2(8, -1, (n1, n2, n2), (n2, 1, 1), (planes, n1 * n2, E), True, 1, 0, blocks, bstride)
+    hb = eng.plan_create_guru2(8, +1, (n1, n2, n2), (n2, 1, 1), (planes, E, n1 * n2), True, blocks, bstride, 1, 0)
+    assert hf is not None and hb is not None
+    assert eng.plan_cost(hf)[2] == 1 and eng.plan_cost(hb)[2] == 1, (eng.plan_describe(hf), eng.plan_describe(hb))
+    a = torch.from_numpy(x).cuda()
+    buf = torch.full((blocks * bstride,), float('nan'), dtype=torch.complex128, device='cuda')
+    eng.execute_ptr(hf, a.data_ptr(), buf.data_ptr(), 1.0 / (n1 * n2))
+    torch.cuda.synchronize()
+    _lib.check_async()
+    got = buf.cpu().numpy().reshape(blocks, planes, E)
+    want = np.fft.fft2(x, axes=(1, 2)) / (n1 * n2)
+    tol = cases.rounding_tol('D', n1 * n2)
+    for j in range(blocks):
+        blk = got[j, :, :nb * n2].reshape(planes, nb, n2)
+        err = np.abs(blk - want[:, j * nb:(j + 1) * nb]).max() / np.abs(want).max()
+        assert err <= tol, (j, err, tol)
+        if pitch:
+            assert np.isnan(got[j, :, nb * n2:].real).all()
+    back = torch.full((planes, n1, n2), float('nan'), dtype=torch.complex128, device='cuda')
+    eng.execute_ptr(hb, buf.data_ptr(), back.data_ptr(), 1.0)
+    torch.cuda.synchronize()
+    _lib.check_async()
+    rt = np.linalg.norm(back.cpu().numpy() - x) / np.linalg.norm(x)
+    assert rt <= tol, (rt, tol)
+    # the same plans as two stand-alone launches: the two forms agree to rounding
+    _lib.set_option('fuse2_mixed', 0)
+    try:
+        h2 = eng.plan_create_guru2(8, -1, (n1, n2, n2), (n2, 1, 1), (planes, n1 * n2, E), True, 1, 0, blocks, bstride)
+        assert eng.plan_cost(h2)[2] == 2
+        buf2 = torch.full((blocks * bstride,), float('nan'), dtype=torch.complex128, device='cuda')
+        eng.execute_ptr(h2, a.data_ptr(), buf2.data_ptr(), 1.0 / (n1 * n2))
+        torch.cuda.synchronize()
+        g2 = buf2.cpu().numpy().reshape(blocks, planes, E)[:, :, :nb * n2]
+        assert np.abs(g2 - got[:, :, :nb * n2]).max() / np.abs(want).max() <= tol
+        eng.plan_destroy(h2)
+    finally:
+        _lib.set_option('fuse2_mixed', 1)
+    eng.plan_destroy(hf)
+    eng.plan_destroy(hb)
+
+
+@pytest.mark.parametrize('shape', [(512, 16, 1024), (1024, 20, 512)])
+def test_one_rank_3d_with_unequal_axes_fuses_its_last_two_passes(shape, small_ring):
+    """fftn of a non-cubic array on one rank: axis 1 alone, then [axis 0 -> rows of axis 2] as one launch although
+    n0 != n2 -- against numpy."""
+    import torch
+    from mpi4py_fft_amd import _lib
+    eng = _lib.engine()
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    want = np.fft.fftn(x)
+    tol = cases.rounding_tol('D', x.size)
+    for kind, ref in ((-1, want), (+1, np.conj(np.fft.fftn(np.conj(x))))):
+        h = eng.plan_create(list(shape), list(shape), [0, 1, 2], kind, 8)
+        desc = eng.plan_describe(h)
+        assert eng.plan_cost(h)[2] == 2 and 'fused pair' in desc, desc
+        a = torch.from_numpy(x).cuda()
+        out = torch.empty_like(a)
+        eng.execute_ptr(h, a.data_ptr(), out.data_ptr(), 1.0)
+        torch.cuda.synchronize()
+        _lib.check_async()
+        err = np.abs(out.cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert err <= tol, (kind, err, tol)
+        eng.plan_destroy(h)
+
+
 def test_guru2_refusals():
     from mpi4py_fft_amd import _lib
     eng = _lib.engine()

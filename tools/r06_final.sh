@@ -2,7 +2,7 @@
 mkdir -p gpurun_out/r06z
 (timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8) > gpurun_out/r06z/gputests.txt; cat gpurun_out/r06z/gputests.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -6 > gpurun_out/r06z/smoke.txt
-bash tools/prof.sh r06_bench python bench.py --steps 6 --warmup 2 --no-cpu > gpurun_out/r06z/prof_bench.log 2>&1
+bash tools/prof.sh r06_bench python bench.py --steps 6 --warmup 2 --no-cpu --no-configs > gpurun_out/r06z/prof_bench.log 2>&1
 timeout 600 python bench.py --no-cpu > gpurun_out/r06z/bench_plain.json 2> gpurun_out/r06z/bench_plain.err
 timeout 1500 python bench.py > gpurun_out/r06z/bench_plain_cpu.json 2> gpurun_out/r06z/bench_plain_cpu.err
 timeout 900 python tools/survey.py > gpurun_out/r06z/survey.txt 2>&1
