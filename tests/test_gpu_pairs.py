@@ -190,7 +190,8 @@ def fake_rccl():
 
 
 @pytest.mark.parametrize('P,shape,dt', [(2, (32, 512, 512), 'D'), (4, (64, 512, 512), 'D'), (8, (128, 512, 512), 'D'),
-                                        (2, (32, 1024, 1024), 'D'), (2, (32, 1024, 1024), 'F')])
+                                        (2, (32, 1024, 1024), 'D'), (2, (32, 1024, 1024), 'F'),
+                                        (2, (32, 512, 1024), 'D'), (4, (64, 1024, 512), 'D')])          # (unequal planes)
 def test_slab_grid_runs_its_local_stages_as_one_launch(P, shape, dt, small_ring, fake_rccl, monkeypatch):
     """PFFT on a slab grid: staged with the pair, staged stage by stage (fuse_pairs=False), pipelined with the pair per
     chunk of planes -- against the oracle, each other and the round trip."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool (round 6): randomised stress of the fused slab pairs (gfft_plan_create_guru2, PFFT._fuse_pairs, pipeline._PairStage) on
-one GPU with thread-ranks, against the oracle at rounding level: slab grids of 2 / 4 / 8 ranks, planes of 512^2 / 1024^2, complex128
+one GPU with thread-ranks, against the oracle at rounding level: slab grids of 2 / 4 / 8 ranks, planes of 512^2 / 1024^2 / 512 x 1024 / 1024 x 512, complex128
 and complex64, staged and pipelined wires, 1-4 chunks of planes, packed and natural exchange buffers, short hand-off rings so that
 launches of 8 planes already fuse.   usage: stress_pairs.py <seed> <seconds>"""
 import os, sys, time
@@ -24,10 +24,10 @@ rng = np.random.default_rng(seed)
 t0, done, fused = time.time(), 0, 0
 while time.time() - t0 < budget:
     P = int(rng.choice([2, 4, 8]))
-    n = int(rng.choice([512, 512, 1024]))
-    dt = 'D' if n == 512 else str(rng.choice(['D', 'F']))
+    n, n2 = [(512, 512), (512, 512), (1024, 1024), (512, 1024), (1024, 512)][int(rng.integers(5))]      # (axis 1, axis 2) of the local planes
+    dt = 'D' if (n, n2) != (1024, 1024) else str(rng.choice(['D', 'F']))
     planes = int(rng.choice([4, 8, 8, 12, 16, 16, 24]))               # per rank
-    if P * planes * n * n > 72_000_000:
+    if P * planes * n * n2 > 72_000_000:
         continue
     ring = int(rng.choice([4, 6, 8]))
     _lib.set_option('fuse2_ring', ring)
@@ -36,7 +36,7 @@ while time.time() - t0 < budget:
     os.environ['GFFT_WIRE'] = str(rng.choice(['torch', 'native', 'native']))
     os.environ['GFFT_FUSE_PAIRS'] = str(rng.choice(['1', '1', '1', '0']))
     pipeline.Pipeline.CHUNKS = int(rng.choice([1, 2, 3, 4]))
-    shape = (P * planes, n, n)
+    shape = (P * planes, n, n2)
 
     def probe(comm):
         f = PFFT(comm, shape, dtype=dt, grid=[P, 1, 1])
