@@ -77,7 +77,7 @@ int gfft_device_name(int device, char *buf, size_t len);
  * planes the producer runs ahead; 0 = auto: about 96 MiB of lead and twice that of ring -- 12 / 6 planes of 16 MiB, 24 / 12 of
  * 8 MiB, 48 / 24 of 4 MiB --, launches with too few planes for that stay unfused), "fuse2_kinds" (bit mask of pair kinds:
  * 2 strided->rows, 4 / 16 four-step, 8 batched 2-D, 32 r2c rows->strided, 64 strided->c2r rows), "fuse2_f32" (1: complex64
- * pairs, 2: real fp32 pairs too), "fuse2_n512" (the n = 512 pairs: 0 off, 1 on 16 lines per tile, 2 [strided -> rows] on 32), "fuse2_mixed" (pairs on planes of 512 x 1024 / 1024 x 512 points), "fuse2_wait_ms" (wall-clock limit of a wait inside a fused
+ * pairs, 2: real fp32 pairs too), "fuse2_n512" (the n = 512 pairs: 0 off, 1 on 16 lines per tile, 2 [strided -> rows] on 32), "fuse2_mixed" (pairs on planes of 512 x 1024 / 1024 x 512 points), "fuse2_f32_n512" (the complex64 n = 512 pairs), "fuse2_wait_ms" (wall-clock limit of a wait inside a fused
  * launch before the launch voids itself, gfft_async_error below; default 2000); GFFT_FUSE2_DEBUG=1 prints a fused
  * launch's counters.  ("debug_tw_index" / "debug_tw_exp": TEST HOOK -- twiddle tables uploaded while debug_tw_exp > 0
  * carry one entry off by 10^-debug_tw_exp: what the rounding-level guards of tests/ must catch.) */

@@ -30,12 +30,32 @@ struct Fused1024F32 {
   typedef PassCfg<float, 1024, 32, 32, true, true, 2 | 8 | 4096 | 8192 | 65536, MODE_C2C, false, 16, 16, 4> ColsFromRingB;
 };
 
+// Round 6: n = 512, [strided -> rows], both tiles on 32 values per thread / radices 32 x 16 = ONE exchange, 512 threads of up to 256 VGPRs (167, no
+// spills): 32 columns (256-byte hand-off segments) and 32 rows (16 lanes per row: the exchange stays inside the wave) -- 128 KiB either tile.
+// Plans alternating on the same arrays (tools/unequal_pair_probe.py f32n512, profiles/r06_f32_n512_pair_probe.txt): slab pairs (256,512,512)
+// 0.397 / 0.392 -> 0.359 / 0.368 ms, (1024,512,512) over 8 blocks 1.743 / 1.660 -> 1.374 / 1.424 ms (0.62 -> 0.78 of 8 TB/s); 512^3 c64 per
+// fwd + bwd step 2.436 -> 2.172 ms.  (First form, not kept: 8 rows per tile with a row inside one wave on 8 values per thread -- 32 KiB row
+// tiles, four times the tickets: the pair LOST 5-26 %.)  Option fuse2_f32_n512.
+struct Fused512F32 {
+  typedef PassCfg<float, 512, 32, 32, true, true, 1 | 8 | 2048 | 8192, MODE_C2C, false, 32, 16> ColsToRing;
+  typedef PassCfg<float, 512, 32, 32, true, true, 1 | 8 | 2048 | 8192 | 32768, MODE_C2C, false, 32, 16> ColsToRingB;
+  typedef PassCfg<float, 512, 32, 32, false, false, 2 | 4096 | 8192, MODE_C2C, false, 32, 16> RowsFromRing;
+};
+int g_fuse2_f32_n512 = 1;
+
 bool fused2_supported_f32(int kind, int n_a, int n_b) {
+  if (n_a == 512 && n_b == 512) return g_fuse2_f32_n512 != 0 && (kind == FUSED_COLS_ROWS || kind == FUSED_PLANES_CR_B);
   if (n_a != 1024 || n_b != 1024) return false;
   return kind == FUSED_COLS_ROWS || kind == FUSED_FOURSTEP || kind == FUSED_PLANES_2D || kind == FUSED_PLANES_2D_B || kind == FUSED_PLANES_CR_B;
 }
 
 int fused2_tiles_f32(int kind, const PassDesc &dA, const PassDesc &dB, int *ta, int *tb) {
+  if (dA.n == 512) {
+    if (kind != FUSED_COLS_ROWS && kind != FUSED_PLANES_CR_B) return -1;
+    *ta = (int)Fused512F32::ColsToRing::ntiles(dA);
+    *tb = (int)Fused512F32::RowsFromRing::ntiles(dB);
+    return 0;
+  }
   switch (kind) {
     case FUSED_COLS_ROWS: *ta = (int)ColsToRingF32::ntiles(dA); *tb = (int)RowsFromRingF32::ntiles(dB); return 0;
     case FUSED_FOURSTEP: *ta = (int)Fused1024F32::FourStepFirst::ntiles(dA); *tb = (int)Fused1024F32::ColsFromRing::ntiles(dB); return 0;
@@ -48,6 +68,11 @@ int fused2_tiles_f32(int kind, const PassDesc &dA, const PassDesc &dB, int *ta, 
 
 hipError_t launch_fused2_f32(int kind, const PassDesc &dA, const PassDesc &dB, const PassDesc *dev, const FusedDesc &f,
                              const void *in, void *ring, void *out, hipStream_t s) {
+  if (dA.n == 512) {
+    if (kind == FUSED_COLS_ROWS) return launch_fused2<Fused512F32::ColsToRing, Fused512F32::RowsFromRing>(dA, dB, dev, f, in, ring, out, s);
+    if (kind == FUSED_PLANES_CR_B) return launch_fused2<Fused512F32::ColsToRingB, Fused512F32::RowsFromRing>(dA, dB, dev, f, in, ring, out, s);
+    return hipErrorInvalidValue;
+  }
   switch (kind) {
     case FUSED_COLS_ROWS: return launch_fused2<ColsToRingF32, RowsFromRingF32>(dA, dB, dev, f, in, ring, out, s);
     case FUSED_FOURSTEP: return launch_fused2<Fused1024F32::FourStepFirst, Fused1024F32::ColsFromRing>(dA, dB, dev, f, in, ring, out, s);

@@ -1275,7 +1275,7 @@ __device__ __forceinline__ void fused_wait(const unsigned *flag, unsigned want, 
 // then) allow it, else one -- which may use 256 VGPRs per thread when it has at most 512 threads
 template <typename A, typename B> constexpr int fused2_per_cu() {
   constexpr size_t lds = A::lds > B::lds ? A::lds : B::lds;
-  constexpr int budget = (A::regs_per_thread > 64 || B::regs_per_thread > 64) ? 256 : 128;       // VGPRs per thread the tiles want
+  constexpr int budget = (A::regs_per_thread >= 64 || B::regs_per_thread >= 64) ? 256 : 128;     // VGPRs per thread the tiles want (64 of values alone: a radix-32 stage spills under 128)
   return (2 * A::threads / 256 * budget <= 512 && 2 * lds + 1024 <= 160 * 1024) ? 2 : 1;
 }
 // (workgroups of <= 512 threads: two per CU -- one computes while the other loads / stores --, which the

@@ -187,6 +187,7 @@ enum FusedKind { FUSED_ROWS_COLS = 0, FUSED_COLS_ROWS = 1, FUSED_FOURSTEP = 2, F
 // kernels (16 values per thread, two exchanges, 1024 threads); 2 / 4 = (make VARIANTS=1) 8 lines per tile, two workgroups per CU
 extern int g_fuse2_n512;           // option fuse2_n512: the n = 512 pairs (fft_fused_f64.hip)
 extern int g_fuse2_mixed;          // option fuse2_mixed: pairs on planes of 512 x 1024 / 1024 x 512 points (fft_fused_f64.hip)
+extern int g_fuse2_f32_n512;       // option fuse2_f32_n512: the complex64 n = 512 pairs (fft_fused_f32.hip)
 extern int g_fuse2_mixv;           // option fuse2_mixv: the 3-D pair on n = 960 / 896 (fft_fused_f64.hip)
 extern int g_c2r_2048;             // option c2r_2048: the c2r pair on rows of 2048 reals (fft_fused_real_f64.hip)
 bool fused2_supported_f64(int kind, int variant, int n_a, int n_b);

@@ -1814,6 +1814,7 @@ int gfft_set_option(const char *key, int value) {
   else if (!strcmp(key, "c2r_2048")) gfft::g_c2r_2048 = value;
   else if (!strcmp(key, "fuse2_mixv")) gfft::g_fuse2_mixv = value;
   else if (!strcmp(key, "fuse2_mixed")) gfft::g_fuse2_mixed = value;
+  else if (!strcmp(key, "fuse2_f32_n512")) gfft::g_fuse2_f32_n512 = value;
   else if (!strcmp(key, "debug_flat")) opts().debug_flat = value;
   else if (!strcmp(key, "flat_out")) opts().flat_out = value;
   else if (!strcmp(key, "wtile")) opts().wtile = value;

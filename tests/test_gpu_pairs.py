@@ -33,8 +33,8 @@ def small_ring():
 
 @pytest.mark.parametrize('dt,n,planes,blocks,pitch,launches', [
     ('D', 1024, 16, 1, 0, 1), ('D', 1024, 16, 2, 0, 1), ('D', 1024, 20, 8, 48, 1), ('D', 512, 24, 4, 16, 1), ('D', 512, 16, 1, 0, 1),
-    ('F', 1024, 16, 2, 0, 1), ('F', 1024, 24, 8, 32, 1),
-    ('D', 256, 16, 4, 16, 2), ('F', 512, 16, 2, 0, 2), ('D', 1024, 6, 2, 0, 2),       # no fused kernels / too few planes: two launches
+    ('F', 1024, 16, 2, 0, 1), ('F', 1024, 24, 8, 32, 1), ('F', 512, 16, 2, 0, 1), ('F', 512, 24, 8, 16, 1),
+    ('D', 256, 16, 4, 16, 2), ('F', 256, 16, 2, 0, 2), ('D', 1024, 6, 2, 0, 2),       # no fused kernels / too few planes: two launches
 ])
 @pytest.mark.parametrize('order', ['cols-first', 'rows-first'])
 def test_guru2_plans_against_numpy(dt, n, planes, blocks, pitch, launches, order, small_ring):
@@ -55,6 +55,8 @@ def test_guru2_plans_against_numpy(dt, n, planes, blocks, pitch, launches, order
     hf = eng.plan_create_guru2(prec, -1, (n, n, n), (n, 1, 1), (planes, n * n, E), cf, 1, 0, blocks, bstride)
     hb = eng.plan_create_guru2(prec, +1, (n, n, n), (n, 1, 1), (planes, E, n * n), cf, blocks, bstride, 1, 0)
     assert hf is not None and hb is not None
+    if dt == 'F' and n == 512 and not cf:
+        launches = 2                         # (the complex64 n = 512 pair exists as [strided -> rows] only)
     assert eng.plan_cost(hf)[2] == launches and eng.plan_cost(hb)[2] == launches, (eng.plan_describe(hf), eng.plan_describe(hb))
     a = torch.from_numpy(x).cuda()
     buf = torch.full((blocks * bstride,), float('nan'), dtype=cdt, device='cuda')
@@ -191,7 +193,8 @@ def fake_rccl():
 
 @pytest.mark.parametrize('P,shape,dt', [(2, (32, 512, 512), 'D'), (4, (64, 512, 512), 'D'), (8, (128, 512, 512), 'D'),
                                         (2, (32, 1024, 1024), 'D'), (2, (32, 1024, 1024), 'F'),
-                                        (2, (32, 512, 1024), 'D'), (4, (64, 1024, 512), 'D')])          # (unequal planes)
+                                        (2, (32, 512, 1024), 'D'), (4, (64, 1024, 512), 'D'),           # (unequal planes)
+                                        (2, (32, 512, 512), 'F')])
 def test_slab_grid_runs_its_local_stages_as_one_launch(P, shape, dt, small_ring, fake_rccl, monkeypatch):
     """PFFT on a slab grid: staged with the pair, staged stage by stage (fuse_pairs=False), pipelined with the pair per
     chunk of planes -- against the oracle, each other and the round trip."""

@@ -46,7 +46,14 @@ def ab(label, make, a, b, alg_bytes):
         eng.plan_destroy(h)
 
 
-if len(sys.argv) > 1 and sys.argv[1] == 'n512':
+PREC, CDT, ISZ = 8, torch.complex128, 16
+if len(sys.argv) > 1 and sys.argv[1] == 'f32n512':
+    # the complex64 n = 512 pair (option fuse2_f32_n512) against two launches
+    OPT, VALS, REST = 'fuse2_f32_n512', (0, 1), 1
+    PREC, CDT, ISZ = 4, torch.complex64, 8
+    SHAPES = [(512, 512, 512), (1024, 512, 512)]
+    SLABS = [(256, 512, 512, 2), (512, 512, 512, 4), (1024, 512, 512, 8)]
+elif len(sys.argv) > 1 and sys.argv[1] == 'n512':
     # the SQUARE n = 512 pair: 16 lines per tile on 256 threads, two workgroups per CU (option fuse2_n512 = 1) against 32 lines per
     # tile on 512 threads, one per CU (= 2, the tile shape of the unequal pairs)
     OPT, VALS, REST = 'fuse2_n512', (1, 2), 2
@@ -57,22 +64,22 @@ else:
     SLABS = [(256, 512, 1024, 2), (128, 512, 1024, 8), (256, 1024, 512, 2), (128, 1024, 512, 8)]
 
 for shape in SHAPES + 0 * [(512, 512, 1024), (512, 1024, 1024), (1024, 512, 512), (1024, 1024, 512), (512, 1024, 512), (1024, 512, 1024)]:
-    a = torch.empty(shape, dtype=torch.complex128, device='cuda')
+    a = torch.empty(shape, dtype=CDT, device='cuda')
     torch.view_as_real(a).normal_()
     b = torch.empty_like(a)
-    nbytes = a.numel() * 16
+    nbytes = a.numel() * ISZ
     for kind, name in ((-1, 'fwd'), (+1, 'bwd')):
-        ab('fftn %s c128 %s' % (shape, name), lambda: eng.plan_create(list(shape), list(shape), [0, 1, 2], kind, 8), a, b, 6 * nbytes)
+        ab('fftn %s %s %s' % (shape, 'c128' if PREC == 8 else 'c64', name), lambda: eng.plan_create(list(shape), list(shape), [0, 1, 2], kind, PREC), a, b, 6 * nbytes)
     del a, b
 
 for planes, n1, n2, p in SLABS:
-    a = torch.empty((planes, n1, n2), dtype=torch.complex128, device='cuda')
+    a = torch.empty((planes, n1, n2), dtype=CDT, device='cuda')
     torch.view_as_real(a).normal_()
     E = (n1 // p) * n2
-    buf = torch.empty((p * planes * E,), dtype=torch.complex128, device='cuda')
-    nbytes = a.numel() * 16
+    buf = torch.empty((p * planes * E,), dtype=CDT, device='cuda')
+    nbytes = a.numel() * ISZ
     ab('slab pair (%d,%d,%d) p=%d fwd' % (planes, n1, n2, p),
-       lambda: eng.plan_create_guru2(8, -1, (n1, n2, n2), (n2, 1, 1), (planes, n1 * n2, E), True, 1, 0, p, planes * E), a, buf, 4 * nbytes)
+       lambda: eng.plan_create_guru2(PREC, -1, (n1, n2, n2), (n2, 1, 1), (planes, n1 * n2, E), True, 1, 0, p, planes * E), a, buf, 4 * nbytes)
     ab('slab pair (%d,%d,%d) p=%d bwd' % (planes, n1, n2, p),
-       lambda: eng.plan_create_guru2(8, +1, (n1, n2, n2), (n2, 1, 1), (planes, E, n1 * n2), True, p, planes * E, 1, 0), buf, a, 4 * nbytes)
+       lambda: eng.plan_create_guru2(PREC, +1, (n1, n2, n2), (n2, 1, 1), (planes, E, n1 * n2), True, p, planes * E, 1, 0), buf, a, 4 * nbytes)
     del a, buf
