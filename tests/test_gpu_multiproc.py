@@ -11,6 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize('nranks,port', [(2, 29551), (4, 29552), (8, 29553)])
 def test_pfft_across_processes_on_one_gpu(nranks, port):
+    # (the workers share the GPU with this process: hand back what earlier tests left in torch's cache and libgfft's workspaces)
+    import gc
+    import torch
+    from mpi4py_fft_amd import _lib
+    gc.collect()
+    torch.cuda.empty_cache()
+    _lib.lib().gfft_scratch_release()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nranks),
            '--master-addr', '127.0.0.1', '--master-port', str(port),
            os.path.join(ROOT, 'tests', 'gpu_multiproc_worker.py')]

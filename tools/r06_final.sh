@@ -1,6 +1,6 @@
 # round 6, final code: the GPU suite, smoke, the headline under rocprofv3 (four passes) and plain, survey, stage probes, stress
 mkdir -p gpurun_out/r06z
-(timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8) > gpurun_out/r06z/gputests.txt; cat gpurun_out/r06z/gputests.txt
+(timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -150) > gpurun_out/r06z/gputests.txt; tail -8 gpurun_out/r06z/gputests.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -6 > gpurun_out/r06z/smoke.txt
 bash tools/prof.sh r06_bench python bench.py --steps 6 --warmup 2 --no-cpu --no-configs > gpurun_out/r06z/prof_bench.log 2>&1
 timeout 600 python bench.py --no-cpu > gpurun_out/r06z/bench_plain.json 2> gpurun_out/r06z/bench_plain.err
