@@ -20,14 +20,24 @@ bool pow2_supported_f32(int n) { return n >= 16 && n <= 4096 && (n & (n - 1)) ==
 hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void *in, void *out,
                            hipStream_t s) {
   if (!cols) {
+    // (the non-temporal kernels below: plain complex passes over arrays that do not fit the Infinity Cache -- on 128 MiB of traffic they LOSE 10-30 %)
+    const bool plain = variant == 0 && d.mode == MODE_C2C && !d.tw_hi && !d.tr_dir && 2.0 * (double)d.batch * d.n * sizeof(float) * 2 >= 268435456.0;
     switch (d.n) {
       case 16: return P32(16, 4, 16, false, false, 1, 4, 4);
       case 32: return P32(32, 8, 16, false, false, 1, 8, 4);
       case 64: return P32(64, 8, 8, false, false, 1, 8, 8);
       case 128: return P32(128, 8, 4, false, false, 1, 8, 8, 2);
       case 256: return P32(256, 16, 4, false, false, 1, 16, 16);
-      case 512: return P32(512, 8, 1, false, false, 1, 8, 8, 8);
-      case 1024: return P32(1024, 16, 1, false, false, 1, 16, 16, 4);
+      // Round 6 (as fft_pow2_f64.hip): plain complex row passes with non-temporal loads and stores; n = 512 on 16 values per thread, 8 rows per 256
+      // threads (512^3 0.401 -> 0.359 ms, (2048,512,512) 1.667 -> 1.535 ms; ONE exchange -- 32 values per thread -- level on the large array, +8 % on
+      // 512^3), n = 1024 on 4 rows per workgroup instead of 1 ((512,1024,1024) 1.678 -> 1.518 ms); n = 2048 level (profiles/r06_rows_probe.txt).
+      // variant 16 = the former table.
+      case 512:
+        if (plain) return P32F(512, 16, 8, false, false, 1, 8 | 3, 16, 8, 4);
+        return P32(512, 8, 1, false, false, 1, 8, 8, 8);
+      case 1024:
+        if (plain) return P32F(1024, 16, 4, false, false, 1, 8 | 3, 16, 16, 4);
+        return P32(1024, 16, 1, false, false, 1, 16, 16, 4);
       case 2048: return P32(2048, 16, 1, false, false, 1, 16, 16, 8);
       case 4096: return P32(4096, 16, 1, false, false, 1, 16, 16, 16);
     }
@@ -102,7 +112,7 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
         // (64 columns: 21 / 23 below, behind except on the smallest array.)  Odd widths keep the three-stage tile: see n = 512.
         // Inside one-rank 3-D schedules (plan_fused3 asks for variant 2 there) too: 256^3 c64 per step 0.363 -> 0.320 ms; the n = 512 lines of
         // such schedules keep variant 2 (512^3 c64: 2.442 ms against 2.547 with this tile shape).
-        if ((variant == 0 || variant == 2) && d.inner % 32 == 0) return P32F(256, 32, 32, true, true, 2, 8 | 3, 32, 8);
+        if ((variant == 0 || variant == 2) && d.inner % 32 == 0 && 2.0 * (double)d.batch * 256 * 8 >= 268435456.0) return P32F(256, 32, 32, true, true, 2, 8 | 3, 32, 8);      // (non-temporal: arrays beyond the Infinity Cache)
         switch (variant) {
           default: return P32F(256, 8, 32, true, false, 1, 8, 8, 8, 4);
           case 21: return P32F(256, 32, 64, true, true, 2, 8 | 3, 32, 8);     // R6 A/B: one exchange, 64 columns = 512-byte segments, 512 threads
@@ -117,7 +127,7 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
         // 0.435 / 0.449 ms, (1024,512,1024) axis 1 1.862 -> 1.795 ms, (512,1024,1024) axis 0 2.409 -> 2.080 ms -- where rows are whole
         // multiples of the tile.  On 513-wide rows (the half spectra of real transforms) it LOSES: (2048,512,513) axis 1 2.353 -> 2.936 ms.
         // (64 columns = 512-byte segments on 1024 threads, 21: behind the default everywhere.)
-        if (variant == 0 && d.inner % 32 == 0) return P32F(512, 32, 32, true, true, 2, 8 | 3, 32, 16);
+        if (variant == 0 && d.inner % 32 == 0 && 2.0 * (double)d.batch * 512 * 8 >= 268435456.0) return P32F(512, 32, 32, true, true, 2, 8 | 3, 32, 16);
         switch (variant) {
           default: return P32F(512, 16, 32, true, true, 1, 8, 16, 8, 4);
           case 21: return P32F(512, 32, 64, true, true, 1, 8 | 3, 32, 16);    // R6 A/B: one exchange, 64 columns = 512-byte segments, 1024 threads

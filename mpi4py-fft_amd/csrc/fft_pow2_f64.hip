@@ -19,19 +19,32 @@ bool pow2_supported_f64(int n) { return n >= 16 && n <= 4096 && (n & (n - 1)) ==
 hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void *in, void *out,
                            hipStream_t s) {
   if (!cols) {
+    // (the non-temporal kernels below: plain complex passes over arrays that do not fit the Infinity Cache -- on 128 MiB of traffic they LOSE 10 %)
+    const bool plain = variant == 0 && d.mode == MODE_C2C && !d.tw_hi && !d.tr_dir && 2.0 * (double)d.batch * d.n * sizeof(double) * 2 >= 268435456.0;
     switch (d.n) {
       case 16: return P64(16, 4, 16, false, 1, 4, 4);
       case 32: return P64(32, 8, 16, false, 1, 8, 4);
       case 64: return P64(64, 8, 8, false, 1, 8, 8);
       case 128: return P64(128, 8, 4, false, 1, 8, 8, 2);
-      case 256: return P64(256, 8, 8, false, 1, 8, 8, 4);
-      case 512: return P64(512, 8, 4, false, 1, 8, 8, 8);
+      // Round 6: row passes with NON-TEMPORAL loads and stores (the arrays are streamed once: nothing to keep in L2 / Infinity Cache), and at
+      // n = 512 / 1024 on 32 values per thread = ONE exchange inside the wave (16 / 8 rows per 256 threads).  Plans alternating on the same
+      // arrays (tools/cols_variant_probe.py with PROBE_OPT=variant_rows, profiles/r06_rows_probe.txt): n = 1024 (256,512,1024) -- config C4's
+      // first stage on 8 GPUs -- 0.777 -> 0.722 ms, 1024^3 6.58 -> 6.33 ms; n = 512 512^3 0.789 -> 0.729 ms; n = 256 256^3 0.099 -> 0.088 ms,
+      // n = 2048 (256,512,2048) 1.534 -> 1.420 ms (these two on the table's radices: one exchange measured behind there).  variant 16 = the
+      // former table.
+      case 256:
+        if (plain) return P64F(256, 8, 8, false, 1, 8 | 3, 8, 8, 4);
+        return P64(256, 8, 8, false, 1, 8, 8, 4);
+      case 512:
+        if (plain) return P64F(512, 32, 16, false, 2, 8 | 3, 32, 16);
+        return P64(512, 8, 4, false, 1, 8, 8, 8);
       case 1024:
         // fused zero-padding on load / truncation on store: the lean plan (measured on the padded
         // 683^3 -> 1024^3 backward row pass: 8.4 ms with R = 16, 6.7 ms with R = 8)
         if (d.tr_dir && variant == 0) return P64(1024, 8, 2, false, 1, 8, 8, 8, 2);
+        if (plain) return P64F(1024, 32, 8, false, 2, 8 | 3, 32, 32);        // one exchange inside the wave, 8 rows / 256 threads, non-temporal
         switch (variant) {
-          default: return P64(1024, 16, 4, false, 1, 16, 16, 4);   // 4 rows / 256 threads, 2 exchanges
+          default: return P64(1024, 16, 4, false, 1, 16, 16, 4);   // 4 rows / 256 threads, 2 exchanges (the table through round 5; fused truncation / padding, r2c / c2r)
           // (R4: 32 values per thread / ONE exchange inside the wave, 8 rows per 256 threads, was measured too: level --
           // (256,512,1024) axis 2 0.745-0.776 against 0.760-0.764 ms; row passes already run at the copy rate)
 #ifdef GFFT_VARIANTS   // measured alternatives (make VARIANTS=1): not in the shipped library
@@ -45,7 +58,9 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
 #endif
           case 3: return P64(1024, 8, 2, false, 1, 8, 8, 8, 2);   // (= the lean plan the fused truncation / padding uses: no extra kernels)
         }
-      case 2048: return P64(2048, 16, 2, false, 1, 16, 16, 8);
+      case 2048:
+        if (plain) return P64F(2048, 16, 2, false, 1, 8 | 3, 16, 16, 8);
+        return P64(2048, 16, 2, false, 1, 16, 16, 8);
       case 4096: return P64(4096, 16, 1, false, 1, 16, 16, 16);
     }
   } else if (d.tw_hi && d.out_es == 1 && d.mode == MODE_C2C && !d.tr_dir && d.n >= 64 && variant != 9) {
@@ -105,7 +120,7 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
         // (tools/cols_variant_probe.py, profiles/r06_cols_t32_probe.txt): (256,256,256) axis 1 0.105 -> 0.094 ms, axis 0 0.114 -> 0.102 ms,
         // (1024,256,1024) axis 1 1.704 -> 1.523 ms, (256,1024,1024) axis 0 1.799 -> 1.641 ms.  (64 columns on 512 threads: 1.450 ms on the
         // third case, slower than the default on the first; the default's radices on 32 columns: slower everywhere.)
-        if (variant == 0 && d.inner % 32 == 0) return P64F(256, 32, 32, true, 2, 8 | 3, 32, 8);
+        if (variant == 0 && d.inner % 32 == 0 && 2.0 * (double)d.batch * 256 * 16 >= 268435456.0) return P64F(256, 32, 32, true, 2, 8 | 3, 32, 8);      // (non-temporal: arrays beyond the Infinity Cache)
         switch (variant) {
           default: return P64F(256, 8, 16, true, 1, 8, 8, 8, 4);
           case 21: return P64F(256, 32, 32, true, 2, 8 | 3, 32, 8);

@@ -37,7 +37,8 @@ static hipError_t launch_half_f32(const PassDesc &d, int variant, const void *in
         // 1.726 ms on two boxes, c2r 1.715 / 1.711 -> 1.688 / 1.675 ms; 2 rows level with 4, 8 rows level with 1.  ONE exchange (32 values per
         // thread, radices 32 x 32, 2 or 8 rows) -- what pays on the strided tiles -- LOSES 2-4 % here: a row's exchanges stay inside its wave and
         // cost no barrier, the 190-220 VGPRs cost occupancy.  Other lengths (1024 and 4096 reals per row): every row count within 2 % of the
-        // table's (tools/real_rows_variant_probe.py, profiles/r06_real_rows_probe.txt).  variant 1 = one row per wave.
+        // table's (tools/real_rows_variant_probe.py, profiles/r06_real_rows_probe.txt).  Non-temporal loads and stores -- a gain of 4-10 % on the
+        // COMPLEX row passes -- are level to worse here (1024 reals per row: r2c 1.744 -> 1.960 ms).  variant 1 = one row per wave.
         default: return H32(MODE, 1024, 16, 4, 16, 16, 4);
         case 1: return H32(MODE, 1024, 16, 1, 16, 16, 4);
 #ifdef GFFT_VARIANTS

@@ -12,6 +12,7 @@ dt = sys.argv[1]
 values = [int(v) for v in sys.argv[2].split(',')]
 prec, cdt, isz = (8, torch.complex128, 16) if dt == 'D' else (4, torch.complex64, 8)
 print(torch.cuda.get_device_name(0), dt)
+OPT = os.environ.get("PROBE_OPT", "variant_cols")
 for case in sys.argv[3:]:
     shp, ax = case.split(':')
     shape = [int(x) for x in shp.split('x')]
@@ -20,9 +21,9 @@ for case in sys.argv[3:]:
     b = torch.empty_like(a)
     plans = {}
     for v in values:
-        _lib.set_option('variant_cols', v)
+        _lib.set_option(OPT, v)
         plans[v] = eng.plan_create(shape, shape, [int(ax)], -1, prec)
-    _lib.set_option('variant_cols', 0)
+    _lib.set_option(OPT, 0)
     tot = {v: [] for v in values}
     for rnd in range(5):
         for v in values:
