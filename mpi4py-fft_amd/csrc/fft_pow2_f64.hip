@@ -109,6 +109,11 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
     }
   } else {
     // strided axis: 16 adjacent columns = 256-byte segments wherever the thread budget allows
+    // Round 6: the non-temporal streams of the n = 512 / 1024 defaults cost 20-27 % where rows do not start on 128-byte lines and the stride is near
+    // ((256,1024,513) axis 1 -- a stage of a real transform on several GPUs -- 1.221 against 0.958 ms, (512,512,513) axis 1 1.324 against 1.107 ms;
+    // far strides and 520-wide rows: ahead by 2-3 % as everywhere else, profiles/r06_cols_nt_probe.txt): such passes take the plain streams.
+    const bool odd_rows = (d.in_es * 16) % 128 != 0 || (d.out_es * 16) % 128 != 0;
+    const bool odd_near = odd_rows && d.in_es < 65536 && d.out_es < 65536;
     switch (d.n) {
       case 16: return P64F(16, 4, 16, true, 1, 8, 4, 4);
       case 32: return P64F(32, 8, 16, true, 1, 8, 8, 4);
@@ -120,7 +125,7 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
         // (tools/cols_variant_probe.py, profiles/r06_cols_t32_probe.txt): (256,256,256) axis 1 0.105 -> 0.094 ms, axis 0 0.114 -> 0.102 ms,
         // (1024,256,1024) axis 1 1.704 -> 1.523 ms, (256,1024,1024) axis 0 1.799 -> 1.641 ms.  (64 columns on 512 threads: 1.450 ms on the
         // third case, slower than the default on the first; the default's radices on 32 columns: slower everywhere.)
-        if (variant == 0 && d.inner % 32 == 0 && 2.0 * (double)d.batch * 256 * 16 >= 268435456.0) return P64F(256, 32, 32, true, 2, 8 | 3, 32, 8);      // (non-temporal: arrays beyond the Infinity Cache)
+        if (variant == 0 && d.inner % 32 == 0 && !odd_rows && 2.0 * (double)d.batch * 256 * 16 >= 268435456.0) return P64F(256, 32, 32, true, 2, 8 | 3, 32, 8);      // (non-temporal: arrays beyond the Infinity Cache)
         switch (variant) {
           default: return P64F(256, 8, 16, true, 1, 8, 8, 8, 4);
           case 21: return P64F(256, 32, 32, true, 2, 8 | 3, 32, 8);
@@ -131,7 +136,9 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
         // (fft_fused_f64.hip Fused512T32): (512,512,512) axis 1 0.831 -> 0.730 ms, (256,512,512) axis 1 0.406 -> 0.387 ms,
         // (1024,512,1024) axis 1 3.190 -> 2.828 ms.  On FAR strides (axis 0) the same tile LOSES 8 %: (512,512,512) axis 0 0.800 -> 0.865 ms,
         // (512,256,512) 0.391 -> 0.423 ms -- they keep 16 columns on 256 threads, two workgroups per CU (profiles/r06_cols_t32_probe.txt).
-        if (variant == 0 && d.inner % 32 == 0 && d.in_es < 65536 && d.out_es < 65536) return P64F(512, 32, 32, true, 2, 8 | 3, 32, 16);
+        if (variant == 0 && d.inner % 32 == 0 && !odd_rows && d.in_es < 65536 && d.out_es < 65536) return P64F(512, 32, 32, true, 2, 8 | 3, 32, 16);
+        // (... and rows that do NOT start on 128-byte lines -- 513-wide half spectra -- on near strides: the plain streams of variant 15, below)
+        if (variant == 0 && odd_near) return P64F(512, 32, 16, true, 2, 8, 32, 16);
         switch (variant) {
           case 21: return P64F(512, 32, 32, true, 2, 8 | 3, 32, 16);
           // R4: 32 values per thread, radices 32 x 16 = ONE exchange, 256 threads on 16 columns (two workgroups per CU),
@@ -146,6 +153,7 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
 #endif
         }
       case 1024:
+        if (variant == 0 && odd_near) return P64F(1024, 32, 16, true, 2, 8, 32, 32);
         switch (variant) {
           // R4: 32 values per thread, radices 32 x 32 = ONE exchange, 512 threads (<= 256 VGPRs: 181), non-temporal loads
           // and stores.  Against the former default (17): the stand-alone pass of the complex 3-D schedule 6.62 -> 6.45 ms
@@ -168,7 +176,12 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
           case 14: return P64F(1024, 16, 16, true, 4, 8 | 3, 16, 16, 4);   // non-temporal loads and stores
 #endif
         }
-      case 2048: return P64F(2048, 16, 8, true, 4, 8, 16, 16, 8);
+      case 2048:
+        // (round 6: non-temporal streams as at n = 512 / 1024 where rows start on 128-byte lines: (2048,256,512) axis 0 2.699 -> 2.300 ms, (256,2048,512)
+        // axis 1 1.923 -> 1.876 ms; 513-wide rows lose with them, fft_pow2_f32.hip)
+        if (variant == 0 && (d.in_es * 16) % 128 == 0 && (d.out_es * 16) % 128 == 0 && d.inner % 8 == 0 && 2.0 * (double)d.batch * 2048 * 16 >= 268435456.0)
+          return P64F(2048, 16, 8, true, 4, 8 | 3, 16, 16, 8);
+        return P64F(2048, 16, 8, true, 4, 8, 16, 16, 8);
       case 4096: return P64F(4096, 16, 4, true, 4, 8, 16, 16, 16);
     }
   }
