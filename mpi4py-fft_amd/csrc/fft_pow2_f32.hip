@@ -115,15 +115,13 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
         // per butterfly of complex128: the exchange phase is what complex64 tiles wait on, and this halves it.  Plans
         // alternating on the same arrays (tools/cols_variant_probe.py, profiles/r06_cols_t32_probe.txt): (256,256,256) axis 1 / 0
         // 0.068 / 0.065 -> 0.058 / 0.058 ms, (1024,256,1024) axis 1 0.893 -> 0.796 ms, (256,1024,1024) axis 0 1.126 -> 0.836 ms.
-        // (64 columns: 21 / 23 below, behind except on the smallest array.)  Odd widths keep the three-stage tile: see n = 512.
+        // (64 columns on 512 or 1024 threads: measured behind except on the smallest array.)  Odd widths keep the three-stage tile: see n = 512.
         // Inside one-rank 3-D schedules (plan_fused3 asks for variant 2 there) too: 256^3 c64 per step 0.363 -> 0.320 ms; the n = 512 lines of
         // such schedules keep variant 2 (512^3 c64: 2.442 ms against 2.547 with this tile shape).
         if ((variant == 0 || variant == 2) && d.inner % 32 == 0 && (d.in_es * 8) % 128 == 0 && (d.out_es * 8) % 128 == 0 && 2.0 * (double)d.batch * 256 * 8 >= 268435456.0) return P32F(256, 32, 32, true, true, 2, 8 | 3, 32, 8);      // (non-temporal: arrays beyond the Infinity Cache)
         switch (variant) {
           default: return P32F(256, 8, 32, true, false, 1, 8, 8, 8, 4);
-          case 21: return P32F(256, 32, 64, true, true, 2, 8 | 3, 32, 8);     // R6 A/B: one exchange, 64 columns = 512-byte segments, 512 threads
-          case 22: return P32F(256, 32, 32, true, true, 2, 8 | 3, 32, 8);     // ... 32 columns, 256 threads
-          case 23: return P32F(256, 16, 64, true, true, 1, 8 | 3, 16, 16);    // 16 values per thread, 64 columns, 1024 threads
+          case 22: return P32F(256, 32, 32, true, true, 2, 8 | 3, 32, 8);     // (the automatic choice above, whatever the array: for A/B)
 #ifdef GFFT_VARIANTS
           case 1: return P32(256, 16, 16, true, false, 1, 16, 16);
 #endif
@@ -132,12 +130,11 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
         // Round 6: 32 values per thread = ONE exchange (radices 32 x 16), 32 columns, 512 threads: (512,512,512) axis 1 / 0 0.500 / 0.588 ->
         // 0.435 / 0.449 ms, (1024,512,1024) axis 1 1.862 -> 1.795 ms, (512,1024,1024) axis 0 2.409 -> 2.080 ms -- where rows are whole
         // multiples of the tile.  On 513-wide rows (the half spectra of real transforms) it LOSES: (2048,512,513) axis 1 2.353 -> 2.936 ms.
-        // (64 columns = 512-byte segments on 1024 threads, 21: behind the default everywhere.)
+        // (64 columns = 512-byte segments on 1024 threads: measured behind the default everywhere.)
         if (variant == 0 && d.inner % 32 == 0 && (d.in_es * 8) % 128 == 0 && (d.out_es * 8) % 128 == 0 && 2.0 * (double)d.batch * 512 * 8 >= 268435456.0) return P32F(512, 32, 32, true, true, 2, 8 | 3, 32, 16);
         switch (variant) {
           default: return P32F(512, 16, 32, true, true, 1, 8, 16, 8, 4);
-          case 21: return P32F(512, 32, 64, true, true, 1, 8 | 3, 32, 16);    // R6 A/B: one exchange, 64 columns = 512-byte segments, 1024 threads
-          case 22: return P32F(512, 32, 32, true, true, 2, 8 | 3, 32, 16);    // ... 32 columns, 512 threads
+          case 22: return P32F(512, 32, 32, true, true, 2, 8 | 3, 32, 16);    // (the automatic choice above, whatever the array: for A/B)
 #ifdef GFFT_VARIANTS
           case 1: return P32(512, 8, 16, true, true, 1, 8, 8, 8);
 #endif

@@ -128,7 +128,7 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
         if (variant == 0 && d.inner % 32 == 0 && !odd_rows && 2.0 * (double)d.batch * 256 * 16 >= 268435456.0) return P64F(256, 32, 32, true, 2, 8 | 3, 32, 8);      // (non-temporal: arrays beyond the Infinity Cache)
         switch (variant) {
           default: return P64F(256, 8, 16, true, 1, 8, 8, 8, 4);
-          case 21: return P64F(256, 32, 32, true, 2, 8 | 3, 32, 8);
+          case 21: return P64F(256, 32, 32, true, 2, 8 | 3, 32, 8);      // (the automatic choice above, whatever the array: for A/B)
         }
       case 512:
         // Round 6: on NEAR strides (the line's entries less than 2^16 elements apart: axis 1 of a 3-D array) 32 columns = 512-byte
@@ -140,7 +140,7 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
         // (... and rows that do NOT start on 128-byte lines -- 513-wide half spectra -- on near strides: the plain streams of variant 15, below)
         if (variant == 0 && odd_near) return P64F(512, 32, 16, true, 2, 8, 32, 16);
         switch (variant) {
-          case 21: return P64F(512, 32, 32, true, 2, 8 | 3, 32, 16);
+          case 21: return P64F(512, 32, 32, true, 2, 8 | 3, 32, 16);     // (the automatic choice above, whatever the array: for A/B)
           // R4: 32 values per thread, radices 32 x 16 = ONE exchange, 256 threads on 16 columns (two workgroups per CU),
           // non-temporal loads and stores.  Against the former default (17), same box: (512,512,512) axis 1 0.85-0.88 -> 0.79 ms,
           // axis 0 0.95 -> 0.83 ms; the C3 stage (512,256,512) axis 0 0.47-0.48 -> 0.40 ms, (256,512,512) axis 1 0.42 ->
