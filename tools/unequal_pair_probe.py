@@ -2,7 +2,10 @@
 """Developer probe: the fused pairs on planes of 512 x 1024 / 1024 x 512 points (option fuse2_mixed) against the same plans
 as stand-alone launches -- plans alternating on the SAME arrays, 5 rounds x 10 executions.
   one-rank 3-D transforms of non-cubic arrays (pair = [axis 0 -> rows of axis 2]) and the local pair of a slab
-  (gfft_plan_create_guru2, blocks of the strided axis on the buffer side: forward out, backward in)."""
+  (gfft_plan_create_guru2, blocks of the strided axis on the buffer side: forward out, backward in).
+usage: unequal_pair_probe.py            the unequal pairs (option fuse2_mixed 0 / 1)
+       unequal_pair_probe.py n512       the square complex128 n = 512 pair on 16- against 32-line tiles (fuse2_n512 1 / 2)
+       unequal_pair_probe.py f32n512    the complex64 n = 512 pair against two launches (fuse2_f32_n512 0 / 1)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -63,7 +66,7 @@ else:
     SHAPES = [(512, 512, 1024), (512, 1024, 1024), (1024, 512, 512), (1024, 1024, 512), (512, 1024, 512), (1024, 512, 1024)]
     SLABS = [(256, 512, 1024, 2), (128, 512, 1024, 8), (256, 1024, 512, 2), (128, 1024, 512, 8)]
 
-for shape in SHAPES + 0 * [(512, 512, 1024), (512, 1024, 1024), (1024, 512, 512), (1024, 1024, 512), (512, 1024, 512), (1024, 512, 1024)]:
+for shape in SHAPES:
     a = torch.empty(shape, dtype=CDT, device='cuda')
     torch.view_as_real(a).normal_()
     b = torch.empty_like(a)
