@@ -102,7 +102,8 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
     // axis 1 0.990 -> 0.953 ms, (2048,512,512) axis 0 -- the slower twin of config C5's last stage -- 2.997 -> 2.780 ms, (512,2048,512) axis 1
     // 2.098 -> 2.027 ms.  On 513-wide rows the same streams cost up to 65 % ((512,2048,513) axis 1 2.72 -> 4.48 ms: partial lines written
     // around the cache): they keep the plain ones (profiles/r06_cols_nt_probe.txt).
-    const bool nt_ok = (d.in_es * 8) % 128 == 0 && (d.out_es * 8) % 128 == 0 && d.inner % 16 == 0 && 2.0 * (double)d.batch * d.n * 8 >= 268435456.0;
+    const bool whole = strided_lines_whole(d, 8);
+    const bool nt_ok = whole && d.inner % 16 == 0 && 2.0 * (double)d.batch * d.n * 8 >= 268435456.0;
     // plain c2c along a strided axis: 32 adjacent columns = 256-byte segments up to n = 512
     // (measured on (2048,512,1024) c64: 3.88 -> 3.35 ms; n = 256: 3.53 -> 3.37 ms).
     switch (d.n) {
@@ -118,7 +119,7 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
         // (64 columns on 512 or 1024 threads: measured behind except on the smallest array.)  Odd widths keep the three-stage tile: see n = 512.
         // Inside one-rank 3-D schedules (plan_fused3 asks for variant 2 there) too: 256^3 c64 per step 0.363 -> 0.320 ms; the n = 512 lines of
         // such schedules keep variant 2 (512^3 c64: 2.442 ms against 2.547 with this tile shape).
-        if ((variant == 0 || variant == 2) && d.inner % 32 == 0 && (d.in_es * 8) % 128 == 0 && (d.out_es * 8) % 128 == 0 && 2.0 * (double)d.batch * 256 * 8 >= 268435456.0) return P32F(256, 32, 32, true, true, 2, 8 | 3, 32, 8);      // (non-temporal: arrays beyond the Infinity Cache)
+        if ((variant == 0 || variant == 2) && d.inner % 32 == 0 && whole && 2.0 * (double)d.batch * 256 * 8 >= 268435456.0) return P32F(256, 32, 32, true, true, 2, 8 | 3, 32, 8);      // (non-temporal: arrays beyond the Infinity Cache)
         switch (variant) {
           default: return P32F(256, 8, 32, true, false, 1, 8, 8, 8, 4);
           case 22: return P32F(256, 32, 32, true, true, 2, 8 | 3, 32, 8);     // (the automatic choice above, whatever the array: for A/B)
@@ -131,7 +132,7 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
         // 0.435 / 0.449 ms, (1024,512,1024) axis 1 1.862 -> 1.795 ms, (512,1024,1024) axis 0 2.409 -> 2.080 ms -- where rows are whole
         // multiples of the tile.  On 513-wide rows (the half spectra of real transforms) it LOSES: (2048,512,513) axis 1 2.353 -> 2.936 ms.
         // (64 columns = 512-byte segments on 1024 threads: measured behind the default everywhere.)
-        if (variant == 0 && d.inner % 32 == 0 && (d.in_es * 8) % 128 == 0 && (d.out_es * 8) % 128 == 0 && 2.0 * (double)d.batch * 512 * 8 >= 268435456.0) return P32F(512, 32, 32, true, true, 2, 8 | 3, 32, 16);
+        if (variant == 0 && d.inner % 32 == 0 && whole && 2.0 * (double)d.batch * 512 * 8 >= 268435456.0) return P32F(512, 32, 32, true, true, 2, 8 | 3, 32, 16);
         switch (variant) {
           default: return P32F(512, 16, 32, true, true, 1, 8, 16, 8, 4);
           case 22: return P32F(512, 32, 32, true, true, 2, 8 | 3, 32, 16);    // (the automatic choice above, whatever the array: for A/B)

@@ -112,7 +112,7 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
     // Round 6: the non-temporal streams of the n = 512 / 1024 defaults cost 20-27 % where rows do not start on 128-byte lines and the stride is near
     // ((256,1024,513) axis 1 -- a stage of a real transform on several GPUs -- 1.221 against 0.958 ms, (512,512,513) axis 1 1.324 against 1.107 ms;
     // far strides and 520-wide rows: ahead by 2-3 % as everywhere else, profiles/r06_cols_nt_probe.txt): such passes take the plain streams.
-    const bool odd_rows = (d.in_es * 16) % 128 != 0 || (d.out_es * 16) % 128 != 0;
+    const bool odd_rows = !strided_lines_whole(d, 16);
     const bool odd_near = odd_rows && d.in_es < 65536 && d.out_es < 65536;
     switch (d.n) {
       case 16: return P64F(16, 4, 16, true, 1, 8, 4, 4);
@@ -179,7 +179,7 @@ hipError_t launch_pow2_f64(const PassDesc &d, bool cols, int variant, const void
       case 2048:
         // (round 6: non-temporal streams as at n = 512 / 1024 where rows start on 128-byte lines: (2048,256,512) axis 0 2.699 -> 2.300 ms, (256,2048,512)
         // axis 1 1.923 -> 1.876 ms; 513-wide rows lose with them, fft_pow2_f32.hip)
-        if (variant == 0 && (d.in_es * 16) % 128 == 0 && (d.out_es * 16) % 128 == 0 && d.inner % 8 == 0 && 2.0 * (double)d.batch * 2048 * 16 >= 268435456.0)
+        if (variant == 0 && !odd_rows && d.inner % 8 == 0 && 2.0 * (double)d.batch * 2048 * 16 >= 268435456.0)
           return P64F(2048, 16, 8, true, 4, 8 | 3, 16, 16, 8);
         return P64F(2048, 16, 8, true, 4, 8, 16, 16, 8);
       case 4096: return P64F(4096, 16, 4, true, 4, 8, 16, 16, 16);

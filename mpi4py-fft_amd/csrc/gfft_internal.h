@@ -150,6 +150,20 @@ hipError_t launch_generic(const PassDesc &d, const Factors &f, int precision, co
 // max transform length the generic LDS kernel accepts for this precision
 int generic_max_n(int precision);
 
+// A strided (COLS) pass touches its 128-byte lines WHOLE on both sides: entries of a column, rows (m), outer slabs (o) and the blocks of an all-to-all
+// buffer are whole lines apart (adjacent columns are adjacent elements; tile-major and flat layouts are aligned by construction).  What decides
+// between non-temporal and plain streams: write-around stores of PARTIAL lines cost up to 65 % (profiles/r06_cols_nt_probe.txt) -- also where only
+// the ROW pitch is odd (a 513-wide natural array behind a 512-column body: the far stage of config C5's odd rank column, 2.29 -> 2.44 ms).
+inline bool strided_lines_whole(const PassDesc &d, int esz) {
+  auto ok = [&](int64_t s) { return (s * esz) % 128 == 0; };
+  if (!ok(d.in_es) || !ok(d.out_es)) return false;
+  const int64_t rows = d.mid * d.inner > 0 ? d.batch / (d.mid * d.inner) : 1;
+  if (d.mid > 1 && !d.flat && (!ok(d.in_ms) || !ok(d.out_ms))) return false;
+  if (rows > 1 && (!ok(d.in_os) || !ok(d.out_os))) return false;
+  if ((d.in_lgp && !ok(d.in_jump)) || (d.out_lgp && !ok(d.out_jump))) return false;
+  return true;
+}
+
 // fast power-of-two kernels; returns false if (n, precision) has no instantiation
 bool pow2_supported_f64(int n);
 bool pow2_supported_f32(int n);
