@@ -148,6 +148,9 @@ hipError_t launch_pow2_f32(const PassDesc &d, bool cols, int variant, const void
       case 1024:
         switch (variant) {
           case 0: if (nt_ok) return P32F(1024, 32, 32, true, true, 1, 8 | 3, 16, 16, 4);      // (falls through to the plain streams otherwise)
+          // (R6, measured and NOT kept: ONE exchange -- radices 32 x 32 -- on 16 columns = 128-byte segments, 512 threads of 182 VGPRs, two workgroups per CU,
+          // non-temporal: near strides -2 ... -3.5 % ((256,1024,1024) axis 1 0.972 -> 0.938 ms), far strides +13 ... +15 % ((1024,256,1024) axis 0 1.058 -> 1.212 ms):
+          // where the exchange halves, the segment width costs more)
           default: return P32F(1024, 32, 32, true, true, 1, 8, 16, 16, 4);
 #ifdef GFFT_VARIANTS
           case 1: return P32(1024, 16, 16, true, true, 1, 16, 16, 4);
