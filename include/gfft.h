@@ -192,7 +192,8 @@ int gfft_plan_create_guru_padded(gfft_plan *plan, int precision, int kind, const
  *     At most one side takes blocks.
  * kind: GFFT_C2C_FORWARD / _BACKWARD; gfft_execute's d_in / d_out are the addresses of element 0 and must not
  * overlap unless both sides have the same natural layout; the input is preserved otherwise.  Where the pair has
- * no fused kernels (lengths other than 512 / 1024 in fp64, 1024 in fp32; too few planes for a hand-off ring) the
+ * no fused kernels (planes other than 512 / 1024 points a side in fp64 -- equal or not --, 512 x 512 / 1024 x 1024 in fp32;
+ * rows-first order outside the square fp64 / 1024 x 1024 fp32 pairs; too few planes for a hand-off ring) the
  * plan runs two stand-alone passes -- the first one carries the data across, the second works in place on the
  * output -- with the same results up to nothing: the arithmetic of a pass does not depend on its launch form.
  * GFFT_ERR_UNSUPPORTED when a length has no single-pass register kernel or the block count does not fit. */
